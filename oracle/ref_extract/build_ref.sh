@@ -1,0 +1,91 @@
+#!/bin/sh
+# TEST INFRASTRUCTURE -- builds oracle/_ref/libcnf2ref.so: the reference's OWN
+# hot-path code, compiled from where it lies under /root/reference, driven by
+# ref_driver.inc (our code).  Follows SURVEY.md section 8(c).
+#
+# The whole reference is NOT buildable here (Boost, xstd/bit_set.hpp and toulbar2
+# are absent, cnF2freq.cpp:49-89,142-144), so the translation unit is assembled
+# by LINE RANGE from cnF2freq.cpp into a temp dir outside the repository,
+# compiled, and deleted.  No reference text enters /root/repo; only the shared
+# object lands in oracle/_ref/ (git-ignored, travels with gpurun).
+#
+# Disclosure (DESIGN.md "Oracle"): two container names the extract mentions
+# (boost flat_map / the small_map alias of cpp:367) are aliased to std::map in
+# the prelude below, exactly as SURVEY.md section 8(c) prescribes; on the sweep
+# path they are only iterated in sorted order (relmap in ignoreflag2), which
+# std::map preserves.  _isnan/_finite are the reference's own gcc mapping
+# (cpp:135-138).
+set -e
+REF=${CNF2_REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT="$HERE/../_ref"
+if [ ! -f "$REF/cnF2freq.cpp" ]; then
+    echo "reference tree not present at $REF: keeping any prebuilt oracle/_ref" >&2
+    exit 0
+fi
+TMP=$(mktemp -d /tmp/cnf2ref.XXXXXX)
+trap 'rm -rf "$TMP"' EXIT
+SRC="$REF/cnF2freq.cpp"
+TU="$TMP/tu.cpp"
+r() { sed -n "$1,$2p" "$SRC" >> "$TU"; }
+
+cat > "$TU" <<'EOF'
+#include <vector>
+#include <string.h>
+#include <stdio.h>
+#include <omp.h>
+#include <limits>
+#include <array>
+#include <memory>
+#include <string>
+#include <iostream>
+#include <errno.h>
+#include <assert.h>
+#include <stdlib.h>
+#include <set>
+#include <algorithm>
+#include <math.h>
+#include <cmath>
+#include <type_traits>
+#include <map>
+#include <float.h>
+#include <numeric>
+#include <utility>
+#include <unistd.h>
+using namespace std;
+#define _isnan isnan
+#define _finite isfinite
+template<class K, class V> using flat_map = std::map<K, V>;
+EOF
+r 33 44
+echo '#include "settings.h"' >> "$TU"
+r 146 147
+r 156 160
+r 171 239
+r 303 353
+echo 'template<class K, class T, int N = 2> using small_map = std::map<K, T>;' >> "$TU"
+r 372 380
+r 392 394
+r 397 403
+r 407 407
+r 411 412
+r 414 418
+r 423 424
+r 434 475
+r 485 571
+r 575 795
+r 834 850
+r 853 2445
+r 2448 2514
+r 3099 3187
+r 3462 3496
+r 3553 3570
+echo "#include \"$HERE/ref_driver.inc\"" >> "$TU"
+
+mkdir -p "$OUT"
+g++ -std=c++20 -O2 -ffast-math -fopenmp -DDOEXTERNFORGCC -fPIC -shared -w \
+    -I"$REF" -o "$OUT/libcnf2ref.so" "$TU"
+# IEEE build (no -ffast-math) for bit-level comparisons with the C restatement
+g++ -std=c++20 -O2 -fopenmp -DDOEXTERNFORGCC -fPIC -shared -w \
+    -I"$REF" -o "$OUT/libcnf2ref_ieee.so" "$TU"
+echo "built $OUT/libcnf2ref.so and libcnf2ref_ieee.so"
