@@ -1,0 +1,117 @@
+"""Generate tests/golden/*.npz from the reference's own hot-path code.
+
+Run in the build container only (needs oracle/_ref/libcnf2ref_ieee.so, built by
+oracle/ref_extract/build_ref.sh from /root/reference):
+
+    python tests/golden/make_golden.py
+
+Each fixture holds the inputs (pedigree arrays from cnf2freq_amd.synth with fixed
+seeds) and the reference's outputs for them -- data only, no reference text:
+  G1 emission  e(m,g,flag2,s) for sampled (g,flag2) incl. flag2=-1      (cpp:1380-1385)
+  G2 fwbw[s][m][0..2][64], fwbwfactors                                   (cpp:2074-2418)
+  G3 factors[8], factor                                                  (cpp:5375-5403)
+  G4/G7 dosage rows = sum of val by mapval (full fan-out)                (cpp:5406-5553)
+  G5 rawervals[turn][s] for sampled markers                              (cpp:5686-5752)
+  G6 fixtrees outputs, founder flags, ignoreflag2 samples                (cpp:3099-3187,3462-3496)
+  G7 mapval(g,flag2,s) samples                                           (cpp:5511-5512)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_STACKSIZE", "128M")
+
+from cnf2freq_amd import synth  # noqa: E402
+from oracle.ref_extract.pyref import RefPed  # noqa: E402
+
+CASES = {
+    # name: (constructor, kwargs)
+    "f2_implicit_f1": (synth.make_f2, dict(n_ind=4, markers_per_chrom=23, n_chrom=1, seed=12345,
+                                           chrom_cm=40.0, missing=0.1)),
+    "outbred3_missing": (synth.make_outbred3, dict(n_fam=2, kids_per_fam=2, markers_per_chrom=15,
+                                                   seed=777, missing=0.2, random_hw=True,
+                                                   random_sure=True)),
+    "random_windows": (synth.make_random_windows, dict(n_windows=24, n_markers=6, seed=4242)),
+}
+
+
+def ped_inputs(ped):
+    return dict(par=ped.par, gen=ped.gen, empty=ped.empty, row_of=ped.row_of, allele=ped.allele,
+                sure=ped.sure, hw=ped.hw, pos=ped.pos, chromstarts=ped.chromstarts, dous=ped.dous)
+
+
+def generate(name):
+    ctor, kw = CASES[name]
+    ped = ctor(**kw)
+    R = RefPed(ped, ieee=True)
+    rs = np.random.RandomState(99)
+    out = {"in_" + k: v for k, v in ped_inputs(ped).items()}
+    out["founder"] = R.founder()
+    M = ped.n_markers
+    n = len(ped.dous)
+    fix = np.zeros((n, 2), np.int32)
+    rel = np.full((n, 7, 3), -1, np.int32)
+    ordered = np.zeros((n, 7), np.int32)
+    factors = np.zeros((n, 8))
+    factor = np.zeros(n)
+    ok = np.zeros(n, np.uint8)
+    fwbw = np.zeros((n, 8, M, 3, 64))
+    fwbwf = np.zeros((n, 8, M, 3))
+    dosage = np.zeros((n, M, 3))
+    turn_markers = np.array(sorted(set([0, M // 2, M - 1])), np.int32)
+    rawer = np.full((n, len(turn_markers), 128, 8), np.nan)
+    em_idx, em_val, mv_idx, mv_val, ig_idx, ig_val = [], [], [], [], [], []
+    for j, ind in enumerate(ped.dous):
+        ind = int(ind)
+        gen = int(ped.gen[ind])
+        t = R.fixtrees(ind)
+        fix[j] = (t["shiftignore"], t["flag2ignore"])
+        rel[j, :len(t["rel"])] = t["rel"]
+        ordered[j] = t["ordered"]
+        r = R.sweep(ind, gen)
+        factors[j], factor[j], ok[j] = r["factors"], r["factor"], r["ok"]
+        fwbw[j], fwbwf[j] = r["fwbw"], r["fwbwfactors"]
+        shiftend = 8 if gen >= 2 else 2
+        if r["ok"]:
+            dosage[j] = R.dosage_rows(M)
+            for ti, m in enumerate(turn_markers):
+                for turn in range(128):
+                    if turn & (t["flag2ignore"] >> 1):
+                        continue
+                    for s in range(shiftend):
+                        if s & t["shiftignore"]:
+                            continue
+                        rawer[j, ti, turn, s] = R.turn_query(int(m), turn, s, -50000 + r["factor"]) - r["factor"]
+        for m in range(M):
+            for s in range(8):
+                for g in rs.choice(64, 3, replace=False):
+                    for f2 in [-1] + list(rs.choice(128, 3)):
+                        em_idx.append((ind, m, int(g), int(f2), s))
+                        em_val.append(R.emission(ind, m, int(g), int(f2), s))
+                        if f2 >= 0:
+                            mv_idx.append((ind, m, int(g), int(f2), s))
+                            mv_val.append(R.mapval(ind, m, int(g), int(f2), s)[0])
+                            ig_idx.append((j, m, int(g), int(f2), s))
+                            # relmap of the last fixtrees belongs to this individual after sweep()
+                            ig_val.append(0)
+        # ignoreflag2 uses the thread-private relmap left by the last fixtrees: re-run it
+        R.sweep(ind, gen, store=False)
+        for k in range(len(ig_idx) - M * 8 * 9, len(ig_idx)):
+            _, m, g, f2, s = ig_idx[k]
+            ig_val[k] = R.L.ref_ignoreflag2(f2, g, s, m)
+    out.update(fixtrees=fix, rel=rel, ordered=ordered, factors=factors, factor=factor, ok=ok,
+               fwbw=fwbw, fwbwfactors=fwbwf, dosage=dosage, turn_markers=turn_markers, rawervals=rawer,
+               em_idx=np.array(em_idx, np.int32), em_val=np.array(em_val),
+               mv_idx=np.array(mv_idx, np.int32), mv_val=np.array(mv_val, np.int32),
+               ig_idx=np.array(ig_idx, np.int32), ig_val=np.array(ig_val, np.uint8))
+    path = os.path.join(os.path.dirname(__file__), name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        generate(name)
