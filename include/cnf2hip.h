@@ -1,0 +1,135 @@
+/*
+ * cnf2hip.h -- C ABI of libcnf2hip.so, the MI355X (gfx950) implementation of
+ * cnF2freq's per-individual HMM forward-backward sweep.
+ *
+ * The reference has no FFI; its seam for this path is the in-process call
+ *   double individ::doanalyze<Turner,Stop>(tb, turner, startmark, endmark, stopdata,
+ *                                          flag2, ruleout, realprobs, minfactor)
+ * (cnF2freq.cpp:2122-2131) driven per individual by doit<> (cnF2freq.cpp:5294-5583),
+ * reading the global individ graph (cnF2freq.cpp:853-914, 2448-2514), markerposes /
+ * chromstarts / genrec (cnF2freq.cpp:233-239) and thread-private alpha/beta stores
+ * (cnF2freq.cpp:392-394).  This header is the batch form of that seam: the globals
+ * become explicit uploads, the OpenMP loop over `dous` becomes one call.
+ *
+ * Conventions: plain C types, caller-owned buffers, int status (0 = ok, <0 = error,
+ * message via cnf2_last_error).  Impossible data is reported in-band exactly like the
+ * reference: a log-likelihood <= CNF2_MINFACTOR (or NaN) means "skip this individual"
+ * (cnF2freq.cpp:1659, 5403); no exceptions, no abort.
+ * One context per GPU; a context is not thread-safe, distinct contexts are independent.
+ * The library fails loudly (CNF2_ERR_NO_DEVICE) when no HIP device is usable; there is
+ * no CPU fallback.
+ */
+#ifndef CNF2HIP_H
+#define CNF2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNF2_NUMTYPES   64      /* settings.h:27  inheritance states          */
+#define CNF2_NUMSHIFTS  8       /* settings.h:35  phase-shift modes           */
+#define CNF2_NUMPATHS   128     /* settings.h:32  allele-assignment paths     */
+#define CNF2_MINFACTOR  (-1e15f)/* settings.h:29                              */
+#define CNF2_IGNORED    (-1e30) /* factors[] value of a masked shift mode, cnF2freq.cpp:5378 */
+
+enum {
+    CNF2_OK            = 0,
+    CNF2_ERR_NO_DEVICE = -1,
+    CNF2_ERR_ARG       = -2,
+    CNF2_ERR_STATE     = -3,   /* call order violated (e.g. sweep before uploads) */
+    CNF2_ERR_HIP       = -4,
+    CNF2_ERR_NOMEM     = -5
+};
+
+/* cnf2_sweep flags */
+enum {
+    CNF2_OUT_DEVICE   = 1u << 0, /* output pointers are device pointers (no D2H copy, no sync) */
+    CNF2_NO_DOSAGE    = 1u << 1, /* HOT LOOP 1 only: factors/loglik, skip the per-locus rows    */
+    CNF2_RAW_DOSAGE   = 1u << 2, /* rows un-normalised (sum of val by class, cnF2freq.cpp:3523) */
+    CNF2_NO_TIES      = 1u << 3  /* drop ignoreflag2's all-or-none rule (cnF2freq.cpp:3484-3486) */
+};
+
+typedef struct cnf2_ctx cnf2_ctx;
+
+/* Library / device ------------------------------------------------------------ */
+int         cnf2_device_count(void);
+int         cnf2_ctx_create(int device, cnf2_ctx **out);
+void        cnf2_ctx_destroy(cnf2_ctx *ctx);
+const char *cnf2_last_error(const cnf2_ctx *ctx);           /* ctx may be NULL: last create error */
+const char *cnf2_version(void);
+
+/* Marker map: replaces markerposes / chromstarts / genrec
+ * (readalphamap cnF2freq.cpp:6669-6685; main cnF2freq.cpp:7927-7943).
+ * pos[n_markers] in cM; chromstarts[n_chrom+1] with chromstarts[n_chrom] == n_markers;
+ * genrec[3] (NULL = {-0.02,-0.02,-0.02}). */
+int cnf2_upload_map(cnf2_ctx *ctx, const double *pos, int n_markers, const int32_t *chromstarts,
+                    int n_chrom, const double *genrec);
+
+/* Genotype rows: replaces individ::markerdata / markersure / haploweight
+ * (cnF2freq.cpp:876-887; filled by readalphadata cnF2freq.cpp:6542-6667).
+ * Rows are de-duplicated storage; several individuals may share one row (all
+ * `empty` individuals normally share a blank row: alleles 0, sure 0, hw 0.5).
+ *   allele [n_rows][n_markers][2]  MarkerVal values 0 (unknown), 1, 2, 9
+ *   sure   [n_rows][n_markers][2]
+ *   hw     [n_rows][n_markers]
+ * cnf2_update_rows overwrites rows [row0,row0+n) between sweeps (the per-iteration
+ * parameter updates of cnF2freq.cpp:6344-6368 stay on the host). */
+int cnf2_upload_rows(cnf2_ctx *ctx, int n_rows, const uint8_t *allele, const double *sure,
+                     const double *hw);
+int cnf2_update_rows(cnf2_ctx *ctx, int row0, int n, const uint8_t *allele, const double *sure,
+                     const double *hw);
+
+/* Pedigree graph: replaces individer[] / individ::{pars,empty,gen} and `dous`
+ * (readalphaped cnF2freq.cpp:6495-6540).  par[n_rec][2] record index or -1;
+ * row_of[n_rec] row index; dous[n_dous] the analysed records in output order.
+ * The library derives, per analysed individual, what fixtrees (cnF2freq.cpp:3099-3187)
+ * produces: the 7-slot window, shiftignore, flag2ignore, founder flags (for every
+ * record, as postmarkerdata does, cnF2freq.cpp:3373-3389) and the groups of slots
+ * occupied by one ancestor (relmap). */
+int cnf2_upload_pedigree(cnf2_ctx *ctx, int n_rec, const int32_t *par, const uint8_t *empty,
+                         const int32_t *gen, const int32_t *row_of, const int32_t *dous,
+                         int n_dous);
+
+/* Window topology as derived by the library (parity hook for fixtrees):
+ * out[0]=shiftignore out[1]=flag2ignore out[2]=founder out[3..9]=slot records (-1 none)
+ * out[10..16]=tie group per slot (-1 = ancestor occupies a single slot). */
+int cnf2_window_info(cnf2_ctx *ctx, int ind, int32_t *out17);
+
+/* The sweep: per-individual body of doit<> (cnF2freq.cpp:5294-5403) plus the per-locus
+ * allele-2 dosage posterior row that genotypereporter accumulates (cnF2freq.cpp:5406-5553,
+ * 3532-3538) for analysed individuals [ind_begin, ind_end), every chromosome.
+ *   factors_out [n][n_chrom][8]  log-likelihood per shift mode (CNF2_IGNORED if masked)
+ *   loglik_out  [n][n_chrom]     logsumexp over modes; <= CNF2_MINFACTOR or NaN => skipped
+ *   dosage_out  [n][n_markers][3] posterior of 0/1/2 copies of allele 2, rows normalised
+ *                                (all-zero row for a skipped individual); may be NULL with
+ *                                CNF2_NO_DOSAGE
+ * With CNF2_OUT_DEVICE the three pointers are device pointers and the call only enqueues
+ * work on the context's stream (use cnf2_sync). */
+int cnf2_sweep(cnf2_ctx *ctx, int ind_begin, int ind_end, double *factors_out, double *loglik_out,
+               double *dosage_out, uint32_t flags);
+int cnf2_sync(cnf2_ctx *ctx);
+
+/* Parity/debug view of the alpha/beta store of one individual and chromosome in the
+ * reference's layout (cnF2freq.cpp:392-393): fwbw_out[8][mc][3][64] with slot 0 = alpha
+ * before emission, 1 = beta, 2 = alpha after emission; fwbwfactors_out[8][mc][3] the
+ * cumulative log scales; mc = markers on the chromosome.  Masked modes are left zero. */
+int cnf2_fwbw_store(cnf2_ctx *ctx, int ind, int chrom, double *fwbw_out, double *fwbwfactors_out);
+
+/* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
+ * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
+int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);
+
+/* Measurement support for bench.py: duration in ms of the kernels of the last cnf2_sweep
+ * measured with hipEvents on the context's stream (kernel_ms[0] = forward-backward kernel),
+ * and workspace bytes currently allocated on the device. */
+int    cnf2_last_kernel_ms(cnf2_ctx *ctx, float *kernel_ms, int n);
+size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
+void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNF2HIP_H */

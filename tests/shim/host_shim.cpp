@@ -1,0 +1,92 @@
+// Host build of the product's emission/window code for CPU unit tests
+// (tests/test_host_emission.py).  Compiled with g++ from the same headers the HIP
+// kernels include; contains no algorithmic code of its own beyond the lane loop.
+#include <string.h>
+
+#include "cnf2_lane.h"
+
+using namespace cnf2;
+
+static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                             const int32_t* row_of)
+{
+    HostPedigree P;
+    P.n_rec = n_rec;
+    P.par.assign(par, par + 2 * n_rec);
+    P.empty.assign(empty, empty + n_rec);
+    P.gen.assign(gen, gen + n_rec);
+    P.row_of.assign(row_of, row_of + n_rec);
+    derive_founders(P);
+    return P;
+}
+
+extern "C" {
+
+int shim_founders(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                  const int32_t* row_of, uint8_t* out)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    memcpy(out, P.founder.data(), n_rec);
+    return 0;
+}
+
+// out17: shiftignore, flag2ignore, founder, 7 slot records, 7 tie groups
+int shim_window(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                const int32_t* row_of, int rec, int32_t* out17)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    int32_t slot_rec[7];
+    derive_window(P, rec, &w, slot_rec);
+    out17[0] = w.shiftignore;
+    out17[1] = w.flag2ignore;
+    out17[2] = P.founder[rec];
+    for (int i = 0; i < 7; i++) {
+        out17[3 + i]  = slot_rec[i];
+        out17[10 + i] = w.tie[i];
+    }
+    return w.n_groups;
+}
+
+// All 64 table entries of (rec, marker) for tie combination `combo`:
+// tot[64], rtot[64], two[64] in lane order and c[f][s0] -> c4[f*2+s0].
+int shim_emtab(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+               const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+               int n_markers, int rec, int marker, int combo, double* tot, double* rtot, double* two,
+               double* c4)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    auto slot_at = [&](int row) {
+        size_t i = (size_t)row * n_markers + marker;
+        return unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    };
+    Slot root = slot_at(w.row[0]);
+    bool root_attop = w.flags[0] & SLOT_FOUNDER;
+    for (int lane = 0; lane < 64; lane++) {
+        LaneJob L;
+        make_lane(w, lane, &L);
+        RootTerms R;
+        root_terms(root, root_attop, L.f, &R);
+        if (root_attop) {
+            // root is the top of its single line (cnF2freq.cpp:1260-1271)
+            tot[lane] = rtot[lane] = 1.0;
+            two[lane] = (L.P == 0 && R.inmv0 == 2) ? 1.0 : 0.0;
+            continue;
+        }
+        LineTerms T;
+        line_terms(L.cfg, slot_at(L.row_par), slot_at(L.row_tr), slot_at(L.row_ot),
+                   L.P ? R.inmv1 : R.inmv0, L.P ? R.sv1 : R.sv0, L.P == 0 && R.inmv0 == 2, &T);
+        tot[lane] = line_total(T);
+        line_restricted(L.cfg, T, tie_force(L.tie_par, combo), tie_force(L.tie_tr, combo),
+                        tie_force(L.tie_ot, combo), &rtot[lane], &two[lane]);
+    }
+    for (int f = 0; f < 2; f++) {
+        RootTerms R;
+        root_terms(root, root_attop, f, &R);
+        for (int s0 = 0; s0 < 2; s0++) c4[f * 2 + s0] = R.cbase * phase_weight(root, f ^ s0);
+    }
+    return w.n_groups;
+}
+}

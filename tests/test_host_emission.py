@@ -1,0 +1,118 @@
+"""CPU suite: the product's emission/window code (cnf2freq_amd/csrc/cnf2_emission.h,
+cnf2_lane.h, cnf2_window.cpp -- the same headers the HIP kernels include) compiled for the
+host and compared with the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cnf2freq_amd import synth
+from conftest import ROOT, oracle_ped
+
+SHIM_DIR = os.path.join(ROOT, "tests", "shim")
+CSRC = os.path.join(ROOT, "cnf2freq_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(SHIM_DIR, "libcnf2hostshim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + CSRC, "-o", so,
+                           os.path.join(SHIM_DIR, "host_shim.cpp"), os.path.join(CSRC, "cnf2_window.cpp")])
+    return C.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ped_args(ped):
+    return [C.c_int(ped.n_rec), _p(ped.par), _p(ped.empty), _p(ped.gen), _p(ped.row_of)]
+
+
+def lane_index(P, f, sp, k):
+    return (P << 5) | (f << 4) | (sp << 3) | k
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_window_matches_fixtrees(shim, seed):
+    ped = synth.make_random_windows(40, 3, seed=seed)
+    o = oracle_ped(ped)
+    f = np.zeros(ped.n_rec, np.uint8)
+    shim.shim_founders(*_ped_args(ped), _p(f))
+    assert (f == o.founder).all()
+    for ind in ped.dous:
+        out = np.zeros(17, np.int32)
+        ng = shim.shim_window(*_ped_args(ped), int(ind), _p(out))
+        t = o.fixtrees(int(ind))
+        assert (out[0], out[1]) == (t.shiftignore, t.flag2ignore)
+        # tie groups == relmap entries with more than one bit
+        want = sorted(m for m in list(t.rel_map)[:t.n_rel] if bin(m).count("1") > 1)
+        got = sorted(sum(1 << i for i in range(7) if out[10 + i] == g) for g in range(ng))
+        assert got == want
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_table_entries_match_oracle(shim, seed):
+    ped = synth.make_random_windows(30, 4, seed=seed)
+    o = oracle_ped(ped)
+    tot, rtot, two, c4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    for ind in ped.dous:
+        ind = int(ind)
+        t = o.fixtrees(ind)
+        for m in range(ped.n_markers):
+            shim.shim_emtab(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
+                            ind, m, 0, _p(tot), _p(rtot), _p(two), _p(c4))
+            for s in range(8):
+                s0, s1, s2 = s & 1, (s >> 1) & 1, (s >> 2) & 1
+                T = o.emission_tables(ind, m, s, t.flag2ignore)
+                for f in range(2):
+                    np.testing.assert_allclose(c4[f * 2 + s0], T["c"][f], rtol=1e-15, atol=0)
+                    if T["c"][f] == 0:
+                        continue  # the oracle skips the recursion when the root term is zero
+                    for k in range(8):
+                        np.testing.assert_allclose(tot[lane_index(0, f, s1, k)], T["A"][f][k], rtol=4e-16, atol=0)
+                        np.testing.assert_allclose(tot[lane_index(1, f, s2, k)], T["B"][f][k], rtol=4e-16, atol=0)
+                # full emission e(g) from the lane table
+                for g in range(0, 64, 7):
+                    e = sum(c4[f * 2 + s0] * tot[lane_index(0, f, s1, g & 7)] * tot[lane_index(1, f, s2, g >> 3)]
+                            for f in range(2))
+                    np.testing.assert_allclose(e, o.emission(ind, m, g, -1, s), rtol=1e-14, atol=1e-300)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_restricted_class_split_reproduces_reference_rows(shim, seed):
+    """Row = sum over tie combos of the class-split restricted tables weighted by
+    alpha-minus * beta; must equal the reference-semantics fan-out (oracle mode 0)."""
+    ped = synth.make_random_windows(24, 3, seed=seed)
+    o = oracle_ped(ped)
+    tot, rtot, two, c4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    for ind in ped.dous:
+        ind = int(ind)
+        r = o.sweep_ind(ind, int(ped.gen[ind]), mode=0, keep_store=True)
+        if not r["ok"]:
+            continue
+        t = o.fixtrees(ind)
+        out = np.zeros(17, np.int32)
+        ng = shim.shim_window(*_ped_args(ped), ind, _p(out))
+        for m in range(ped.n_markers):
+            row = np.zeros(3)
+            for s in range(8):
+                if s & t.shiftignore or r["factor"] - r["factors"][s] > 40:
+                    continue
+                s0, s1, s2 = s & 1, (s >> 1) & 1, (s >> 2) & 1
+                w = (r["fwbw"][s, m, 0] * r["fwbw"][s, m, 1]
+                     * np.exp(r["fwbwfactors"][s, m, 0] + r["fwbwfactors"][s, m, 1] - r["factor"]))
+                for combo in range(1 << ng):
+                    shim.shim_emtab(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
+                                    ind, m, combo, _p(tot), _p(rtot), _p(two), _p(c4))
+                    for g in range(64):
+                        for f in range(2):
+                            la, lb = lane_index(0, f, s1, g & 7), lane_index(1, f, s2, g >> 3)
+                            a, a1, b, b1 = rtot[la], two[la], rtot[lb], two[lb]
+                            c = c4[f * 2 + s0]
+                            row[2] += w[g] * c * a1 * b1
+                            row[1] += w[g] * c * (a1 * (b - b1) + (a - a1) * b1)
+                            row[0] += w[g] * c * (a - a1) * (b - b1)
+            np.testing.assert_allclose(row, r["dosage"][m], rtol=1e-10, atol=1e-14)
