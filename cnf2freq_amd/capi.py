@@ -1,0 +1,191 @@
+"""ctypes binding of libcnf2hip.so (include/cnf2hip.h).
+
+This is the Python host mirror used by tests and bench.py; the reference's own host side
+is compiled C++, whose mirror is cnf2freq_amd/csrc/host (readers + CLI).  Everything that
+computes goes through the C ABI; there is no CPU fallback: if the shared library is
+missing or no HIP device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnf2hip.so")
+
+OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES = 1, 2, 4, 8
+MINFACTOR = float(np.float32(-1e15))
+IGNORED = -1e30
+
+# every symbol include/cnf2hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "cnf2_device_count", "cnf2_ctx_create", "cnf2_ctx_destroy", "cnf2_last_error", "cnf2_version",
+    "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_upload_pedigree",
+    "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_emission",
+    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
+]
+
+
+class Cnf2Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libcnf2hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Cnf2Error("libcnf2hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C cnf2freq_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.cnf2_device_count.restype = i32
+        L.cnf2_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.cnf2_ctx_destroy.argtypes = [vp]
+        L.cnf2_ctx_destroy.restype = None
+        L.cnf2_last_error.argtypes = [vp]
+        L.cnf2_last_error.restype = C.c_char_p
+        L.cnf2_version.restype = C.c_char_p
+        L.cnf2_upload_map.argtypes = [vp, vp, i32, vp, i32, vp]
+        L.cnf2_upload_rows.argtypes = [vp, i32, vp, vp, vp]
+        L.cnf2_update_rows.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.cnf2_upload_pedigree.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32]
+        L.cnf2_window_info.argtypes = [vp, i32, vp]
+        L.cnf2_sweep.argtypes = [vp, i32, i32, vp, vp, vp, C.c_uint32]
+        L.cnf2_sync.argtypes = [vp]
+        L.cnf2_fwbw_store.argtypes = [vp, i32, i32, vp, vp]
+        L.cnf2_emission.argtypes = [vp, i32, i32, vp]
+        L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
+        L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
+        L.cnf2_workspace_bytes.argtypes = [vp]
+        L.cnf2_workspace_bytes.restype = C.c_size_t
+        L.cnf2_stream.argtypes = [vp]
+        L.cnf2_stream.restype = vp
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU context (one per process/rank)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.cnf2_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise Cnf2Error("cnf2_ctx_create: %s" % self.L.cnf2_last_error(None).decode())
+        self.h = h
+        self.n_markers = self.n_chrom = self.n_ind = 0
+        self.chromstarts = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cnf2_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Cnf2Error("%s failed (%d): %s" % (what, rc, self.L.cnf2_last_error(self.h).decode()))
+
+    # -- uploads ---------------------------------------------------------------
+    def upload_map(self, pos, chromstarts, genrec=None):
+        pos = np.ascontiguousarray(pos, np.float64)
+        cs = np.ascontiguousarray(chromstarts, np.int32)
+        g = None if genrec is None else np.ascontiguousarray(genrec, np.float64)
+        self._chk(self.L.cnf2_upload_map(self.h, _p(pos), len(pos), _p(cs), len(cs) - 1,
+                                         None if g is None else _p(g)), "cnf2_upload_map")
+        self.n_markers, self.n_chrom, self.chromstarts = len(pos), len(cs) - 1, cs
+
+    def upload_rows(self, allele, sure, hw):
+        allele = np.ascontiguousarray(allele, np.uint8)
+        sure = np.ascontiguousarray(sure, np.float64)
+        hw = np.ascontiguousarray(hw, np.float64)
+        assert allele.shape == sure.shape == hw.shape + (2,) and hw.shape[1] == self.n_markers
+        self._chk(self.L.cnf2_upload_rows(self.h, hw.shape[0], _p(allele), _p(sure), _p(hw)), "cnf2_upload_rows")
+
+    def update_rows(self, row0, allele, sure, hw):
+        allele = np.ascontiguousarray(allele, np.uint8)
+        sure = np.ascontiguousarray(sure, np.float64)
+        hw = np.ascontiguousarray(hw, np.float64)
+        self._chk(self.L.cnf2_update_rows(self.h, row0, hw.shape[0], _p(allele), _p(sure), _p(hw)), "cnf2_update_rows")
+
+    def upload_pedigree(self, par, empty, gen, row_of, dous):
+        par = np.ascontiguousarray(par, np.int32)
+        empty = np.ascontiguousarray(empty, np.uint8)
+        gen = np.ascontiguousarray(gen, np.int32)
+        row_of = np.ascontiguousarray(row_of, np.int32)
+        dous = np.ascontiguousarray(dous, np.int32)
+        self._chk(self.L.cnf2_upload_pedigree(self.h, len(par), _p(par), _p(empty), _p(gen), _p(row_of), _p(dous),
+                                              len(dous)), "cnf2_upload_pedigree")
+        self.n_ind = len(dous)
+
+    def upload(self, ped, dous=None):
+        """Convenience: everything from a cnf2freq_amd.synth.Pedigree."""
+        self.upload_map(ped.pos, ped.chromstarts)
+        self.upload_rows(ped.allele, ped.sure, ped.hw)
+        self.upload_pedigree(ped.par, ped.empty, ped.gen, ped.row_of, ped.dous if dous is None else dous)
+
+    # -- the sweep -------------------------------------------------------------
+    def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True):
+        ind_end = self.n_ind if ind_end is None else ind_end
+        n = ind_end - ind_begin
+        factors = np.zeros((n, self.n_chrom, 8))
+        loglik = np.zeros((n, self.n_chrom))
+        dos = np.zeros((n, self.n_markers, 3)) if dosage else None
+        flags = (0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
+        self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
+                                    _p(dos) if dosage else None, flags), "cnf2_sweep")
+        return dict(factors=factors, loglik=loglik, dosage=dos)
+
+    def sweep_device(self, ind_begin, ind_end, d_factors, d_loglik, d_dosage, flags=0):
+        """Device-pointer form (ints or None); only enqueues on the context's stream."""
+        self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, C.c_void_p(d_factors), C.c_void_p(d_loglik),
+                                    C.c_void_p(d_dosage) if d_dosage else None, flags | OUT_DEVICE), "cnf2_sweep")
+
+    def sync(self):
+        self._chk(self.L.cnf2_sync(self.h), "cnf2_sync")
+
+    def last_kernel_ms(self):
+        ms = np.zeros(4, np.float32)
+        self._chk(self.L.cnf2_last_kernel_ms(self.h, _p(ms), 4), "cnf2_last_kernel_ms")
+        return float(ms[0])
+
+    def workspace_bytes(self):
+        return int(self.L.cnf2_workspace_bytes(self.h))
+
+    # -- parity hooks ------------------------------------------------------------
+    def window_info(self, ind):
+        out = np.zeros(17, np.int32)
+        self._chk(self.L.cnf2_window_info(self.h, ind, _p(out)), "cnf2_window_info")
+        return dict(shiftignore=int(out[0]), flag2ignore=int(out[1]), founder=int(out[2]),
+                    slots=out[3:10].copy(), tie=out[10:17].copy())
+
+    def fwbw_store(self, ind, chrom=0):
+        mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
+        fw = np.zeros((8, mc, 3, 64))
+        ff = np.zeros((8, mc, 3))
+        self._chk(self.L.cnf2_fwbw_store(self.h, ind, chrom, _p(fw), _p(ff)), "cnf2_fwbw_store")
+        return fw, ff
+
+    def emission(self, ind, marker):
+        e = np.zeros((8, 64))
+        self._chk(self.L.cnf2_emission(self.h, ind, marker, _p(e)), "cnf2_emission")
+        return e
+
+    def selftest_lane_xor(self):
+        out = np.zeros((6, 64))
+        self._chk(self.L.cnf2_selftest_lane_xor(self.h, _p(out)), "cnf2_selftest_lane_xor")
+        return out

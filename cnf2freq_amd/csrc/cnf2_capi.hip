@@ -1,0 +1,521 @@
+// cnf2_capi.hip -- implementation of the C ABI declared in include/cnf2hip.h.
+// Host side only: owns device memory, derives the window tables, builds the job list and
+// launches the kernels of cnf2_kernels.hip on the context's stream.  There is no CPU
+// compute path here: without a usable HIP device every entry point fails.
+#include "../../include/cnf2hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cnf2_device.h"
+#include "cnf2_emission.h"
+
+using namespace cnf2;
+
+struct cnf2_ctx {
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    bool        timed = false;
+    std::string err;
+    int         n_cu = 0;
+    int         blocks_per_cu = 1;
+
+    // map
+    int                  n_markers = 0, n_chrom = 0;
+    std::vector<int32_t> chromstarts;
+    double               genrec[3] = {-0.02, -0.02, -0.02};
+    double2*             d_rho = nullptr;
+
+    // rows
+    int      n_rows = 0;
+    uint8_t* d_allele8 = nullptr;
+    double2* d_sure = nullptr;
+    double*  d_hw = nullptr;
+
+    // pedigree
+    HostPedigree        ped;
+    std::vector<Window> windows;     // one per analysed individual
+    Window*             d_windows = nullptr;
+
+    // workspace
+    Job*    d_jobs = nullptr;
+    size_t  jobs_cap = 0;
+    double* d_spill = nullptr;
+    size_t  spill_bytes = 0;
+    double *d_factors = nullptr, *d_loglik = nullptr, *d_dosage = nullptr;
+    size_t  factors_cap = 0, loglik_cap = 0, dosage_cap = 0;
+    double* d_scratch = nullptr;     // small parity buffers
+    size_t  scratch_cap = 0;
+};
+
+static std::string g_create_error;
+
+static int fail(cnf2_ctx* ctx, int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? CNF2_ERR_NOMEM : CNF2_ERR_HIP,        \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                        \
+    } while (0)
+
+template <class T>
+static int ensure(cnf2_ctx* ctx, T** ptr, size_t* cap, size_t count)
+{
+    if (*cap >= count && *ptr) return CNF2_OK;
+    if (*ptr) HIP_TRY(ctx, hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)ptr, count * sizeof(T)));
+    *cap = count;
+    return CNF2_OK;
+}
+
+extern "C" {
+
+const char* cnf2_version(void) { return "cnf2hip 0.1 (gfx950)"; }
+
+int cnf2_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* cnf2_last_error(const cnf2_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int cnf2_ctx_create(int device, cnf2_ctx** out)
+{
+    if (!out) return fail(nullptr, CNF2_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, CNF2_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, CNF2_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    cnf2_ctx* ctx = new cnf2_ctx();
+    ctx->device   = device;
+    hipError_t e  = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        fail(nullptr, CNF2_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return CNF2_ERR_HIP;
+    }
+    ctx->n_cu          = prop.multiProcessorCount;
+    ctx->blocks_per_cu = fb_blocks_per_cu();
+    *out = ctx;
+    return CNF2_OK;
+}
+
+void cnf2_ctx_destroy(cnf2_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_rho);
+    hipFree(ctx->d_allele8);
+    hipFree(ctx->d_sure);
+    hipFree(ctx->d_hw);
+    hipFree(ctx->d_windows);
+    hipFree(ctx->d_jobs);
+    hipFree(ctx->d_spill);
+    hipFree(ctx->d_factors);
+    hipFree(ctx->d_loglik);
+    hipFree(ctx->d_dosage);
+    hipFree(ctx->d_scratch);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* cnf2_stream(cnf2_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int cnf2_sync(cnf2_ctx* ctx)
+{
+    if (!ctx) return CNF2_ERR_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_upload_map(cnf2_ctx* ctx, const double* pos, int n_markers, const int32_t* chromstarts, int n_chrom,
+                    const double* genrec)
+{
+    if (!ctx || !pos || !chromstarts || n_markers <= 0 || n_chrom <= 0) return fail(ctx, CNF2_ERR_ARG, "bad map arguments");
+    if (chromstarts[0] != 0 || chromstarts[n_chrom] != n_markers)
+        return fail(ctx, CNF2_ERR_ARG, "chromstarts must run from 0 to n_markers");
+    for (int c = 0; c < n_chrom; c++)
+        if (chromstarts[c + 1] <= chromstarts[c]) return fail(ctx, CNF2_ERR_ARG, "empty chromosome %d", c);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_markers != n_markers && (ctx->d_allele8 || ctx->d_sure || ctx->d_hw))
+        return fail(ctx, CNF2_ERR_STATE, "marker count changed after rows were uploaded");
+    ctx->n_markers = n_markers;
+    ctx->n_chrom   = n_chrom;
+    ctx->chromstarts.assign(chromstarts, chromstarts + n_chrom + 1);
+    if (genrec) memcpy(ctx->genrec, genrec, sizeof(ctx->genrec));
+    // recombination fraction per gap, exactly as realanalyze forms it (cnF2freq.cpp:2270-2286);
+    // a gap with dist <= 0 performs no transition (cnF2freq.cpp:2273) == rho 0
+    std::vector<double2> rho(n_markers);
+    for (int m = 0; m < n_markers; m++) {
+        double2 r = make_double2(0.0, 0.0);
+        if (m + 1 < n_markers) {
+            double dist = pos[m + 1] - pos[m];
+            if (dist > 0) {
+                r.x = 0.5 * (1.0 - exp(ctx->genrec[0] * dist));
+                r.y = 0.5 * (1.0 - exp(ctx->genrec[1] * dist));
+            }
+        }
+        rho[m] = r;
+    }
+    if (ctx->d_rho) HIP_TRY(ctx, hipFree(ctx->d_rho));
+    ctx->d_rho = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rho, sizeof(double2) * n_markers));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_rho, rho.data(), sizeof(double2) * n_markers, hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
+static int copy_rows(cnf2_ctx* ctx, int row0, int n, const uint8_t* allele, const double* sure, const double* hw)
+{
+    const size_t M = ctx->n_markers;
+    const size_t cnt = (size_t)n * M;
+    // pack (a0, a1) into one byte on the host, in slabs to bound the staging buffer
+    const size_t slab = 1u << 24;
+    std::vector<uint8_t> packed(cnt < slab ? cnt : slab);
+    for (size_t off = 0; off < cnt; off += slab) {
+        size_t k = cnt - off < slab ? cnt - off : slab;
+        for (size_t i = 0; i < k; i++) {
+            uint8_t a0 = allele[(off + i) * 2], a1 = allele[(off + i) * 2 + 1];
+            if (a0 > 15 || a1 > 15) return fail(ctx, CNF2_ERR_ARG, "allele value out of range");
+            packed[i] = (uint8_t)(a0 | (a1 << 4));
+        }
+        HIP_TRY(ctx, hipMemcpy(ctx->d_allele8 + (size_t)row0 * M + off, packed.data(), k, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_sure + (size_t)row0 * M, sure, cnt * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_hw + (size_t)row0 * M, hw, cnt * sizeof(double), hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
+int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const double* sure, const double* hw)
+{
+    if (!ctx || n_rows <= 0 || !allele || !sure || !hw) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
+    if (ctx->n_markers <= 0) return fail(ctx, CNF2_ERR_STATE, "upload the map before the rows");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_allele8) HIP_TRY(ctx, hipFree(ctx->d_allele8));
+    if (ctx->d_sure) HIP_TRY(ctx, hipFree(ctx->d_sure));
+    if (ctx->d_hw) HIP_TRY(ctx, hipFree(ctx->d_hw));
+    ctx->d_allele8 = nullptr;
+    ctx->d_sure = nullptr;
+    ctx->d_hw = nullptr;
+    ctx->n_rows = 0;
+    size_t cnt = (size_t)n_rows * ctx->n_markers;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_allele8, cnt));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sure, cnt * sizeof(double2)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hw, cnt * sizeof(double)));
+    ctx->n_rows = n_rows;
+    return copy_rows(ctx, 0, n_rows, allele, sure, hw);
+}
+
+int cnf2_update_rows(cnf2_ctx* ctx, int row0, int n, const uint8_t* allele, const double* sure, const double* hw)
+{
+    if (!ctx || !allele || !sure || !hw) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
+    if (!ctx->d_allele8) return fail(ctx, CNF2_ERR_STATE, "no rows uploaded");
+    if (row0 < 0 || n < 0 || row0 + n > ctx->n_rows) return fail(ctx, CNF2_ERR_ARG, "row range out of bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n == 0) return CNF2_OK;
+    return copy_rows(ctx, row0, n, allele, sure, hw);
+}
+
+int cnf2_upload_pedigree(cnf2_ctx* ctx, int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                         const int32_t* row_of, const int32_t* dous, int n_dous)
+{
+    if (!ctx || n_rec <= 0 || !par || !empty || !gen || !row_of || !dous || n_dous < 0)
+        return fail(ctx, CNF2_ERR_ARG, "bad pedigree arguments");
+    if (ctx->n_rows <= 0) return fail(ctx, CNF2_ERR_STATE, "upload the rows before the pedigree");
+    for (int r = 0; r < n_rec; r++) {
+        for (int k = 0; k < 2; k++)
+            if (par[r * 2 + k] < -1 || par[r * 2 + k] >= n_rec) return fail(ctx, CNF2_ERR_ARG, "parent index out of range at record %d", r);
+        if (row_of[r] < 0 || row_of[r] >= ctx->n_rows) return fail(ctx, CNF2_ERR_ARG, "row index out of range at record %d", r);
+    }
+    for (int j = 0; j < n_dous; j++)
+        if (dous[j] < 0 || dous[j] >= n_rec) return fail(ctx, CNF2_ERR_ARG, "analysed record out of range at %d", j);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HostPedigree& P = ctx->ped;
+    P.n_rec = n_rec;
+    P.par.assign(par, par + 2 * (size_t)n_rec);
+    P.empty.assign(empty, empty + n_rec);
+    P.gen.assign(gen, gen + n_rec);
+    P.row_of.assign(row_of, row_of + n_rec);
+    P.dous.assign(dous, dous + n_dous);
+    derive_founders(P);
+    ctx->windows.resize(n_dous);
+    for (int j = 0; j < n_dous; j++) derive_window(P, dous[j], &ctx->windows[j], nullptr);
+    if (ctx->d_windows) HIP_TRY(ctx, hipFree(ctx->d_windows));
+    ctx->d_windows = nullptr;
+    if (n_dous > 0) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_windows, sizeof(Window) * n_dous));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_windows, ctx->windows.data(), sizeof(Window) * n_dous, hipMemcpyHostToDevice));
+    }
+    return CNF2_OK;
+}
+
+int cnf2_window_info(cnf2_ctx* ctx, int ind, int32_t* out17)
+{
+    if (!ctx || !out17) return CNF2_ERR_ARG;
+    if (ind < 0 || ind >= (int)ctx->windows.size()) return fail(ctx, CNF2_ERR_ARG, "individual out of range");
+    Window  w;
+    int32_t slot_rec[7];
+    derive_window(ctx->ped, ctx->ped.dous[ind], &w, slot_rec);
+    out17[0] = w.shiftignore;
+    out17[1] = w.flag2ignore;
+    out17[2] = ctx->ped.founder[ctx->ped.dous[ind]];
+    for (int i = 0; i < 7; i++) {
+        out17[3 + i]  = slot_rec[i];
+        out17[10 + i] = w.tie[i];
+    }
+    return CNF2_OK;
+}
+
+static int ready(cnf2_ctx* ctx)
+{
+    if (!ctx) return CNF2_ERR_ARG;
+    if (!ctx->d_rho || !ctx->d_allele8 || !ctx->d_windows)
+        return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
+    return CNF2_OK;
+}
+
+static void base_params(cnf2_ctx* ctx, KernelParams* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->windows   = ctx->d_windows;
+    p->allele8   = ctx->d_allele8;
+    p->sure      = ctx->d_sure;
+    p->hw        = ctx->d_hw;
+    p->rho       = ctx->d_rho;
+    p->n_markers = ctx->n_markers;
+    p->n_chrom   = ctx->n_chrom;
+}
+
+static int max_chrom_len(const cnf2_ctx* ctx)
+{
+    int mx = 0;
+    for (int c = 0; c < ctx->n_chrom; c++) {
+        int l = ctx->chromstarts[c + 1] - ctx->chromstarts[c];
+        if (l > mx) mx = l;
+    }
+    return mx;
+}
+
+int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, double* loglik_out, double* dosage_out,
+               uint32_t flags)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    const int n_all = (int)ctx->windows.size();
+    if (ind_begin < 0 || ind_end > n_all || ind_begin > ind_end) return fail(ctx, CNF2_ERR_ARG, "individual range out of bounds");
+    const bool want_dosage = !(flags & CNF2_NO_DOSAGE);
+    if (!factors_out || !loglik_out || (want_dosage && !dosage_out)) return fail(ctx, CNF2_ERR_ARG, "output pointer is NULL");
+    const int n = ind_end - ind_begin;
+    if (n == 0) return CNF2_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const size_t n_jobs = (size_t)n * ctx->n_chrom;
+    if (n_jobs > 0x7fffffff) return fail(ctx, CNF2_ERR_ARG, "too many jobs in one call");
+    // job list: individuals x chromosomes (the loops at cnF2freq.cpp:5283 and 5294)
+    std::vector<Job> jobs(n_jobs);
+    size_t           k = 0;
+    for (int c = 0; c < ctx->n_chrom; c++)
+        for (int j = 0; j < n; j++) {
+            Job jb;
+            jb.ind   = j;
+            jb.first = ctx->chromstarts[c];
+            jb.last  = ctx->chromstarts[c + 1] - 1;
+            jb.chrom = c;
+            jobs[k++] = jb;
+        }
+    rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, n_jobs);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(Job) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // jobs vector goes out of scope
+
+    // grid: one wave per job in flight, capped at what is resident so that the spill stays small
+    int grid = (int)((n_jobs + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+    int cap  = ctx->n_cu * ctx->blocks_per_cu;
+    if (grid > cap) grid = cap;
+    const size_t stride = (size_t)max_chrom_len(ctx) * 512;
+    const size_t need   = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
+    {
+        size_t capd = ctx->spill_bytes / sizeof(double);
+        rc = ensure(ctx, &ctx->d_spill, &capd, need);
+        ctx->spill_bytes = capd * sizeof(double);
+        if (rc) return rc;
+    }
+
+    double *d_f, *d_l, *d_d = nullptr;
+    const size_t nf = (size_t)n * ctx->n_chrom * 8, nl = (size_t)n * ctx->n_chrom, nd = (size_t)n * ctx->n_markers * 3;
+    if (flags & CNF2_OUT_DEVICE) {
+        d_f = factors_out;
+        d_l = loglik_out;
+        d_d = dosage_out;
+    } else {
+        if ((rc = ensure(ctx, &ctx->d_factors, &ctx->factors_cap, nf))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_loglik, &ctx->loglik_cap, nl))) return rc;
+        if (want_dosage && (rc = ensure(ctx, &ctx->d_dosage, &ctx->dosage_cap, nd))) return rc;
+        d_f = ctx->d_factors;
+        d_l = ctx->d_loglik;
+        d_d = ctx->d_dosage;
+    }
+
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows      = ctx->d_windows + ind_begin;
+    p.jobs         = ctx->d_jobs;
+    p.n_jobs       = (int)n_jobs;
+    p.spill        = ctx->d_spill;
+    p.spill_stride = stride;
+    p.factors      = d_f;
+    p.loglik       = d_l;
+    p.dosage       = d_d;
+    p.flags        = (want_dosage ? 0 : KP_NO_DOSAGE) | ((flags & CNF2_RAW_DOSAGE) ? KP_RAW_DOSAGE : 0) |
+              ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    launch_fb(p, grid, false, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+
+    if (!(flags & CNF2_OUT_DEVICE)) {
+        HIP_TRY(ctx, hipMemcpyAsync(factors_out, d_f, nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(loglik_out, d_l, nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (want_dosage)
+            HIP_TRY(ctx, hipMemcpyAsync(dosage_out, d_d, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CNF2_OK;
+}
+
+int cnf2_last_kernel_ms(cnf2_ctx* ctx, float* kernel_ms, int n)
+{
+    if (!ctx || !kernel_ms || n < 1) return CNF2_ERR_ARG;
+    if (!ctx->timed) return fail(ctx, CNF2_ERR_STATE, "no sweep has been launched");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    kernel_ms[0] = ms;
+    for (int i = 1; i < n; i++) kernel_ms[i] = 0;
+    return CNF2_OK;
+}
+
+size_t cnf2_workspace_bytes(cnf2_ctx* ctx)
+{
+    if (!ctx) return 0;
+    return ctx->spill_bytes + ctx->jobs_cap * sizeof(Job) +
+           (ctx->factors_cap + ctx->loglik_cap + ctx->dosage_cap + ctx->scratch_cap) * sizeof(double);
+}
+
+int cnf2_fwbw_store(cnf2_ctx* ctx, int ind, int chrom, double* fwbw_out, double* fwbwfactors_out)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ind < 0 || ind >= (int)ctx->windows.size() || chrom < 0 || chrom >= ctx->n_chrom || !fwbw_out || !fwbwfactors_out)
+        return fail(ctx, CNF2_ERR_ARG, "bad fwbw_store arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int    first = ctx->chromstarts[chrom], last = ctx->chromstarts[chrom + 1] - 1, len = last - first + 1;
+    const size_t nfw = (size_t)8 * len * 3 * 64, nff = (size_t)8 * len * 3;
+    const size_t stride = (size_t)len * 512;
+    // scratch: fwbw | factors | spill(4 waves) | out factors(8) | loglik(1) | dosage(n_markers*3) | job
+    const size_t total = nfw + nff + stride * CNF2_WAVES_PER_BLOCK + 16 + (size_t)ctx->n_markers * 3 + 8;
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, total))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, (nfw + nff) * sizeof(double), ctx->stream));
+    double* d_fw  = ctx->d_scratch;
+    double* d_ff  = d_fw + nfw;
+    double* d_sp  = d_ff + nff;
+    double* d_f   = d_sp + stride * CNF2_WAVES_PER_BLOCK;
+    double* d_l   = d_f + 8;
+    double* d_d   = d_l + 8;
+    Job*    d_job = (Job*)(d_d + (size_t)ctx->n_markers * 3);
+    Job     jb;
+    jb.ind = 0;
+    jb.first = first;
+    jb.last = last;
+    jb.chrom = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(d_job, &jb, sizeof(jb), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows      = ctx->d_windows + ind;
+    p.n_chrom      = 1;
+    p.jobs         = d_job;
+    p.n_jobs       = 1;
+    p.spill        = d_sp;
+    p.spill_stride = stride;
+    p.factors      = d_f;
+    p.loglik       = d_l;
+    p.dosage       = d_d;   // rows of this individual, indexed by global marker
+    p.flags        = KP_NO_DOSAGE;
+    p.dbg_fwbw     = d_fw;
+    p.dbg_factors  = d_ff;
+    launch_fb(p, 1, true, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(fwbw_out, d_fw, nfw * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(fwbwfactors_out, d_ff, nff * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_emission(cnf2_ctx* ctx, int ind, int marker, double* e_out)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ind < 0 || ind >= (int)ctx->windows.size() || marker < 0 || marker >= ctx->n_markers || !e_out)
+        return fail(ctx, CNF2_ERR_ARG, "bad emission arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)512))) return rc;
+    KernelParams p;
+    base_params(ctx, &p);
+    launch_emission(p, ind, marker, ctx->d_scratch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(e_out, ctx->d_scratch, 512 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_selftest_lane_xor(cnf2_ctx* ctx, double* out384)
+{
+    if (!ctx || !out384) return CNF2_ERR_ARG;
+    int rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)512))) return rc;
+    launch_xor_selftest(ctx->d_scratch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out384, ctx->d_scratch, 384 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+} // extern "C"

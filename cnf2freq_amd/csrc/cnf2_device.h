@@ -1,0 +1,60 @@
+// cnf2_device.h -- structures shared by the HIP kernels (cnf2_kernels.hip) and the C-ABI
+// implementation (cnf2_capi.hip).  Device memory layout is described in DESIGN.md.
+#ifndef CNF2_DEVICE_H
+#define CNF2_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cnf2_window.h"
+
+namespace cnf2 {
+
+#define CNF2_BLOCK 256
+#define CNF2_WAVES_PER_BLOCK (CNF2_BLOCK / 64)
+#define CNF2_MINFACTOR_F (-1e15f)  /* settings.h:29 */
+#define CNF2_IGNORED_D (-1e30)     /* cnF2freq.cpp:5378 */
+
+enum { KP_NO_DOSAGE = 1, KP_RAW_DOSAGE = 2, KP_NO_TIES = 4 };
+
+// One unit of sequential work: an analysed individual on one chromosome
+// (the body of the loops at cnF2freq.cpp:5283 and 5294).
+struct Job {
+    int32_t ind;     // index into windows[] / output rows (local to the call)
+    int32_t first;   // chromstarts[c]
+    int32_t last;    // chromstarts[c+1] - 1
+    int32_t chrom;
+};
+
+struct KernelParams {
+    // inputs, resident in HBM
+    const Window*  windows;    // [n_ind]
+    const Job*     jobs;       // [n_jobs]
+    const uint8_t* allele8;    // [n_rows][n_markers]  a0 | a1 << 4
+    const double2* sure;       // [n_rows][n_markers]
+    const double*  hw;         // [n_rows][n_markers]
+    const double2* rho;        // [n_markers] recombination fraction of gap m -> m+1 for
+                               //             genrec[0] (.x) and genrec[1] (.y); 0 when dist <= 0
+    int            n_jobs;
+    int            n_markers;
+    int            n_chrom;
+    uint32_t       flags;
+    // workspace: alpha-minus spill, one slot per resident wave, [len][8][64] doubles
+    double*        spill;
+    size_t         spill_stride;   // doubles per wave slot
+    // outputs
+    double*        factors;    // [n_ind][n_chrom][8]
+    double*        loglik;     // [n_ind][n_chrom]
+    double*        dosage;     // [n_ind][n_markers][3]
+    // debug store (fwbw_store): reference layout for ONE job
+    double*        dbg_fwbw;     // [8][len][3][64]
+    double*        dbg_factors;  // [8][len][3]
+};
+
+void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
+void launch_emission(const KernelParams& p, int ind, int marker, double* out, hipStream_t stream);
+void launch_xor_selftest(double* out, hipStream_t stream);
+int  fb_blocks_per_cu();
+
+} // namespace cnf2
+#endif

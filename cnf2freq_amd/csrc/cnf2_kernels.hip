@@ -1,0 +1,481 @@
+// cnf2_kernels.hip -- gfx950 kernels of the cnF2freq forward-backward sweep.
+//
+// One wavefront = one job (analysed individual x chromosome), all 8 shift modes at once:
+//     lane = chain<<3 | lo      chain = shift mode s (cnF2freq.cpp:5375), lo = state bits 0-2
+//     register j = 0..7         state bits 3-5            state g = j*8 + lo
+// so the 8 x 64 state values of the 8 concurrent HMM chains sit in 8 VGPR pairs per lane.
+//   * emission (adjustprobs + trackpossible, cnF2freq.cpp:1579-1670, 1075-1359): the same 64 lanes
+//     first act as the 64 entries of the rank-2 emission table of this (individual, marker)
+//     (cnf2_emission.h / cnf2_lane.h), hand them over through 512 B of LDS, then every lane
+//     forms e(g) = sum_f c_f A_f[lo] B_f[j] for its 8 states;
+//   * transition (realanalyze, cnF2freq.cpp:2273-2367): the 64x64 XOR-indexed matrix is the
+//     6-fold Kronecker product of [[1-r, r],[r, 1-r]]; bits 3-5 are register pairs, bits 0-2
+//     are DPP lane exchanges inside a row -- no LDS, no MFMA;
+//   * scaling (cnF2freq.cpp:1656-1669): per-chain sum by 3 DPP steps; the 8 chains' reciprocals
+//     are computed by one instruction stream (8 lanes each); log scales are carried as
+//     mantissa x 2^exponent and only turned into a logarithm once per chromosome.
+// The forward pass spills alpha-minus (before emission) in register-major order, 8 coalesced
+// 512 B stores per marker; the backward pass of the same wave reads it back, forms the per-locus
+// allele-2 dosage row (genotypereporter, cnF2freq.cpp:3532-3538, closed form of the fan-out of
+// cnF2freq.cpp:5416-5553) and carries beta.
+#include <hip/hip_runtime.h>
+
+#include "cnf2_device.h"
+#include "cnf2_lane.h"
+
+namespace cnf2 {
+
+// ------------------------------------------------------------------ lane exchange helpers
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane (id ^ 1), (id ^ 2), (id ^ 4)
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_mov<0xB1, 0xF>(v, v); } // quad_perm [1,0,3,2]
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_mov<0x4E, 0xF>(v, v); } // quad_perm [2,3,0,1]
+__device__ __forceinline__ double lane_xor4(double v)
+{
+    double t = dpp_mov<0x104, 0x5>(v, v); // row_shl:4 into banks 0,2 (lanes with bit2 == 0 read lane+4)
+    return dpp_mov<0x114, 0xA>(t, v);     // row_shr:4 into banks 1,3 (lanes with bit2 == 1 read lane-4)
+}
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_mov<0x128, 0xF>(v, v); } // row_ror:8
+__device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
+__device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
+
+// sum over the 8 lanes of a chain (lanes differing in bits 0-2); result in every lane
+__device__ __forceinline__ double chain_sum(double v)
+{
+    v += lane_xor1(v);
+    v += lane_xor2(v);
+    v += lane_xor4(v);
+    return v;
+}
+// sum over the 8 chains of values that are already uniform inside each chain
+__device__ __forceinline__ double across_chains_sum(double v)
+{
+    v += lane_xor8(v);
+    v += lane_xor16(v);
+    v += lane_xor32(v);
+    return v;
+}
+__device__ __forceinline__ double across_chains_max(double v)
+{
+    v = fmax(v, lane_xor8(v));
+    v = fmax(v, lane_xor16(v));
+    v = fmax(v, lane_xor32(v));
+    return v;
+}
+
+// ------------------------------------------------------------------ transition
+// One Kronecker factor on a register pair / on a lane pair: x' = (1-r) x + r partner
+// (recombprec of cnF2freq.cpp:2329-2340 factorised over the 6 state bits).
+__device__ __forceinline__ void transition(double (&a)[8], double r0, double r1)
+{
+    // bit t uses genrec[TYPEGENS[t]], TYPEGENS = {1,0,0,1,0,0} (settings.h:23)
+    const double k0 = 1.0 - r0, k1 = 1.0 - r1;
+    // bits 0..2: lanes
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = k1 * a[j] + r1 * lane_xor1(a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * lane_xor2(a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * lane_xor4(a[j]);
+    // bits 3..5: registers
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        double x = a[j], y = a[j + 1];
+        a[j]     = k1 * x + r1 * y;
+        a[j + 1] = k1 * y + r1 * x;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j & 2) continue;
+        double x = a[j], y = a[j + 2];
+        a[j]     = k0 * x + r0 * y;
+        a[j + 2] = k0 * y + r0 * x;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double x = a[j], y = a[j + 4];
+        a[j]     = k0 * x + r0 * y;
+        a[j + 4] = k0 * y + r0 * x;
+    }
+}
+
+// ------------------------------------------------------------------ per-job lane state
+struct LaneCtx {
+    LaneJob L;            // producer role
+    int     row_root;
+    bool    root_attop;
+    int     s0, s1, s2;   // consumer role: bits of this lane's shift mode
+    int     lo;
+    bool    active;       // chain takes part (not masked by shiftignore / shiftend)
+    int     n_combo;      // 1 << n_groups (1 with CNF2_NO_TIES)
+};
+
+__device__ __forceinline__ Slot load_slot(const KernelParams& p, int row, int m)
+{
+    size_t  i  = (size_t)row * p.n_markers + m;
+    uint8_t ap = p.allele8[i];
+    double2 s  = p.sure[i];
+    return unpack_slot(ap, s.x, s.y, p.hw[i]);
+}
+
+// Producer half: this lane's table entry for marker m.
+// Returns the unrestricted value; if WITH_CLASSES also the restricted value and its class-2
+// part for tie combination `combo` (LineTerms kept by the caller).
+__device__ __forceinline__ double produce_entry(const KernelParams& p, const LaneCtx& c, const Slot& root, int m,
+                                                LineTerms* T)
+{
+    RootTerms R;
+    root_terms(root, c.root_attop, c.L.f, &R);
+    Slot par = load_slot(p, c.L.row_par, m);
+    Slot tr  = load_slot(p, c.L.row_tr, m);
+    Slot ot  = load_slot(p, c.L.row_ot, m);
+    line_terms(c.L.cfg, par, tr, ot, c.L.P ? R.inmv1 : R.inmv0, c.L.P ? R.sv1 : R.sv0,
+               c.L.P == 0 && R.inmv0 == 2, T);
+    double tot = line_total(*T);
+    if (c.root_attop) {
+        // the root is the top of its single line (cnF2freq.cpp:1260-1271): tables are 1
+        tot = 1.0;
+    }
+    return tot;
+}
+
+__device__ __forceinline__ void restricted_entry(const LaneCtx& c, const Slot& root, const LineTerms& T, int combo,
+                                                 double* rtot, double* two)
+{
+    if (c.root_attop) {
+        *rtot = 1.0;
+        int mf = c.L.f ? root.a1 : root.a0;
+        *two   = (c.L.P == 0 && mf == 2) ? 1.0 : 0.0;
+        return;
+    }
+    line_restricted(c.L.cfg, T, tie_force(c.L.tie_par, combo), tie_force(c.L.tie_tr, combo),
+                    tie_force(c.L.tie_ot, combo), rtot, two);
+}
+
+// Consumer half: root weights c_f(s0) of this lane's shift mode.
+__device__ __forceinline__ void root_weights(const LaneCtx& c, const Slot& root, double* c0, double* c1)
+{
+    RootTerms R0, R1;
+    root_terms(root, c.root_attop, 0, &R0);
+    root_terms(root, c.root_attop, 1, &R1);
+    *c0 = R0.cbase * phase_weight(root, 0 ^ c.s0);
+    *c1 = R1.cbase * phase_weight(root, 1 ^ c.s0);
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // producer lanes -> consumer lanes of the SAME wave: order the LDS write before the reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// e[j] for the lane's 8 states from one 64-entry table in LDS.
+__device__ __forceinline__ void emission_from_table(const double* tab, const LaneCtx& c, double c0, double c1,
+                                                    double (&e)[8])
+{
+    const double A0 = tab[(0 << 5) | (0 << 4) | (c.s1 << 3) | c.lo];
+    const double A1 = tab[(0 << 5) | (1 << 4) | (c.s1 << 3) | c.lo];
+    const double* B0 = tab + ((1 << 5) | (0 << 4) | (c.s2 << 3));
+    const double* B1 = tab + ((1 << 5) | (1 << 4) | (c.s2 << 3));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        // same association as the reference: ((c * other parent) * traced parent), f = 0 then 1
+        e[j] = (c0 * B0[j]) * A0 + (c1 * B1[j]) * A1;
+    }
+}
+
+// adjustprobs' scaling for the 8 chains at once (cnF2freq.cpp:1656-1669).
+// mant/expo carry prod(sum) as mant * 2^expo; dead = a sum <= 0 was seen (factor := MINFACTOR).
+__device__ __forceinline__ double scale_chain(double (&v)[8], double* mant, int* expo, bool* dead)
+{
+    double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    sum        = chain_sum(sum);
+    if (sum <= 0.0) {
+        *dead = true;               // probs stay as they are (all zero), factor = MINFACTOR
+    } else {
+        double inv = 1.0 / sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] *= inv;
+        int    ex;
+        double mm = frexp(*mant * sum, &ex);
+        *mant     = mm;
+        *expo += ex;
+    }
+    return sum;
+}
+
+template <bool DEBUG_STORE>
+__global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
+{
+    __shared__ double lds_tab[CNF2_WAVES_PER_BLOCK][64];
+    __shared__ double lds_rt[CNF2_WAVES_PER_BLOCK][64];
+    __shared__ double lds_two[CNF2_WAVES_PER_BLOCK][64];
+
+    const int lane  = threadIdx.x & 63;
+    const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
+    const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
+    double*   tab   = lds_tab[wib];
+    double*   tabr  = lds_rt[wib];
+    double*   tab2  = lds_two[wib];
+    double*   spill = p.spill + (size_t)wave * p.spill_stride;
+
+    for (int job = wave; job < p.n_jobs; job += nwave) {
+        const Job    jb = p.jobs[job];
+        const Window w  = p.windows[jb.ind];
+        LaneCtx      c;
+        make_lane(w, lane, &c.L);
+        c.row_root   = w.row[0];
+        c.root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+        const int s  = lane >> 3;
+        c.s0 = s & 1;
+        c.s1 = (s >> 1) & 1;
+        c.s2 = (s >> 2) & 1;
+        c.lo      = lane & 7;
+        c.active  = !(s & w.shiftignore) && s < w.shiftend;
+        c.n_combo = (p.flags & KP_NO_TIES) ? 1 : (1 << w.n_groups);
+        if (p.flags & KP_NO_TIES) c.L.tie_par = c.L.tie_tr = c.L.tie_ot = -1;
+        const int first = jb.first, last = jb.last, len = last - first + 1;
+
+        // ---------------------------------------------------------------- forward
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = 1.0 / 64.0;           // EVENGEN, cnF2freq.cpp:2100-2104
+        double mant = 1.0;
+        int    expo = 0;
+        bool   dead = false;
+        double dbg_factor = 0.0;
+        for (int m = first; m <= last; m++) {
+            const Slot root = load_slot(p, c.row_root, m);
+            LineTerms  T;
+            double     tot = produce_entry(p, c, root, m, &T);
+            tab[lane]      = tot;
+            wave_lds_fence();
+            double c0, c1, e[8];
+            root_weights(c, root, &c0, &c1);
+            emission_from_table(tab, c, c0, c1, e);
+            wave_lds_fence();                                   // table may be overwritten next round
+
+            // alpha-minus: register-major spill, 8 x 512 B coalesced
+            double* sp = spill + (size_t)(m - first) * 512 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+            if (DEBUG_STORE) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    p.dbg_fwbw[(((size_t)s * len + (m - first)) * 3 + 0) * 64 + j * 8 + c.lo] = a[j];
+                if (c.lo == 0) p.dbg_factors[((size_t)s * len + (m - first)) * 3 + 0] = dbg_factor;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] *= e[j];
+            bool   was_dead = dead;
+            double sum      = scale_chain(a, &mant, &expo, &dead);
+            if (DEBUG_STORE) {
+                if (dead) dbg_factor = (double)CNF2_MINFACTOR_F;
+                else dbg_factor += log(sum);
+                (void)was_dead;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    p.dbg_fwbw[(((size_t)s * len + (m - first)) * 3 + 2) * 64 + j * 8 + c.lo] = a[j];
+                if (c.lo == 0) p.dbg_factors[((size_t)s * len + (m - first)) * 3 + 2] = dbg_factor;
+            }
+            if (m < last) {
+                const double2 r = p.rho[m];                     // gap m -> m+1 (0 when dist <= 0)
+                transition(a, r.x, r.y);
+            }
+        }
+
+        // ---------------------------------------------------------------- likelihoods
+        // factors[s] (cnF2freq.cpp:5375-5382) and factor = logsumexp (cnF2freq.cpp:5384-5400)
+        double fs = dead ? (double)CNF2_MINFACTOR_F : (log(mant) + (double)expo * 0.69314718055994530942);
+        if (!c.active) fs = CNF2_IGNORED_D;
+        double fmaxv = across_chains_max(fs);
+        fmaxv        = fmax(fmaxv, -1e15);                      // cnF2freq.cpp:5373
+        double term  = c.active ? exp(fs - fmaxv) : 0.0;
+        double real  = across_chains_sum(term);
+        double factor = fmaxv + log(real);
+        if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = fs;
+        if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = factor;
+        const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;      // cnF2freq.cpp:5403
+        // weight of this chain in the per-locus row; cnF2freq.cpp:5421 drops modes 40 log units down
+        const double ws = (c.active && !skip && !(factor - fs > 40.0)) ? exp(fs - factor) : 0.0;
+
+        if ((p.flags & KP_NO_DOSAGE) && !DEBUG_STORE) continue;
+
+        // ---------------------------------------------------------------- backward + rows
+        double b[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) b[j] = 1.0;                  // cnF2freq.cpp:2111-2114
+        double bmant = 1.0;
+        int    bexpo = 0;
+        bool   bdead = false;
+        double dbg_bfactor = 0.0;
+        for (int m = last; m >= first; m--) {
+            const Slot root = load_slot(p, c.row_root, m);
+            LineTerms  T;
+            double     tot = produce_entry(p, c, root, m, &T);
+            double     c0, c1, e[8];
+            root_weights(c, root, &c0, &c1);
+            tab[lane] = tot;
+            wave_lds_fence();
+            emission_from_table(tab, c, c0, c1, e);
+
+            if (DEBUG_STORE) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    p.dbg_fwbw[(((size_t)s * len + (m - first)) * 3 + 1) * 64 + j * 8 + c.lo] = b[j];
+                if (c.lo == 0) p.dbg_factors[((size_t)s * len + (m - first)) * 3 + 1] = dbg_bfactor;
+            }
+
+            if (!(p.flags & KP_NO_DOSAGE)) {
+                // w_j = alpha-minus * beta ; D = sum_g w e  (normaliser of this chain at this locus)
+                const double* sp = spill + (size_t)(m - first) * 512 + lane;
+                double        wj[8], D = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    wj[j] = sp[j * 64] * b[j];
+                    D += wj[j] * e[j];
+                }
+                double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
+                for (int combo = 0; combo < c.n_combo; combo++) {
+                    double rt, tw;
+                    restricted_entry(c, root, T, combo, &rt, &tw);
+                    wave_lds_fence();
+                    tabr[lane] = rt;
+                    tab2[lane] = tw;
+                    wave_lds_fence();
+#pragma unroll
+                    for (int f = 0; f < 2; f++) {
+                        const int    ia = (0 << 5) | (f << 4) | (c.s1 << 3) | c.lo;
+                        const double* Br = tabr + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                        const double* B1 = tab2 + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                        const double  av = tabr[ia], a1 = tab2[ia];
+                        double        sb = 0.0, sb1 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            sb += wj[j] * Br[j];
+                            sb1 += wj[j] * B1[j];
+                        }
+                        const double cf = f ? c1 : c0;
+                        n_tot += cf * av * sb;
+                        n_a1 += cf * a1 * sb;
+                        n_b1 += cf * av * sb1;
+                        n_2 += cf * a1 * sb1;
+                    }
+                }
+                D     = chain_sum(D);
+                n_tot = chain_sum(n_tot);
+                n_a1  = chain_sum(n_a1);
+                n_b1  = chain_sum(n_b1);
+                n_2   = chain_sum(n_2);
+                const double scale = (D > 0.0) ? ws / D : 0.0;
+                double d2 = across_chains_sum(scale * n_2);
+                double d1 = across_chains_sum(scale * (n_a1 + n_b1 - 2.0 * n_2));
+                double d0 = across_chains_sum(scale * (n_tot - n_a1 - n_b1 + n_2));
+                if (lane == 0) {
+                    if (!(p.flags & KP_RAW_DOSAGE)) {
+                        double tsum = d0 + d1 + d2;
+                        double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
+                        d0 *= inv;
+                        d1 *= inv;
+                        d2 *= inv;
+                    }
+                    double* out = p.dosage + ((size_t)jb.ind * p.n_markers + m) * 3;
+                    out[0] = d0;
+                    out[1] = d1;
+                    out[2] = d2;
+                }
+            }
+
+            // beta_{m-1} = T (e_m . beta_m), rescaled (cnF2freq.cpp:2238 with d = -1, then 2273-2367)
+            if (m > first) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) b[j] *= e[j];
+                double sum = scale_chain(b, &bmant, &bexpo, &bdead);
+                if (DEBUG_STORE) {
+                    if (bdead) dbg_bfactor = (double)CNF2_MINFACTOR_F;
+                    else dbg_bfactor += log(sum);
+                }
+                const double2 r = p.rho[m - 1];
+                transition(b, r.x, r.y);
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// Parity hook: path-free emission e_s(g) of one (individual, marker) for the 8 shift modes,
+// through exactly the producer/consumer code of the sweep.
+__global__ __launch_bounds__(64) void emission_kernel(KernelParams p, int ind, int marker, double* out)
+{
+    __shared__ double tab[64];
+    const int    lane = threadIdx.x;
+    const Window w    = p.windows[ind];
+    LaneCtx      c;
+    make_lane(w, lane, &c.L);
+    c.row_root   = w.row[0];
+    c.root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    const int s  = lane >> 3;
+    c.s0 = s & 1;
+    c.s1 = (s >> 1) & 1;
+    c.s2 = (s >> 2) & 1;
+    c.lo = lane & 7;
+    c.active = true;
+    c.n_combo = 1;
+    const Slot root = load_slot(p, c.row_root, marker);
+    LineTerms  T;
+    tab[lane] = produce_entry(p, c, root, marker, &T);
+    wave_lds_fence();
+    double c0, c1, e[8];
+    root_weights(c, root, &c0, &c1);
+    emission_from_table(tab, c, c0, c1, e);
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[s * 64 + j * 8 + c.lo] = e[j];
+}
+
+// Self-test of the lane-exchange helpers (tests/test_gpu_parity.py): out[k][lane] = value
+// received by `lane` for xor distance 1<<k.
+__global__ __launch_bounds__(64) void xor_selftest_kernel(double* out)
+{
+    const int lane = threadIdx.x;
+    double    v    = 1000.0 + lane;
+    out[0 * 64 + lane] = lane_xor1(v);
+    out[1 * 64 + lane] = lane_xor2(v);
+    out[2 * 64 + lane] = lane_xor4(v);
+    out[3 * 64 + lane] = lane_xor8(v);
+    out[4 * 64 + lane] = lane_xor16(v);
+    out[5 * 64 + lane] = lane_xor32(v);
+}
+
+void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream)
+{
+    if (debug_store) hipLaunchKernelGGL(fb_kernel<true>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(fb_kernel<false>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+
+void launch_emission(const KernelParams& p, int ind, int marker, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(emission_kernel, dim3(1), dim3(64), 0, stream, p, ind, marker, out);
+}
+
+void launch_xor_selftest(double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(xor_selftest_kernel, dim3(1), dim3(64), 0, stream, out);
+}
+
+int fb_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fb_kernel<false>, CNF2_BLOCK, 0) != hipSuccess) n = 2;
+    return n < 1 ? 1 : n;
+}
+
+} // namespace cnf2

@@ -122,6 +122,10 @@ int cnf2_fwbw_store(cnf2_ctx *ctx, int ind, int chrom, double *fwbw_out, double 
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
 int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);
 
+/* Diagnostic: out384[k*64 + lane] = value 1000+src received by `lane` from the lane-exchange
+ * primitive of distance 1<<k (k = 0..5) that the transition butterflies are built on. */
+int cnf2_selftest_lane_xor(cnf2_ctx *ctx, double *out384);
+
 /* Measurement support for bench.py: duration in ms of the kernels of the last cnf2_sweep
  * measured with hipEvents on the context's stream (kernel_ms[0] = forward-backward kernel),
  * and workspace bytes currently allocated on the device. */

