@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the forward-backward sweep (BASELINE.json metric:
+individual x marker fwd-bwd steps/sec on the synthetic 10k-individual x 50k-SNP F2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full sweep (cnf2_sweep through the C ABI: forward + backward over all 8
+shift modes, likelihoods and the per-locus dosage rows) over the rank's individuals, inputs
+resident in HBM.  Individuals shard across ranks with no data-path collective (weak scaling:
+every rank owns --inds individuals); after the sweep the posteriors are gathered on rank 0
+with one RCCL gather inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import os
+
+os.environ.setdefault("OMP_STACKSIZE", "128M")  # demo.sh:36 (reference-extract CPU baseline)
+
+import argparse
+import json
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+B_UNIT = 8248.0        # algorithmic bytes per individual x marker (S_act = 8, f64)
+HBM_PEAK = 8.0e12      # MI355X_MICROARCH.md: 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--inds", type=int, default=10000, help="analysed F2 individuals per GPU")
+    ap.add_argument("--chroms", type=int, default=20)
+    ap.add_argument("--snps-per-chrom", type=int, default=2500)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this process's CPU share)")
+    ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
+    return ap.parse_args()
+
+
+def generate_on_gpu(ctx, args, rank, device, pos, starts):
+    """Synthetic F2 genotypes generated on the GPU (torch) and handed to the library as
+    device rows: founders A=(1,1), B=(2,2); every F2 = two F1 gametes with Haldane crossovers;
+    unphased dosage, sure = 0.02, hw = 0.5."""
+    M = len(pos)
+    n = args.inds
+    ctx.alloc_blank_rows(3 + n)
+    d = np.diff(pos, prepend=pos[0])
+    rho = 0.5 * (1.0 - np.exp(-0.02 * np.maximum(d, 0.0)))
+    rho[np.asarray(starts[:-1])] = 0.5
+    rho_t = torch.tensor(rho, dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(args.seed + 7919 * rank)
+
+    def put(row0, packed):
+        k = packed.shape[0]
+        sure = torch.full((k, M, 2), 0.02, dtype=torch.float64, device=device)
+        hw = torch.full((k, M), 0.5, dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+        ctx.update_rows_device(row0, k, packed.data_ptr(), sure.data_ptr(), hw.data_ptr())
+
+    founders = torch.empty((2, M), dtype=torch.uint8, device=device)
+    founders[0] = 1 | (1 << 4)
+    founders[1] = 2 | (2 << 4)
+    put(1, founders)
+    chunk = 500
+    keep = None
+    for i0 in range(0, n, chunk):
+        k = min(chunk, n - i0)
+        strands = []
+        for _ in range(2):
+            rec = (torch.rand((k, M), generator=gen, device=device) < rho_t).to(torch.int32)
+            strands.append(torch.cumsum(rec, dim=1) & 1)
+        dosage = strands[0] + strands[1]
+        a0 = torch.where(dosage == 2, 2, 1)
+        a1 = torch.where(dosage == 0, 1, 2)
+        packed = (a0 | (a1 << 4)).to(torch.uint8).contiguous()
+        put(3 + i0, packed)
+        if i0 == 0:
+            keep = packed.cpu().numpy()   # sample for the CPU baseline leg
+    return keep
+
+
+def host_cpu_share():
+    """CPUs this process may really use: affinity mask and cgroup quota, not the host's count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(sample_packed, pos, starts, args):
+    """CPU path timed beside the GPU on a bounded sample of the same workload: the first
+    individuals of rank 0 on chromosome 1.  kind "reference" = the reference's own code
+    (oracle/_ref, HOT LOOP 1 as in cnF2freq.cpp:5294-5403); kind "port" = the C restatement
+    (oracle/, sweep + closed-form dosage rows).  The oracle is the thing timed here, never
+    the thing shipped."""
+    from cnf2freq_amd import synth
+    first, last = int(starts[0]), int(starts[1]) - 1
+    mc = last - first + 1
+    threads = args.cpu_threads or host_cpu_share()
+
+    def build_ped(k):
+        par, gen, empty, row_of, dous = synth.f2_pedigree_tables(k)
+        allele = np.zeros((3 + k, mc, 2), np.uint8)
+        allele[1], allele[2] = 1, 2
+        pk = sample_packed[:k, first:last + 1]
+        allele[3:, :, 0] = pk & 15
+        allele[3:, :, 1] = pk >> 4
+        sure = np.where(allele != 0, 0.02, 0.0)
+        hw = np.full((3 + k, mc), 0.5)
+        ped = synth.Pedigree(["r%d" % i for i in range(len(par))], par, gen, empty, row_of, allele, sure, hw,
+                             pos[first:last + 1].copy(), np.array([0, mc], np.int32), dous)
+        ped.founder_flags()
+        return ped
+
+    kind = "port"
+    try:
+        from oracle.ref_extract import pyref
+        if pyref.available(ieee=False):
+            kind = "reference"
+    except Exception:
+        kind = "port"
+
+    def run(k):
+        ped = build_ped(k)
+        if kind == "reference":
+            R = pyref.RefPed(ped, ieee=False)
+            R.sweep_batch(ped.dous[:min(k, threads)], threads=threads)   # warm the thread-private stores
+            t0 = time.perf_counter()
+            _, used = R.sweep_batch(ped.dous, threads=threads)
+            return time.perf_counter() - t0, used
+        from oracle.pyoracle import OraclePed
+        a, s, h = ped.dense()
+        o = OraclePed(a, s, h, ped.par, ped.empty, ped.pos)
+        t0 = time.perf_counter()
+        r = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2, n_threads=threads)
+        return time.perf_counter() - t0, r["threads"]
+
+    k_max = sample_packed.shape[0]
+    k = min(k_max, max(threads, 8))
+    dt, used = run(k)
+    rate = k * mc / dt
+    want = int(min(k_max, max(k, rate * args.cpu_seconds / mc)))
+    if want > k * 1.5:
+        k = want
+        dt, used = run(k)
+        rate = k * mc / dt
+    what = ("HOT LOOP 1 (8 shift modes fwd+bwd, cnF2freq.cpp:5375-5382)" if kind == "reference"
+            else "fwd+bwd over 8 shift modes + closed-form dosage rows")
+    return {"value": rate, "unit": "individual*marker/s", "cores": int(used), "kind": kind,
+            "sample": "%d F2 individuals x %d markers (chromosome 1 of the GPU workload), %.1f s, %s"
+                      % (k, mc, dt, what)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    from cnf2freq_amd import capi, synth
+
+    pos, starts = synth.make_map(args.chroms, args.snps_per_chrom)
+    M = len(pos)
+    n = args.inds
+    ctx = capi.Context(local)
+    ctx.upload_map(pos, starts)
+    sample = generate_on_gpu(ctx, args, rank, device, pos, starts)
+    par, gen, empty, row_of, dous = synth.f2_pedigree_tables(n)
+    ctx.upload_pedigree(par, empty, gen, row_of, dous)
+
+    factors = torch.empty((n, args.chroms, 8), dtype=torch.float64, device=device)
+    loglik = torch.empty((n, args.chroms), dtype=torch.float64, device=device)
+    dosage = torch.empty((n, M, 3), dtype=torch.float64, device=device)
+    gather_list = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and rank == 0:
+        gather_list = [torch.empty_like(dosage) for _ in range(world)]
+        gather_ll = [torch.empty_like(loglik) for _ in range(world)]
+
+    kernel_ms = []
+
+    def step():
+        ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr())
+        ctx.sync()
+        kernel_ms.append(ctx.last_kernel_ms())
+        if do_gather:
+            # the one collective of the path: posteriors to rank 0 over xGMI (RCCL)
+            dist.gather(loglik, gather_ll if rank == 0 else None, dst=0)
+            dist.gather(dosage, gather_list if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        units_per_step = float(n) * M * world
+        value = units_per_step * args.steps / dt
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = (float(n) * M * B_UNIT) / (k_ms * 1e-3) / 1e9   # GB/s, this rank's launch
+        traffic = None
+        try:
+            tj = json.load(open(args.traffic_file))
+            if tj.get("inds") == n and tj.get("markers") == M:
+                traffic = tj.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+        ll = loglik.cpu().numpy()
+        out = {
+            "metric": "individual*marker fwd-bwd steps/sec (all 8 shift modes, forward+backward, dosage rows)",
+            "value": value, "unit": "individual*marker/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic F2 intercross, %d individuals x %d SNPs per GPU (%d chromosomes x %d + 1 "
+                                   "dummy marker each = %d markers swept), private empty F1 parents, 2 inbred founders"
+                                   % (n, args.chroms * args.snps_per_chrom, args.chroms, args.snps_per_chrom, M),
+                       "individuals_per_gpu": n, "markers": M, "shift_modes": 8, "states": 64,
+                       "parallelism": "individuals sharded over %d GPU(s)%s" % (
+                           world, ", one RCCL gather of posteriors to rank 0" if do_gather else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
+                         "kernel": "cnf2::fb_kernel<false>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_unit": B_UNIT},
+            "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
+        }
+        if args.cpu_seconds > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sample, pos, starts, args)
+                out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline must never take the GPU line down
+                out["cpu_baseline"] = {"value": None, "unit": "individual*marker/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

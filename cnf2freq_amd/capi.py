@@ -20,7 +20,8 @@ IGNORED = -1e30
 # every symbol include/cnf2hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "cnf2_device_count", "cnf2_ctx_create", "cnf2_ctx_destroy", "cnf2_last_error", "cnf2_version",
-    "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_upload_pedigree",
+    "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
+    "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
 ]
@@ -52,6 +53,7 @@ def load():
         L.cnf2_upload_map.argtypes = [vp, vp, i32, vp, i32, vp]
         L.cnf2_upload_rows.argtypes = [vp, i32, vp, vp, vp]
         L.cnf2_update_rows.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.cnf2_update_rows_device.argtypes = [vp, i32, i32, vp, vp, vp]
         L.cnf2_upload_pedigree.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32]
         L.cnf2_window_info.argtypes = [vp, i32, vp]
         L.cnf2_sweep.argtypes = [vp, i32, i32, vp, vp, vp, C.c_uint32]
@@ -115,6 +117,14 @@ class Context:
         hw = np.ascontiguousarray(hw, np.float64)
         assert allele.shape == sure.shape == hw.shape + (2,) and hw.shape[1] == self.n_markers
         self._chk(self.L.cnf2_upload_rows(self.h, hw.shape[0], _p(allele), _p(sure), _p(hw)), "cnf2_upload_rows")
+
+    def alloc_blank_rows(self, n_rows):
+        self._chk(self.L.cnf2_upload_rows(self.h, n_rows, None, None, None), "cnf2_upload_rows(blank)")
+
+    def update_rows_device(self, row0, n, d_allele8, d_sure, d_hw):
+        """Device pointers (ints): packed allele bytes [n][M], sure [n][M][2], hw [n][M]."""
+        self._chk(self.L.cnf2_update_rows_device(self.h, row0, n, C.c_void_p(d_allele8), C.c_void_p(d_sure),
+                                                 C.c_void_p(d_hw)), "cnf2_update_rows_device")
 
     def update_rows(self, row0, allele, sure, hw):
         allele = np.ascontiguousarray(allele, np.uint8)

@@ -217,9 +217,23 @@ static int copy_rows(cnf2_ctx* ctx, int row0, int n, const uint8_t* allele, cons
     return CNF2_OK;
 }
 
+static int blank_rows(cnf2_ctx* ctx)
+{
+    const size_t cnt = (size_t)ctx->n_rows * ctx->n_markers;
+    HIP_TRY(ctx, hipMemset(ctx->d_allele8, 0, cnt));
+    HIP_TRY(ctx, hipMemset(ctx->d_sure, 0, cnt * sizeof(double2)));
+    // haploweight of an individual without data is 0.5 (getind, cnF2freq.cpp:2491)
+    std::vector<double> half((size_t)ctx->n_markers, 0.5);
+    for (int r = 0; r < ctx->n_rows; r++)
+        HIP_TRY(ctx, hipMemcpy(ctx->d_hw + (size_t)r * ctx->n_markers, half.data(), sizeof(double) * ctx->n_markers,
+                               hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
 int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const double* sure, const double* hw)
 {
-    if (!ctx || n_rows <= 0 || !allele || !sure || !hw) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
+    const bool blank = !allele && !sure && !hw;
+    if (!ctx || n_rows <= 0 || (!blank && (!allele || !sure || !hw))) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
     if (ctx->n_markers <= 0) return fail(ctx, CNF2_ERR_STATE, "upload the map before the rows");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -235,7 +249,23 @@ int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const dou
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sure, cnt * sizeof(double2)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hw, cnt * sizeof(double)));
     ctx->n_rows = n_rows;
+    if (blank) return blank_rows(ctx);
     return copy_rows(ctx, 0, n_rows, allele, sure, hw);
+}
+
+int cnf2_update_rows_device(cnf2_ctx* ctx, int row0, int n, const uint8_t* d_allele8, const double* d_sure,
+                            const double* d_hw)
+{
+    if (!ctx || !d_allele8 || !d_sure || !d_hw) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
+    if (!ctx->d_allele8) return fail(ctx, CNF2_ERR_STATE, "no rows uploaded");
+    if (row0 < 0 || n < 0 || row0 + n > ctx->n_rows) return fail(ctx, CNF2_ERR_ARG, "row range out of bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t M = ctx->n_markers, cnt = (size_t)n * M;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_allele8 + (size_t)row0 * M, d_allele8, cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sure + (size_t)row0 * M, d_sure, cnt * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hw + (size_t)row0 * M, d_hw, cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
 }
 
 int cnf2_update_rows(cnf2_ctx* ctx, int row0, int n, const uint8_t* allele, const double* sure, const double* hw)

@@ -91,10 +91,24 @@ def make_map(n_chrom, markers_per_chrom, chrom_cm=100.0, dummy=True):
     return pos, starts
 
 
-def _meiosis(seed, stream, n, pos, chromstarts, genrec=-0.02):
-    """n gametes over the map: which grand-parental strand (0/1) is transmitted per marker.
-    Haldane crossover, rho = 0.5(1-exp(genrec*delta)) between adjacent markers."""
+def _meiosis(seed, stream, n, pos, chromstarts, genrec=-0.02, first=0, fast=False):
+    """n gametes (numbers first..first+n-1 of `stream`) over the map: which grand-parental
+    strand (0/1) is transmitted per marker.  Haldane crossover, rho = 0.5(1-exp(genrec*delta))
+    between adjacent markers.  fast=True draws from numpy's PCG64 instead of the counter-based
+    splitmix64 (bench-scale inputs; still deterministic in (seed, stream, first, n))."""
     M = len(pos)
+    if fast:
+        d = np.diff(pos, prepend=pos[0])
+        rho = (0.5 * (1.0 - np.exp(genrec * np.maximum(d, 0.0)))).astype(np.float32)
+        rho[np.asarray(chromstarts[:-1])] = 0.5
+        out = np.empty((n, M), dtype=np.uint8)
+        chunk = max(1, (1 << 25) // max(M, 1))
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            g = np.random.Generator(np.random.PCG64([seed, stream, first + a]))
+            rec = (g.random((b - a, M), dtype=np.float32) < rho[None, :]).astype(np.uint8)
+            out[a:b] = np.bitwise_xor.accumulate(rec, axis=1)
+        return out
     d = np.diff(pos, prepend=pos[0])
     rho = 0.5 * (1.0 - np.exp(genrec * np.maximum(d, 0.0)))
     rho[np.asarray(chromstarts[:-1])] = 0.5  # free recombination between chromosomes
@@ -103,11 +117,52 @@ def _meiosis(seed, stream, n, pos, chromstarts, genrec=-0.02):
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
         idx = (np.uint64(stream) << np.uint64(40)) + (
-            np.arange(a, b, dtype=np.uint64)[:, None] * np.uint64(M) + np.arange(M, dtype=np.uint64)[None, :])
+            np.arange(first + a, first + b, dtype=np.uint64)[:, None] * np.uint64(M)
+            + np.arange(M, dtype=np.uint64)[None, :])
         u = uniform(seed, idx)
         rec = (u < rho[None, :]).astype(np.uint8)
         out[a:b] = np.bitwise_xor.accumulate(rec, axis=1)
     return out
+
+
+def f2_genotype_rows(i0, i1, pos, starts, seed=12345, sure=0.02, missing=0.0, fast=False):
+    """Genotype rows (allele uint8 [n,M,2], sure f64 [n,M,2], hw f64 [n,M]) of F2 individuals
+    i0..i1-1: unphased allele-2 dosage of two F1 gametes, stored as the .gen reader does
+    (cnF2freq.cpp:6568-6587)."""
+    n, M = i1 - i0, len(pos)
+    g0 = _meiosis(seed, 1, n, pos, starts, first=i0, fast=fast)
+    g1 = _meiosis(seed, 2, n, pos, starts, first=i0, fast=fast)
+    dosage = g0 + g1
+    allele = np.empty((n, M, 2), np.uint8)
+    allele[:, :, 0] = np.where(dosage == 2, 2, 1)
+    allele[:, :, 1] = np.where(dosage == 0, 1, 2)
+    if missing > 0:
+        idx = (np.uint64(3) << np.uint64(40)) + (np.arange(i0, i1, dtype=np.uint64)[:, None] * np.uint64(M)
+                                                 + np.arange(M, dtype=np.uint64)[None, :])
+        allele[uniform(seed, idx) < missing] = 0
+    sr = np.where(allele != 0, sure, 0.0)
+    hw = np.full((n, M), 0.5)
+    return allele, sr, hw
+
+
+def f2_pedigree_tables(n_ind):
+    """par/gen/empty/row_of/dous of an F2 with private empty F1 parents, in readalphaped's
+    numbering (rows: 0 blank, 1 = A, 2 = B, 3+i = F2 i)."""
+    R = 2 + 3 * n_ind
+    par = np.full((R, 2), -1, np.int32)
+    gen = np.zeros(R, np.int32)
+    empty = np.ones(R, np.uint8)
+    row_of = np.zeros(R, np.int32)
+    row_of[0], row_of[1] = 1, 2
+    empty[0] = empty[1] = 0
+    r = 2 + 3 * np.arange(n_ind, dtype=np.int32)
+    par[r, 0], par[r, 1] = r + 1, r + 2
+    par[r + 1] = (0, 1)
+    par[r + 2] = (0, 1)
+    gen[r], gen[r + 1], gen[r + 2] = 2, 1, 1
+    empty[r] = 0
+    row_of[r] = 3 + np.arange(n_ind, dtype=np.int32)
+    return par, gen, empty, row_of, r.copy()
 
 
 def make_f2(n_ind, markers_per_chrom, n_chrom=1, seed=12345, chrom_cm=100.0, sure=0.02,

@@ -81,6 +81,12 @@ int cnf2_upload_rows(cnf2_ctx *ctx, int n_rows, const uint8_t *allele, const dou
                      const double *hw);
 int cnf2_update_rows(cnf2_ctx *ctx, int row0, int n, const uint8_t *allele, const double *sure,
                      const double *hw);
+/* cnf2_upload_rows with all three pointers NULL allocates n_rows blank rows (alleles 0,
+ * sure 0, hw 0.5: an individual without data, getind cnF2freq.cpp:2486-2493).
+ * cnf2_update_rows_device takes DEVICE pointers and the packed allele form the kernels use:
+ * d_allele8[n][n_markers] = first | second << 4; d_sure[n][n_markers][2]; d_hw[n][n_markers]. */
+int cnf2_update_rows_device(cnf2_ctx *ctx, int row0, int n, const uint8_t *d_allele8,
+                            const double *d_sure, const double *d_hw);
 
 /* Pedigree graph: replaces individer[] / individ::{pars,empty,gen} and `dous`
  * (readalphaped cnF2freq.cpp:6495-6540).  par[n_rec][2] record index or -1;
