@@ -43,6 +43,9 @@ struct cnf2_ctx {
     HostPedigree        ped;
     std::vector<Window> windows;     // one per analysed individual
     Window*             d_windows = nullptr;
+    bool                windows_dirty = true;   // rows or pedigree changed since the last derivation
+    uint8_t*            d_rowflags = nullptr;
+    int                 fast_blocks_per_cu = 1;
 
     // workspace
     Job*    d_jobs = nullptr;
@@ -125,6 +128,7 @@ int cnf2_ctx_create(int device, cnf2_ctx** out)
     }
     ctx->n_cu          = prop.multiProcessorCount;
     ctx->blocks_per_cu = fb_blocks_per_cu();
+    ctx->fast_blocks_per_cu = fb_fast_blocks_per_cu();
     *out = ctx;
     return CNF2_OK;
 }
@@ -139,6 +143,7 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     hipFree(ctx->d_sure);
     hipFree(ctx->d_hw);
     hipFree(ctx->d_windows);
+    hipFree(ctx->d_rowflags);
     hipFree(ctx->d_jobs);
     hipFree(ctx->d_spill);
     hipFree(ctx->d_factors);
@@ -249,6 +254,7 @@ int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const dou
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sure, cnt * sizeof(double2)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hw, cnt * sizeof(double)));
     ctx->n_rows = n_rows;
+    ctx->windows_dirty = true;
     if (blank) return blank_rows(ctx);
     return copy_rows(ctx, 0, n_rows, allele, sure, hw);
 }
@@ -261,6 +267,7 @@ int cnf2_update_rows_device(cnf2_ctx* ctx, int row0, int n, const uint8_t* d_all
     if (row0 < 0 || n < 0 || row0 + n > ctx->n_rows) return fail(ctx, CNF2_ERR_ARG, "row range out of bounds");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t M = ctx->n_markers, cnt = (size_t)n * M;
+    ctx->windows_dirty = true;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_allele8 + (size_t)row0 * M, d_allele8, cnt, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sure + (size_t)row0 * M, d_sure, cnt * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hw + (size_t)row0 * M, d_hw, cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -276,6 +283,7 @@ int cnf2_update_rows(cnf2_ctx* ctx, int row0, int n, const uint8_t* allele, cons
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n == 0) return CNF2_OK;
+    ctx->windows_dirty = true;
     return copy_rows(ctx, row0, n, allele, sure, hw);
 }
 
@@ -302,14 +310,36 @@ int cnf2_upload_pedigree(cnf2_ctx* ctx, int n_rec, const int32_t* par, const uin
     P.row_of.assign(row_of, row_of + n_rec);
     P.dous.assign(dous, dous + n_dous);
     derive_founders(P);
+    P.row_hom.clear();
+    ctx->windows.assign(n_dous, Window());
+    ctx->windows_dirty = true;
+    return CNF2_OK;
+}
+
+// (Re)derive the window tables: per-row "always homozygous" flags from the device rows, then
+// fixtrees per analysed individual.  Runs lazily before a sweep after rows or pedigree changed.
+static int prepare_windows(cnf2_ctx* ctx)
+{
+    if (!ctx->windows_dirty) return CNF2_OK;
+    HostPedigree& P = ctx->ped;
+    const int n_dous = (int)P.dous.size();
+    if (ctx->d_rowflags) HIP_TRY(ctx, hipFree(ctx->d_rowflags));
+    ctx->d_rowflags = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rowflags, ctx->n_rows));
+    launch_row_flags(ctx->d_allele8, ctx->d_sure, ctx->n_rows, ctx->n_markers, ctx->d_rowflags, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    P.row_hom.assign(ctx->n_rows, 0);
+    HIP_TRY(ctx, hipMemcpyAsync(P.row_hom.data(), ctx->d_rowflags, ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->windows.resize(n_dous);
-    for (int j = 0; j < n_dous; j++) derive_window(P, dous[j], &ctx->windows[j], nullptr);
+    for (int j = 0; j < n_dous; j++) derive_window(P, P.dous[j], &ctx->windows[j], nullptr);
     if (ctx->d_windows) HIP_TRY(ctx, hipFree(ctx->d_windows));
     ctx->d_windows = nullptr;
     if (n_dous > 0) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_windows, sizeof(Window) * n_dous));
         HIP_TRY(ctx, hipMemcpy(ctx->d_windows, ctx->windows.data(), sizeof(Window) * n_dous, hipMemcpyHostToDevice));
     }
+    ctx->windows_dirty = false;
     return CNF2_OK;
 }
 
@@ -319,7 +349,13 @@ int cnf2_window_info(cnf2_ctx* ctx, int ind, int32_t* out17)
     if (ind < 0 || ind >= (int)ctx->windows.size()) return fail(ctx, CNF2_ERR_ARG, "individual out of range");
     Window  w;
     int32_t slot_rec[7];
-    derive_window(ctx->ped, ctx->ped.dous[ind], &w, slot_rec);
+    {
+        // topology exactly as fixtrees leaves it: tie groups are not pruned by row content here
+        std::vector<uint8_t> keep;
+        keep.swap(ctx->ped.row_hom);
+        derive_window(ctx->ped, ctx->ped.dous[ind], &w, slot_rec);
+        keep.swap(ctx->ped.row_hom);
+    }
     out17[0] = w.shiftignore;
     out17[1] = w.flag2ignore;
     out17[2] = ctx->ped.founder[ctx->ped.dous[ind]];
@@ -333,9 +369,10 @@ int cnf2_window_info(cnf2_ctx* ctx, int ind, int32_t* out17)
 static int ready(cnf2_ctx* ctx)
 {
     if (!ctx) return CNF2_ERR_ARG;
-    if (!ctx->d_rho || !ctx->d_allele8 || !ctx->d_windows)
+    if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0)
         return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
-    return CNF2_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return prepare_windows(ctx);
 }
 
 static void base_params(cnf2_ctx* ctx, KernelParams* p)
@@ -375,27 +412,40 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
 
     const size_t n_jobs = (size_t)n * ctx->n_chrom;
     if (n_jobs > 0x7fffffff) return fail(ctx, CNF2_ERR_ARG, "too many jobs in one call");
-    // job list: individuals x chromosomes (the loops at cnF2freq.cpp:5283 and 5294)
-    std::vector<Job> jobs(n_jobs);
-    size_t           k = 0;
-    for (int c = 0; c < ctx->n_chrom; c++)
-        for (int j = 0; j < n; j++) {
-            Job jb;
-            jb.ind   = j;
-            jb.first = ctx->chromstarts[c];
-            jb.last  = ctx->chromstarts[c + 1] - 1;
-            jb.chrom = c;
-            jobs[k++] = jb;
-        }
+    // job list: individuals x chromosomes (the loops at cnF2freq.cpp:5283 and 5294), windows
+    // without an active tie group first (fast kernel), tied windows after (general kernel)
+    std::vector<Job> jobs;
+    jobs.reserve(n_jobs);
+    size_t n_fast = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int c = 0; c < ctx->n_chrom; c++)
+            for (int j = 0; j < n; j++) {
+                const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
+                if (tied != (pass == 1)) continue;
+                Job jb;
+                jb.ind   = j;
+                jb.first = ctx->chromstarts[c];
+                jb.last  = ctx->chromstarts[c + 1] - 1;
+                jb.chrom = c;
+                jobs.push_back(jb);
+            }
+        if (pass == 0) n_fast = jobs.size();
+    }
+    const size_t n_general = n_jobs - n_fast;
     rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, n_jobs);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(Job) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // jobs vector goes out of scope
 
-    // grid: one wave per job in flight, capped at what is resident so that the spill stays small
-    int grid = (int)((n_jobs + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-    int cap  = ctx->n_cu * ctx->blocks_per_cu;
-    if (grid > cap) grid = cap;
+    // grids: one wave per job in flight, capped at what is resident so that the spill stays small
+    auto grid_for = [&](size_t nj, int per_cu) {
+        int g   = (int)((nj + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+        int cap = ctx->n_cu * per_cu;
+        return g > cap ? cap : g;
+    };
+    const int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
+    const int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
+    const int grid      = grid_fast > grid_gen ? grid_fast : grid_gen;
     const size_t stride = (size_t)max_chrom_len(ctx) * 512;
     const size_t need   = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
     {
@@ -424,7 +474,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     base_params(ctx, &p);
     p.windows      = ctx->d_windows + ind_begin;
     p.jobs         = ctx->d_jobs;
-    p.n_jobs       = (int)n_jobs;
+    p.n_jobs       = (int)n_fast;
     p.spill        = ctx->d_spill;
     p.spill_stride = stride;
     p.factors      = d_f;
@@ -434,8 +484,16 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
               ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    launch_fb(p, grid, false, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
+    if (n_fast > 0) {
+        launch_fb_fast(p, grid_fast, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (n_general > 0) {
+        p.jobs   = ctx->d_jobs + n_fast;
+        p.n_jobs = (int)n_general;
+        launch_fb(p, grid_gen, false, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
 

@@ -52,6 +52,10 @@ struct KernelParams {
 };
 
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
+void launch_fb_fast(const KernelParams& p, int grid, hipStream_t stream);
+void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
+                      hipStream_t stream);
+int  fb_fast_blocks_per_cu();
 void launch_emission(const KernelParams& p, int ind, int marker, double* out, hipStream_t stream);
 void launch_xor_selftest(double* out, hipStream_t stream);
 int  fb_blocks_per_cu();

@@ -22,6 +22,7 @@
 
 #include "cnf2_device.h"
 #include "cnf2_lane.h"
+#include "cnf2_emtab.h"
 
 namespace cnf2 {
 
@@ -412,6 +413,234 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
     }
 }
 
+
+// =====================================================================================
+// Fast kernel: windows without an active tie (the common case; F2, outbred, ...).
+// Same lane/register layout and the same sweep arithmetic as fb_kernel; the emission tables
+// are produced per tile of 8 markers by cnf2_emtab.h (lane = part x marker, division-free)
+// into LDS, so the per-marker critical path only reads them.
+// LDS per wave: 8 markers x TAB_STRIDE doubles: [0,64) tot, [64,68) root weights c[f][s0],
+// and for the backward pass [72,136) restricted totals, [136,200) class-2 parts.
+// =====================================================================================
+#define TAB_STRIDE 202   /* doubles per marker row: 16-B aligned rows, conflict-free producer stores */
+#define TAB_C 64
+#define TAB_R 72
+#define TAB_2 136
+
+struct FastCtx {
+    PartCfg pc;
+    int     part, mi;
+    int32_t row_root, row_par, row_tr, row_ot;
+    int     s0, s1, s2, lo;
+    bool    active;
+};
+
+template <bool CLASSES>
+__device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last)
+{
+    const int m = m0 + c.mi;
+    if (m <= last) {
+        const Slot root = load_slot(p, c.row_root, m);
+        const Slot par  = load_slot(p, c.row_par, m);
+        const Slot tr   = load_slot(p, c.row_tr, m);
+        const Slot ot   = load_slot(p, c.row_ot, m);
+        double tot[8], rtot[8], two[8], cw[2];
+        emtab_part<CLASSES>(c.pc, root, par, tr, ot, tot, rtot, two, cw);
+        double* row = tab + c.mi * TAB_STRIDE;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int idx = part_entry_index(c.part, e);
+            row[idx] = tot[e];
+            if (CLASSES) {
+                row[TAB_R + idx] = rtot[e];
+                row[TAB_2 + idx] = two[e];
+            }
+        }
+        if ((c.part & 5) == 0) {                    // P == 0, firstpar == 0: one writer per f
+            row[TAB_C + c.pc.f * 2 + 0] = cw[0];
+            row[TAB_C + c.pc.f * 2 + 1] = cw[1];
+        }
+    }
+}
+
+__device__ __forceinline__ void emission_from_row(const double* row, const FastCtx& c, double (&e)[8])
+{
+    const double cA0 = row[TAB_C + 0 + c.s0] * row[(0 << 5) | (0 << 4) | (c.s1 << 3) | c.lo];
+    const double cA1 = row[TAB_C + 2 + c.s0] * row[(0 << 5) | (1 << 4) | (c.s1 << 3) | c.lo];
+    const double* B0 = row + ((1 << 5) | (0 << 4) | (c.s2 << 3));
+    const double* B1 = row + ((1 << 5) | (1 << 4) | (c.s2 << 3));
+#pragma unroll
+    for (int j = 0; j < 8; j++) e[j] = cA0 * B0[j] + cA1 * B1[j];
+}
+
+__global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
+{
+    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
+
+    const int lane  = threadIdx.x & 63;
+    const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
+    const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
+    double*   tab   = lds[wib];
+    double*   spill = p.spill + (size_t)wave * p.spill_stride;
+
+    for (int job = wave; job < p.n_jobs; job += nwave) {
+        const Job    jb = p.jobs[job];
+        const Window w  = p.windows[jb.ind];
+        FastCtx      c;
+        c.part = lane >> 3;
+        c.mi   = lane & 7;
+        make_part(w, c.part, &c.pc, &c.row_par, &c.row_tr, &c.row_ot);
+        c.row_root  = w.row[0];
+        const int s = lane >> 3;
+        c.s0 = s & 1;
+        c.s1 = (s >> 1) & 1;
+        c.s2 = (s >> 2) & 1;
+        c.lo = lane & 7;
+        c.active = !(s & w.shiftignore) && s < w.shiftend;
+        const int first = jb.first, last = jb.last;
+        const int ntile = (last - first + 8) >> 3;
+
+        // ---------------------------------------------------------------- forward
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = 1.0 / 64.0;
+        double mant = 1.0;
+        int    expo = 0;
+        bool   dead = false;
+        for (int t = 0; t < ntile; t++) {
+            const int m0 = first + t * 8;
+            produce_tile<false>(p, c, tab, m0, last);
+            wave_lds_fence();
+            const int mend = (m0 + 7 < last) ? m0 + 7 : last;
+            for (int m = m0; m <= mend; m++) {
+                double e[8];
+                emission_from_row(tab + (m - m0) * TAB_STRIDE, c, e);
+                double* sp = spill + (size_t)(m - first) * 512 + lane;
+#pragma unroll
+                for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] *= e[j];
+                scale_chain(a, &mant, &expo, &dead);
+                if (m < last) {
+                    const double2 r = p.rho[m];
+                    transition(a, r.x, r.y);
+                }
+            }
+            wave_lds_fence();
+        }
+
+        // ---------------------------------------------------------------- likelihoods
+        double fs = dead ? (double)CNF2_MINFACTOR_F : (log(mant) + (double)expo * 0.69314718055994530942);
+        if (!c.active) fs = CNF2_IGNORED_D;
+        double fmaxv = across_chains_max(fs);
+        fmaxv        = fmax(fmaxv, -1e15);
+        double term  = c.active ? exp(fs - fmaxv) : 0.0;
+        double real  = across_chains_sum(term);
+        double factor = fmaxv + log(real);
+        if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = fs;
+        if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = factor;
+        const bool   skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;
+        const double ws   = (c.active && !skip && !(factor - fs > 40.0)) ? exp(fs - factor) : 0.0;
+        if (p.flags & KP_NO_DOSAGE) continue;
+
+        // ---------------------------------------------------------------- backward + rows
+        double b[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) b[j] = 1.0;
+        double bmant = 1.0;
+        int    bexpo = 0;
+        bool   bdead = false;
+        for (int t = ntile - 1; t >= 0; t--) {
+            const int m0 = first + t * 8;
+            produce_tile<true>(p, c, tab, m0, last);
+            wave_lds_fence();
+            const int mend = (m0 + 7 < last) ? m0 + 7 : last;
+            for (int m = mend; m >= m0; m--) {
+                const double* row = tab + (m - m0) * TAB_STRIDE;
+                double        e[8];
+                emission_from_row(row, c, e);
+                const double* sp = spill + (size_t)(m - first) * 512 + lane;
+                double        wj[8], D = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    wj[j] = sp[j * 64] * b[j];
+                    D += wj[j] * e[j];
+                }
+                double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const int     ia = (0 << 5) | (f << 4) | (c.s1 << 3) | c.lo;
+                    const double* Br = row + TAB_R + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                    const double* B1 = row + TAB_2 + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                    const double  cf = row[TAB_C + f * 2 + c.s0];
+                    const double  av = cf * row[TAB_R + ia], a1 = cf * row[TAB_2 + ia];
+                    double        sb = 0.0, sb1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        sb += wj[j] * Br[j];
+                        sb1 += wj[j] * B1[j];
+                    }
+                    n_tot += av * sb;
+                    n_a1 += a1 * sb;
+                    n_b1 += av * sb1;
+                    n_2 += a1 * sb1;
+                }
+                D     = chain_sum(D);
+                n_tot = chain_sum(n_tot);
+                n_a1  = chain_sum(n_a1);
+                n_b1  = chain_sum(n_b1);
+                n_2   = chain_sum(n_2);
+                const double scale = (D > 0.0) ? ws / D : 0.0;
+                double d2 = across_chains_sum(scale * n_2);
+                double d1 = across_chains_sum(scale * (n_a1 + n_b1 - 2.0 * n_2));
+                double d0 = across_chains_sum(scale * (n_tot - n_a1 - n_b1 + n_2));
+                if (lane == 0) {
+                    if (!(p.flags & KP_RAW_DOSAGE)) {
+                        double tsum = d0 + d1 + d2;
+                        double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
+                        d0 *= inv;
+                        d1 *= inv;
+                        d2 *= inv;
+                    }
+                    double* out = p.dosage + ((size_t)jb.ind * p.n_markers + m) * 3;
+                    out[0] = d0;
+                    out[1] = d1;
+                    out[2] = d2;
+                }
+                if (m > first) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) b[j] *= e[j];
+                    scale_chain(b, &bmant, &bexpo, &bdead);
+                    const double2 r = p.rho[m - 1];
+                    transition(b, r.x, r.y);
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// per-row flag: every marker homozygous (or doubly unknown) with equal sure -- such an ancestor
+// can never make a tie group active (cnF2freq.cpp:3488: its zero-weight paths are the pruned ones)
+__global__ __launch_bounds__(256) void row_flags_kernel(const uint8_t* allele8, const double2* sure, int n_markers,
+                                                        uint8_t* flags)
+{
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * n_markers;
+    int          mine = 0;
+    for (int m = threadIdx.x; m < n_markers; m += blockDim.x) {
+        const uint8_t ap = allele8[base + m];
+        const double2 s  = sure[base + m];
+        if ((ap & 15) != (ap >> 4) || s.x != s.y) mine = 1;
+    }
+    if (mine) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 0 : 1;
+}
+
 // Parity hook: path-free emission e_s(g) of one (individual, marker) for the 8 shift modes,
 // through exactly the producer/consumer code of the sweep.
 __global__ __launch_bounds__(64) void emission_kernel(KernelParams p, int ind, int marker, double* out)
@@ -453,6 +682,24 @@ __global__ __launch_bounds__(64) void xor_selftest_kernel(double* out)
     out[3 * 64 + lane] = lane_xor8(v);
     out[4 * 64 + lane] = lane_xor16(v);
     out[5 * 64 + lane] = lane_xor32(v);
+}
+
+void launch_fb_fast(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fb_fast_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+
+void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
+                      hipStream_t stream)
+{
+    hipLaunchKernelGGL(row_flags_kernel, dim3(n_rows), dim3(256), 0, stream, allele8, sure, n_markers, flags);
+}
+
+int fb_fast_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fb_fast_kernel, CNF2_BLOCK, 0) != hipSuccess) n = 2;
+    return n < 1 ? 1 : n;
 }
 
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream)

@@ -91,6 +91,16 @@ void derive_window(const HostPedigree& P, int rec, Window* w, int32_t* slot_rec_
             if (in_relmap[j] && slot_rec[j] == slot_rec[i]) multi = true;
         // an ancestor that is also the individual itself cannot occur (slot 0 is the child)
         if (!multi) continue;
+        // An ancestor whose two alleles are equal (or both unknown) with equal sure at every marker
+        // can never activate the all-or-none rule: the only paths it would prune have weight 0
+        // (cnF2freq.cpp:1235-1239 and 3488).  Such windows stay on the fast kernel.
+        // Only for grandparent slots: their localshift is 0 in every slot (cnF2freq.cpp:986), so the
+        // forced phase is the same nonzero-weight allele everywhere; a parent in both parent slots
+        // sees two different shift bits and keeps its group.
+        bool gp_only = true;
+        for (int j = i; j < 7; j++)
+            if (in_relmap[j] && slot_rec[j] == slot_rec[i] && (j == 1 || j == 4)) gp_only = false;
+        if (gp_only && !P.row_hom.empty() && P.row_hom[P.row_of[slot_rec[i]]]) continue;
         for (int j = i; j < 7; j++)
             if (in_relmap[j] && slot_rec[j] == slot_rec[i]) w->tie[j] = (int8_t)ng;
         ng++;

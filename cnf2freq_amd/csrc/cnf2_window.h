@@ -32,6 +32,7 @@ struct HostPedigree {
     std::vector<int32_t> gen;      // [n_rec]
     std::vector<int32_t> row_of;   // [n_rec]
     std::vector<uint8_t> founder;  // [n_rec] derived
+    std::vector<uint8_t> row_hom;  // [n_rows] optional: row is homozygous with equal sure at EVERY marker
     std::vector<int32_t> dous;     // analysed records
 };
 

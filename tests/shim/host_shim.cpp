@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "cnf2_lane.h"
+#include "cnf2_emtab.h"
 
 using namespace cnf2;
 
@@ -86,6 +87,38 @@ int shim_emtab(int n_rec, const int32_t* par, const uint8_t* empty, const int32_
         RootTerms R;
         root_terms(root, root_attop, f, &R);
         for (int s0 = 0; s0 < 2; s0++) c4[f * 2 + s0] = R.cbase * phase_weight(root, f ^ s0);
+    }
+    return w.n_groups;
+}
+
+// Same tables through the tile producer of the fast kernel (cnf2_emtab.h), no ties:
+// tot/rtot/two[64] in table-index order, c4[f*2+s0] = root weight.
+int shim_emtab_fast(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                    const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+                    int n_markers, int rec, int marker, double* tot, double* rtot, double* two, double* c4)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    auto slot_at = [&](int row) {
+        size_t i = (size_t)row * n_markers + marker;
+        return unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    };
+    Slot root = slot_at(w.row[0]);
+    for (int part = 0; part < 8; part++) {
+        PartCfg c;
+        int32_t rp, rt, ro;
+        make_part(w, part, &c, &rp, &rt, &ro);
+        double t[8], r[8], t2[8], cw[2];
+        emtab_part<true>(c, root, slot_at(rp), slot_at(rt), slot_at(ro), t, r, t2, cw);
+        for (int e = 0; e < 8; e++) {
+            int idx = part_entry_index(part, e);
+            tot[idx] = t[e];
+            rtot[idx] = r[e];
+            two[idx] = t2[e];
+        }
+        c4[c.f * 2 + 0] = cw[0];
+        c4[c.f * 2 + 1] = cw[1];
     }
     return w.n_groups;
 }

@@ -116,3 +116,31 @@ def test_restricted_class_split_reproduces_reference_rows(shim, seed):
                             row[1] += w[g] * c * (a1 * (b - b1) + (a - a1) * b1)
                             row[0] += w[g] * c * (a - a1) * (b - b1)
             np.testing.assert_allclose(row, r["dosage"][m], rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_fast_tile_producer_matches_general_producer(shim, seed):
+    """cnf2_emtab.h (division-free tile producer of the fast kernel) against cnf2_emission.h:
+    same emission e_s(g) and same class-split products for every state and shift mode."""
+    ped = synth.make_random_windows(40, 4, seed=seed)
+    tot, rtot, two, c4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    ftot, frtot, ftwo, fc4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    g = np.arange(64)
+    for ind in ped.dous:
+        ind = int(ind)
+        for m in range(ped.n_markers):
+            args = _ped_args(ped) + [_p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, ind, m]
+            ng = shim.shim_emtab(*args, 0, _p(tot), _p(rtot), _p(two), _p(c4))
+            shim.shim_emtab_fast(*args, _p(ftot), _p(frtot), _p(ftwo), _p(fc4))
+            kinds = [((tot, tot), (ftot, ftot))]
+            if ng == 0:  # the fast producer has no tie rule; tied windows take the general kernel
+                kinds += [((rtot, rtot), (frtot, frtot)), ((two, rtot), (ftwo, frtot)),
+                          ((rtot, two), (frtot, ftwo)), ((two, two), (ftwo, ftwo))]
+            for s in range(8):
+                s0, s1, s2 = s & 1, (s >> 1) & 1, (s >> 2) & 1
+                for (ta, tb), (fa, fb) in kinds:
+                    want = sum(c4[f * 2 + s0] * ta[lane_index(0, f, s1, g & 7)] * tb[lane_index(1, f, s2, g >> 3)]
+                               for f in range(2))
+                    got = sum(fc4[f * 2 + s0] * fa[lane_index(0, f, s1, g & 7)] * fb[lane_index(1, f, s2, g >> 3)]
+                              for f in range(2))
+                    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
