@@ -269,7 +269,7 @@ def main():
                            world, ", one RCCL gather of posteriors to rank 0" if do_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
-                         "kernel": "cnf2::fb_kernel<false>", "kernel_ms": k_ms,
+                         "kernel": "cnf2::fb_fast_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": B_UNIT},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
         }

@@ -446,7 +446,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     const int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
     const int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
     const int grid      = grid_fast > grid_gen ? grid_fast : grid_gen;
-    const size_t stride = (size_t)max_chrom_len(ctx) * 512;
+    const size_t stride = (size_t)max_chrom_len(ctx) * 520;   // SPILL_ROW of the fast kernel (general kernel uses 512)
     const size_t need   = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
     {
         size_t capd = ctx->spill_bytes / sizeof(double);

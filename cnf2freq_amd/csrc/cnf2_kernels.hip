@@ -195,14 +195,26 @@ __device__ __forceinline__ void emission_from_table(const double* tab, const Lan
 
 // adjustprobs' scaling for the 8 chains at once (cnF2freq.cpp:1656-1669).
 // mant/expo carry prod(sum) as mant * 2^expo; dead = a sum <= 0 was seen (factor := MINFACTOR).
-__device__ __forceinline__ double scale_chain(double (&v)[8], double* mant, int* expo, bool* dead)
+// 1/x for a positive normal double: hardware estimate + two Newton steps (full double accuracy up
+// to the last bit or two; the reference divides each state by sum, cnF2freq.cpp:1664-1667).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r        = fma(fma(-x, r, 1.0), r, r);
+    r        = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double scale_chain(double (&v)[8], double* mant, int* expo, bool* dead, double* inv_out = nullptr)
 {
     double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     sum        = chain_sum(sum);
+    if (inv_out) *inv_out = 1.0;
     if (sum <= 0.0) {
         *dead = true;               // probs stay as they are (all zero), factor = MINFACTOR
     } else {
-        double inv = 1.0 / sum;
+        double inv = fast_rcp(sum);
+        if (inv_out) *inv_out = inv;
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] *= inv;
         int    ex;
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 // LDS per wave: 8 markers x TAB_STRIDE doubles: [0,64) tot, [64,68) root weights c[f][s0],
 // and for the backward pass [72,136) restricted totals, [136,200) class-2 parts.
 // =====================================================================================
+#define SPILL_ROW 520    /* doubles per marker in the spill: 8 x 64 alpha-minus + 8 chain reciprocals */
 #define TAB_STRIDE 202   /* doubles per marker row: 16-B aligned rows, conflict-free producer stores */
 #define TAB_C 64
 #define TAB_R 72
@@ -508,6 +521,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
         double mant = 1.0;
         int    expo = 0;
         bool   dead = false;
+        double2 rf_next = p.rho[first];
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 8;
             produce_tile<false>(p, c, tab, m0, last);
@@ -516,16 +530,19 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
             for (int m = m0; m <= mend; m++) {
                 double e[8];
                 emission_from_row(tab + (m - m0) * TAB_STRIDE, c, e);
-                double* sp = spill + (size_t)(m - first) * 512 + lane;
+                const double2 r = rf_next;
+                if (m < last) rf_next = p.rho[m + 1];
+                double* sp = spill + (size_t)(m - first) * SPILL_ROW + lane;
 #pragma unroll
                 for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
 #pragma unroll
                 for (int j = 0; j < 8; j++) a[j] *= e[j];
-                scale_chain(a, &mant, &expo, &dead);
-                if (m < last) {
-                    const double2 r = p.rho[m];
-                    transition(a, r.x, r.y);
-                }
+                double inv;
+                scale_chain(a, &mant, &expo, &dead, &inv);
+                // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
+                // forward scale before each marker without a reduction
+                if (c.lo == 0) sp[512 - lane + s] = inv;
+                if (m < last) transition(a, r.x, r.y);
             }
             wave_lds_fence();
         }
@@ -545,27 +562,61 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
         if (p.flags & KP_NO_DOSAGE) continue;
 
         // ---------------------------------------------------------------- backward + rows
+        // Row of the reference: sum over (g, s, path) of val = exp(query - factor) by class
+        // (cnF2freq.cpp:5499-5508, 3536).  With Fpre(m) = prod_{k<m} sum_k (forward normalisers) and
+        // Bsuf(m) the backward ones, val summed over paths of class d and states is
+        //     exp(-factor) * Fpre_s(m) * Bsuf_s(m) * sum_g alphaminus_s(g) beta_s(g) e^{(d)}_s(g).
+        // Scales are carried as mantissa * 2^exponent; Fpre is rebuilt from the stored reciprocals.
         double b[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) b[j] = 1.0;
         double bmant = 1.0;
         int    bexpo = 0;
         bool   bdead = false;
+        double fmant = mant;          // becomes Fpre(m) after multiplying the reciprocals of k >= m
+        int    fexpo = expo;
+        // exp(-factor) = xm * 2^xe
+        const double nf  = -factor * 1.4426950408889634074;
+        const double nfk = floor(nf);
+        const double xm  = exp2(nf - nfk);
+        const int    xe  = (int)nfk;
+        const bool   chain_on = c.active && !skip && !dead && !(factor - fs > 40.0);   // cnF2freq.cpp:5420-5421
+        // software pipeline: the spill row, the reciprocals and the recombination fractions of the NEXT
+        // marker (m-1) are requested before the current marker is processed
+        double am_next[8], inv_next;
+        double2 r_next = make_double2(0.0, 0.0);
+        {
+            const double* sp = spill + (size_t)(last - first) * SPILL_ROW + lane;
+#pragma unroll
+            for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
+            inv_next = sp[512 - lane + s];
+            if (last > first) r_next = p.rho[last - 1];
+        }
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
             produce_tile<true>(p, c, tab, m0, last);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = mend; m >= m0; m--) {
-                const double* row = tab + (m - m0) * TAB_STRIDE;
+                double*       row = tab + (m - m0) * TAB_STRIDE;
                 double        e[8];
                 emission_from_row(row, c, e);
-                const double* sp = spill + (size_t)(m - first) * 512 + lane;
-                double        wj[8], D = 0.0;
+                double        wj[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    wj[j] = sp[j * 64] * b[j];
-                    D += wj[j] * e[j];
+                for (int j = 0; j < 8; j++) wj[j] = am_next[j] * b[j];
+                const double  inv_m = inv_next;
+                const double2 r_m   = r_next;
+                if (m > first) {
+                    const double* sp = spill + (size_t)(m - 1 - first) * SPILL_ROW + lane;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
+                    inv_next = sp[512 - lane + s];
+                    if (m - 1 > first) r_next = p.rho[m - 2];
+                }
+                {
+                    int ex;
+                    fmant = frexp(fmant * inv_m, &ex);
+                    fexpo += ex;
                 }
                 double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
 #pragma unroll
@@ -586,35 +637,54 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
                     n_b1 += av * sb1;
                     n_2 += a1 * sb1;
                 }
-                D     = chain_sum(D);
-                n_tot = chain_sum(n_tot);
-                n_a1  = chain_sum(n_a1);
-                n_b1  = chain_sum(n_b1);
-                n_2   = chain_sum(n_2);
-                const double scale = (D > 0.0) ? ws / D : 0.0;
-                double d2 = across_chains_sum(scale * n_2);
-                double d1 = across_chains_sum(scale * (n_a1 + n_b1 - 2.0 * n_2));
-                double d0 = across_chains_sum(scale * (n_tot - n_a1 - n_b1 + n_2));
-                if (lane == 0) {
-                    if (!(p.flags & KP_RAW_DOSAGE)) {
-                        double tsum = d0 + d1 + d2;
-                        double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
-                        d0 *= inv;
-                        d1 *= inv;
-                        d2 *= inv;
-                    }
-                    double* out = p.dosage + ((size_t)jb.ind * p.n_markers + m) * 3;
-                    out[0] = d0;
-                    out[1] = d1;
-                    out[2] = d2;
+                const double scale = chain_on ? ldexp(xm * fmant * bmant, xe + fexpo + bexpo) : 0.0;
+                double q2 = scale * n_2;
+                double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
+                double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+                // sum over groups of 4 lanes, then 16 partials per class go to LDS (the class tables of
+                // this marker are dead by now); the tile epilogue finishes the sum over the wave
+                q0 += lane_xor1(q0);
+                q1 += lane_xor1(q1);
+                q2 += lane_xor1(q2);
+                q0 += lane_xor2(q0);
+                q1 += lane_xor2(q1);
+                q2 += lane_xor2(q2);
+                wave_lds_fence();
+                if ((lane & 3) == 0) {
+                    double* red = row + TAB_R + (lane >> 2);
+                    red[0]  = q0;
+                    red[16] = q1;
+                    red[32] = q2;
                 }
                 if (m > first) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) b[j] *= e[j];
                     scale_chain(b, &bmant, &bexpo, &bdead);
-                    const double2 r = p.rho[m - 1];
-                    transition(b, r.x, r.y);
+                    transition(b, r_m.x, r_m.y);
                 }
+            }
+            wave_lds_fence();
+            // tile epilogue: lane mi < 8 finishes marker m0 + mi: 3 x 16 partials, normalise, store
+            if (lane < 8 && m0 + lane <= last) {
+                const double* red = tab + lane * TAB_STRIDE + TAB_R;
+                double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    d0 += red[i];
+                    d1 += red[16 + i];
+                    d2 += red[32 + i];
+                }
+                if (!(p.flags & KP_RAW_DOSAGE)) {
+                    const double tsum = d0 + d1 + d2;
+                    const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
+                    d0 *= inv;
+                    d1 *= inv;
+                    d2 *= inv;
+                }
+                double* out = p.dosage + ((size_t)jb.ind * p.n_markers + (m0 + lane)) * 3;
+                out[0] = d0;
+                out[1] = d1;
+                out[2] = d2;
             }
             wave_lds_fence();
         }
