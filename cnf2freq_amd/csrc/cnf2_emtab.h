@@ -22,6 +22,12 @@
 
 #include "cnf2_emission.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CNF2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CNF2_SCHED_FENCE() ((void)0)
+#endif
+
 namespace cnf2 {
 
 struct PartCfg {
@@ -209,11 +215,19 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
         leaf_match(trs, vtr[fp], &Ltr[fp]);
         leaf_match(ots, vot[fp], &Lot[fp]);
     }
+    double wl[2][2];         // [sp][fp]: parent phase weight, zeroed where !baseval (cnF2freq.cpp:1271)
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int fp = 0; fp < 2; fp++) {
+            const double w = c.firstpar ? pw[(fp ^ sp) ^ 1] : pw[fp ^ sp];   // no dynamic register indexing
+            wl[sp][fp] = (bzero[fp] || w == 0.0) ? 0.0 : w;
+        }
     const int KINDS = CLASSES ? 3 : 1;
-    // H[kind][fp][bit_ot][bit_tr]
-    double H[3][2][2][2];
+    // one kind at a time (0 tot, 1 restricted, 2 class-2 part): keeps few values live
 #pragma unroll
     for (int kind = 0; kind < KINDS; kind++) {
+        double H[2][2][2];   // [fp][bit_ot][bit_tr]
 #pragma unroll
         for (int fp = 0; fp < 2; fp++) {
             double G[2], OO[2];
@@ -229,33 +243,22 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
 #pragma unroll
             for (int bo = 0; bo < 2; bo++)
 #pragma unroll
-                for (int bt = 0; bt < 2; bt++) H[kind][fp][bo][bt] = OO[bo] * G[bt];
+                for (int bt = 0; bt < 2; bt++) H[fp][bo][bt] = OO[bo] * G[bt];
         }
-    }
+        double* out = kind == 0 ? tot : (kind == 1 ? rtot : two);
 #pragma unroll
-    for (int sp = 0; sp < 2; sp++) {
-        double wl[2];
+        for (int sp = 0; sp < 2; sp++)
 #pragma unroll
-        for (int fp = 0; fp < 2; fp++) {
-            const double w = c.firstpar ? pw[(fp ^ sp) ^ 1] : pw[fp ^ sp];   // no dynamic register indexing
-            wl[fp] = (bzero[fp] || w == 0.0) ? 0.0 : w;     // !baseval => 0 (cnF2freq.cpp:1271)
-        }
+            for (int bb = 0; bb < 2; bb++)
 #pragma unroll
-        for (int bb = 0; bb < 2; bb++)
-#pragma unroll
-            for (int ba = 0; ba < 2; ba++) {
-                // traced grandparent = pars[firstpar]: (bit_ot, bit_tr) = firstpar ? (ba, bb) : (bb, ba);
-                // selects between statically indexed registers (no dynamic indexing => no scratch)
-                const int e = sp * 4 + ba + 2 * bb;
-#define CNF2_HSEL(kind, fp) (c.firstpar ? H[kind][fp][ba][bb] : H[kind][fp][bb][ba])
-                tot[e] = wl[0] * CNF2_HSEL(0, 0) + wl[1] * CNF2_HSEL(0, 1);
-                if (CLASSES) {
-                    const double w1 = par_r0 ? 0.0 : wl[1];
-                    rtot[e] = wl[0] * CNF2_HSEL(1, 0) + w1 * CNF2_HSEL(1, 1);
-                    two[e]  = wl[0] * CNF2_HSEL(2, 0) + w1 * CNF2_HSEL(2, 1);
+                for (int ba = 0; ba < 2; ba++) {
+                    // traced grandparent = pars[firstpar]: (bit_ot, bit_tr) = firstpar ? (ba, bb) : (bb, ba);
+                    // selects between statically indexed registers (no dynamic indexing => no scratch)
+                    const double h0 = c.firstpar ? H[0][ba][bb] : H[0][bb][ba];
+                    const double h1 = c.firstpar ? H[1][ba][bb] : H[1][bb][ba];
+                    const double w1 = (kind >= 1 && par_r0) ? 0.0 : wl[sp][1];
+                    out[sp * 4 + ba + 2 * bb] = wl[sp][0] * h0 + w1 * h1;
                 }
-#undef CNF2_HSEL
-            }
     }
 }
 

@@ -448,15 +448,38 @@ struct FastCtx {
     bool    active;
 };
 
+// Raw inputs of one lane of the tile producer (4 window members at one marker), kept packed so
+// that they can be requested a whole tile ahead.
+struct RawSlots {
+    uint8_t ap[4];
+    double2 su[4];
+    double  hw[4];
+};
+
+__device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c, int m0, int lo_m, int hi_m, RawSlots* r)
+{
+    int m = m0 + c.mi;
+    m     = m < lo_m ? lo_m : (m > hi_m ? hi_m : m);      // clamp: lanes beyond the chromosome load a valid marker
+    const int32_t rows[4] = {c.row_root, c.row_par, c.row_tr, c.row_ot};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t i = (size_t)rows[k] * p.n_markers + m;
+        r->ap[k] = p.allele8[i];
+        r->su[k] = p.sure[i];
+        r->hw[k] = p.hw[i];
+    }
+}
+
 template <bool CLASSES>
-__device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last)
+__device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
+                                             const RawSlots& raw)
 {
     const int m = m0 + c.mi;
     if (m <= last) {
-        const Slot root = load_slot(p, c.row_root, m);
-        const Slot par  = load_slot(p, c.row_par, m);
-        const Slot tr   = load_slot(p, c.row_tr, m);
-        const Slot ot   = load_slot(p, c.row_ot, m);
+        const Slot root = unpack_slot(raw.ap[0], raw.su[0].x, raw.su[0].y, raw.hw[0]);
+        const Slot par  = unpack_slot(raw.ap[1], raw.su[1].x, raw.su[1].y, raw.hw[1]);
+        const Slot tr   = unpack_slot(raw.ap[2], raw.su[2].x, raw.su[2].y, raw.hw[2]);
+        const Slot ot   = unpack_slot(raw.ap[3], raw.su[3].x, raw.su[3].y, raw.hw[3]);
         double tot[8], rtot[8], two[8], cw[2];
         emtab_part<CLASSES>(c.pc, root, par, tr, ot, tot, rtot, two, cw);
         double* row = tab + c.mi * TAB_STRIDE;
@@ -486,7 +509,7 @@ __device__ __forceinline__ void emission_from_row(const double* row, const FastC
     for (int j = 0; j < 8; j++) e[j] = cA0 * B0[j] + cA1 * B1[j];
 }
 
-__global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
+__global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
 
@@ -522,9 +545,12 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
         int    expo = 0;
         bool   dead = false;
         double2 rf_next = p.rho[first];
+        RawSlots raw;
+        load_raw(p, c, first, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 8;
-            produce_tile<false>(p, c, tab, m0, last);
+            produce_tile<false>(p, c, tab, m0, last, raw);
+            if (t + 1 < ntile) load_raw(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = m0; m <= mend; m++) {
@@ -594,7 +620,12 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_fast_kernel(KernelParams p)
         }
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
-            produce_tile<true>(p, c, tab, m0, last);
+            {
+                // (no tile-ahead request here: the class tables already use the register budget)
+                RawSlots rawb;
+                load_raw(p, c, m0, first, last, &rawb);
+                produce_tile<true>(p, c, tab, m0, last, rawb);
+            }
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = mend; m >= m0; m--) {
