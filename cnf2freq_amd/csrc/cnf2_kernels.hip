@@ -35,15 +35,36 @@ __device__ __forceinline__ double dpp_mov(double old, double v)
     return __hiloint2double(hi, lo);
 }
 
+// full-wave DPP move without a tied "old" operand (every lane is written, so no copy is needed)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_all(double v)
+{
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// lane exchange through the LDS crossbar (no LDS memory is touched): BitMode swizzle, xor mask K
+template <int K>
+__device__ __forceinline__ double swizzle_xor(double v)
+{
+    int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (K << 10) | 0x1F);
+    int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (K << 10) | 0x1F);
+    return __hiloint2double(hi, lo);
+}
+
 // value of lane (id ^ 1), (id ^ 2), (id ^ 4)
-__device__ __forceinline__ double lane_xor1(double v) { return dpp_mov<0xB1, 0xF>(v, v); } // quad_perm [1,0,3,2]
-__device__ __forceinline__ double lane_xor2(double v) { return dpp_mov<0x4E, 0xF>(v, v); } // quad_perm [2,3,0,1]
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_mov_all<0xB1>(v); } // quad_perm [1,0,3,2]
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_mov_all<0x4E>(v); } // quad_perm [2,3,0,1]
+#ifdef CNF2_XOR4_DPP
 __device__ __forceinline__ double lane_xor4(double v)
 {
     double t = dpp_mov<0x104, 0x5>(v, v); // row_shl:4 into banks 0,2 (lanes with bit2 == 0 read lane+4)
     return dpp_mov<0x114, 0xA>(t, v);     // row_shr:4 into banks 1,3 (lanes with bit2 == 1 read lane-4)
 }
-__device__ __forceinline__ double lane_xor8(double v) { return dpp_mov<0x128, 0xF>(v, v); } // row_ror:8
+#else
+__device__ __forceinline__ double lane_xor4(double v) { return swizzle_xor<4>(v); }
+#endif
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128>(v); } // row_ror:8
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
 
