@@ -195,6 +195,7 @@ def main():
     if world > 1:
         dist.barrier()
     from cnf2freq_amd import capi, synth
+    from cnf2freq_amd import dist as cdist
 
     pos, starts = synth.make_map(args.chroms, args.snps_per_chrom)
     M = len(pos)
@@ -208,7 +209,7 @@ def main():
     factors = torch.empty((n, args.chroms, 8), dtype=torch.float64, device=device)
     loglik = torch.empty((n, args.chroms), dtype=torch.float64, device=device)
     dosage = torch.empty((n, M, 3), dtype=torch.float64, device=device)
-    gather_list = None
+    gather_list = gather_ll = None
     do_gather = world > 1 and not args.no_gather
     if do_gather and rank == 0:
         gather_list = [torch.empty_like(dosage) for _ in range(world)]
@@ -222,8 +223,8 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
             # the one collective of the path: posteriors to rank 0 over xGMI (RCCL)
-            dist.gather(loglik, gather_ll if rank == 0 else None, dst=0)
-            dist.gather(dosage, gather_list if rank == 0 else None, dst=0)
+            cdist.gather_to_root(loglik, 0, gather_ll if rank == 0 else None)
+            cdist.gather_to_root(dosage, 0, gather_list if rank == 0 else None)
 
     for _ in range(args.warmup):
         step()

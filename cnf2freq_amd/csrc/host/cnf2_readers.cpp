@@ -1,0 +1,242 @@
+// cnf2_readers.cpp -- see cnf2_readers.h.
+#include "cnf2_readers.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace cnf2host {
+
+// getind(string) / getind(int, true): cnF2freq.cpp:6480-6491 and 2456-2514.
+// The very first lookup in the reference is getind("0") at static-init time, which maps "0" to a
+// null individual; real individuals are numbered 1, 2, ... in order of first mention.
+int Pedigree::getind(const std::string& name)
+{
+    if (index.empty()) index["0"] = -1;
+    auto it = index.find(name);
+    if (it != index.end()) return it->second;
+    Individual ind;
+    ind.n    = (int)index.size();          // origindex = indmap.size() (cnF2freq.cpp:6485)
+    ind.name = name;
+    const size_t M = pos.size();
+    ind.allele.assign(M * 2, 0);           // UnknownMarkerVal (cnF2freq.cpp:2488)
+    ind.sure.assign(M * 2, 0.0);           // cnF2freq.cpp:2493
+    ind.hw.assign(M, 0.5);                 // cnF2freq.cpp:2491
+    inds.push_back(ind);
+    const int idx = (int)inds.size() - 1;
+    index[name]   = idx;
+    char buf[64];
+    snprintf(buf, sizeof(buf), "Creating %d", ind.n);   // cnF2freq.cpp:2464
+    log.push_back(buf);
+    return idx;
+}
+
+// cnF2freq.cpp:6669-6685
+bool read_alpha_map(FILE* in, Pedigree& P)
+{
+    if (!in) return false;
+    double prevval = 1e30, value;
+    int    nowmarker = 0;
+    while (fscanf(in, "%lf", &value) == 1) {
+        if (value < prevval) P.chromstarts.push_back(nowmarker);
+        nowmarker++;
+        P.pos.push_back(value);
+        prevval = value;
+    }
+    P.chromstarts.push_back((int32_t)P.pos.size());
+    return !P.pos.empty();
+}
+
+// cnF2freq.cpp:6495-6540
+bool read_alpha_ped(FILE* in, Pedigree& P)
+{
+    if (!in) return false;
+    char me[255], father[255], mother[255];
+    while (fscanf(in, "%254s %254s %254s", me, father, mother) == 3) {
+        char line[255];
+        line[0] = 0;
+        if (!fgets(line, 255, in)) line[0] = 0;
+        int gen = 0;
+        if (sscanf(line, "%d", &gen) != 1) gen = 0;
+        const int ime = P.getind(me);
+        const int iff = P.getind(father);
+        const int ifm = P.getind(mother);
+        if (ime < 0) continue;                          // an individual called "0": the reference dereferences null
+        P.inds[ime].empty = true;                       // cnF2freq.cpp:6511-6513
+        if (iff >= 0) P.inds[iff].empty = true;
+        if (ifm >= 0) P.inds[ifm].empty = true;
+        // The reference reads ifounderf->gen through a null pointer when a gen >= 2 line names "0" as a
+        // parent (cnF2freq.cpp:6515); here a missing parent counts as generation 0.
+        const int gf = iff >= 0 ? P.inds[iff].gen : 0;
+        const int gm = ifm >= 0 ? P.inds[ifm].gen : 0;
+        if (gen >= 2 && !gf && !gm) {                   // implicit private F1 parents (cnF2freq.cpp:6515-6527)
+            const int rf = P.getind(std::string(me) + "_aux_realf");
+            const int rm = P.getind(std::string(me) + "_aux_realm");
+            const int real[2] = {rf, rm};
+            for (int k = 0; k < 2; k++) {
+                P.inds[ime].pars[k]      = real[k];
+                P.inds[real[k]].gen      = 1;
+                P.inds[real[k]].pars[0]  = iff;
+                P.inds[real[k]].pars[1]  = ifm;
+                P.inds[real[k]].empty    = true;
+            }
+            P.inds[ime].gen = gen;
+        } else {
+            P.inds[ime].gen     = gen;
+            P.inds[ime].pars[0] = iff;
+            P.inds[ime].pars[1] = ifm;
+        }
+        if (gen >= 2) P.dous.push_back(ime);            // cnF2freq.cpp:6535-6538
+    }
+    return true;
+}
+
+// pdf of Binomial(n, 1/2) at k: what boost::math::pdf(binomial_distribution<double>(n), k) returns
+// for the default success fraction 0.5 (cnF2freq.cpp:6599-6611).
+static double binom_half_pdf(int n, int k)
+{
+    if (k < 0 || k > n) return 0.0;
+    return exp(lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0) - n * 0.69314718055994530942);
+}
+
+// cnF2freq.cpp:6542-6667
+bool read_alpha_gen(FILE* in, Pedigree& P)
+{
+    if (!in) return false;
+    const size_t M = P.pos.size();
+    const int haplo = P.getind("haplo");                // cnF2freq.cpp:6544-6549
+    for (size_t x = 0; x < M; x++) {
+        P.inds[haplo].allele[x * 2] = P.inds[haplo].allele[x * 2 + 1] = 9;
+        P.inds[haplo].sure[x * 2] = P.inds[haplo].sure[x * 2 + 1] = 0.0;
+    }
+    char me[255];
+    while (fscanf(in, "%254s", me) == 1) {
+        const int ime = P.getind(me);
+        if (ime < 0) return false;
+        const bool doublehaplo = (P.inds[ime].pars[1] == P.getind("haplo"));
+        P.inds[ime].empty = false;
+        int data = 0;
+        for (size_t x = 0; x < M; x++) {
+            char datastr[255];
+            if (fscanf(in, "%254s", datastr) != 1) datastr[0] = 0;
+            int data2 = 0;
+            const int numread = sscanf(datastr, "%d/%d", &data, &data2);
+            Individual& I = P.inds[ime];
+            I.hw[x] = 0.5;
+            if (numread == 1) {                         // cnF2freq.cpp:6565-6588
+                uint8_t a0 = 0, a1 = 0;
+                switch (data) {
+                case 0: a0 = 1; a1 = 1; break;
+                case 1: a0 = 1; a1 = 2; break;
+                case 2: a0 = 2; a1 = 2; break;
+                default: break;
+                }
+                I.allele[x * 2] = a0;
+                I.allele[x * 2 + 1] = a1;
+                if (a0 != 0) I.sure[x * 2] = I.sure[x * 2 + 1] = 0.02;
+            } else {                                    // read counts a/b (cnF2freq.cpp:6589-6662)
+                char buf[300];
+                snprintf(buf, sizeof(buf), "%s %d", datastr, numread);
+                P.log.push_back(buf);
+                if (data == data2 && !data) {
+                    I.allele[x * 2] = I.allele[x * 2 + 1] = 0;
+                    I.sure[x * 2] = I.sure[x * 2 + 1] = 0.0;
+                } else {
+                    double sure1 = 0, sure2 = 0, probsum = 0;
+                    for (int rl1 = 0; rl1 <= data; rl1++)
+                        for (int rl2 = 0; rl2 <= data2; rl2++) {
+                            int    l1 = rl1, l2 = rl2;
+                            double overallprob = (data ? binom_half_pdf(data, l1) : 1) * (data2 ? binom_half_pdf(data2, l2) : 1);
+                            double sureb1, sureb2;
+                            while (true) {
+                                sureb1 = 0.5;
+                                sureb2 = 0.5;
+                                if (l1 + l2) sureb1 = l1 / (double)(l1 + l2);
+                                if (data + data2 - l1 - l2) sureb2 = (data2 - l2) / (double)(data + data2 - l1 - l2);
+                                if (sureb1 + 1e-9 > 1 - sureb2) break;
+                                l1 = data - l1;
+                                l2 = data2 - l2;
+                            }
+                            overallprob *= pow(sureb1, l1) * pow(1 - sureb1, l2) * pow(sureb2, (data2 - l2)) * pow(1 - sureb2, data - l1);
+                            sure1 += sureb1 * overallprob;
+                            sure2 += sureb2 * overallprob;
+                            probsum += overallprob;
+                        }
+                    sure1 /= probsum;
+                    sure2 /= probsum;
+                    uint8_t mk[2] = {2, 1};
+                    double  ms[2] = {sure1, sure2};
+                    for (int k = 0; k < 2; k++)
+                        if (ms[k] > 0.5) {                // cnF2freq.cpp:6644-6652
+                            ms[k] = 1 - ms[k];
+                            mk[k] = (uint8_t)(k + 1);
+                        }
+                    I.allele[x * 2] = mk[0];
+                    I.allele[x * 2 + 1] = mk[1];
+                    I.sure[x * 2] = ms[0];
+                    I.sure[x * 2 + 1] = ms[1];
+                    snprintf(buf, sizeof(buf), "%d/%d turned into %d %d with %lf;%lf", data, data2, mk[0], mk[1], ms[0], ms[1]);
+                    P.log.push_back(buf);
+                }
+                if (doublehaplo) I.allele[x * 2 + 1] = 9;
+            }
+        }
+        Individual& I  = P.inds[ime];
+        I.prior_allele = I.allele;                      // cnF2freq.cpp:6664-6665
+        I.prior_sure   = I.sure;
+        I.has_prior    = true;
+    }
+    return true;
+}
+
+void cap_markers(Pedigree& P, int cap)
+{
+    if (cap <= 0 || cap >= (int)P.pos.size()) return;
+    P.pos.resize(cap);
+    std::vector<int32_t> cs;
+    for (size_t c = 0; c + 1 < P.chromstarts.size(); c++)
+        if (P.chromstarts[c] < cap) cs.push_back(P.chromstarts[c]);
+    cs.push_back(cap);
+    P.chromstarts = cs;
+    for (auto& I : P.inds) {
+        I.allele.resize((size_t)cap * 2);
+        I.sure.resize((size_t)cap * 2);
+        I.hw.resize(cap);
+        if (I.has_prior) {
+            I.prior_allele.resize((size_t)cap * 2);
+            I.prior_sure.resize((size_t)cap * 2);
+        }
+    }
+}
+
+void build_tables(const Pedigree& P, Tables& T)
+{
+    const size_t M = P.pos.size();
+    const int    R = (int)P.inds.size();
+    T.par.assign((size_t)R * 2, -1);
+    T.gen.assign(R, 0);
+    T.empty.assign(R, 0);
+    T.row_of.assign(R, 0);
+    T.dous.assign(P.dous.begin(), P.dous.end());
+    T.allele.assign(M * 2, 0);
+    T.sure.assign(M * 2, 0.0);
+    T.hw.assign(M, 0.5);
+    T.n_rows = 1;
+    for (int r = 0; r < R; r++) {
+        const Individual& I = P.inds[r];
+        T.par[r * 2]     = I.pars[0];
+        T.par[r * 2 + 1] = I.pars[1];
+        T.gen[r]         = I.gen;
+        T.empty[r]       = I.empty ? 1 : 0;
+        bool blank = true;
+        for (size_t x = 0; x < M && blank; x++)
+            if (I.allele[x * 2] || I.allele[x * 2 + 1] || I.sure[x * 2] != 0.0 || I.sure[x * 2 + 1] != 0.0 || I.hw[x] != 0.5)
+                blank = false;
+        if (blank) continue;
+        T.row_of[r] = T.n_rows++;
+        T.allele.insert(T.allele.end(), I.allele.begin(), I.allele.end());
+        T.sure.insert(T.sure.end(), I.sure.begin(), I.sure.end());
+        T.hw.insert(T.hw.end(), I.hw.begin(), I.hw.end());
+    }
+}
+
+}  // namespace cnf2host

@@ -1,0 +1,68 @@
+"""CPU suite: the N > 1 path (block partition of individuals + one gather to rank 0) with
+world_size 2 on the gloo backend.  The per-rank sweep is played by the oracle here (the
+checker standing in for the GPU, which this container does not have); the code under test is
+cnf2freq_amd/dist.py, the same functions bench.py and GPU runs use."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cnf2freq_amd import dist as cdist
+from cnf2freq_amd import synth
+from conftest import oracle_ped
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ped = synth.make_f2(7, 20, 1, seed=5, chrom_cm=30.0, missing=0.1)
+    o = oracle_ped(ped)
+
+    def sweep(i0, i1):
+        r = o.sweep_batch(ped.dous[i0:i1], ped.gen[ped.dous[i0:i1]], mode=2, n_threads=1)
+        return dict(factors=r["factors"], loglik=r["factor"], dosage=r["dosage"])
+
+    res = cdist.run_sharded(len(ped.dous), sweep)
+    if rank == 0:
+        full = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2, n_threads=1)
+        ok = (np.array_equal(res["factors"], full["factors"]) and np.array_equal(res["loglik"], full["factor"])
+              and np.array_equal(res["dosage"], full["dosage"]))
+        q.put(bool(ok))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 7, 10, 10000):
+        for world in (1, 2, 3, 8):
+            ranges = [cdist.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_sweep_and_gather_equals_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -170,3 +170,47 @@ def test_range_and_ragged_inputs(capi):
         np.testing.assert_allclose(full["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(full["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
+
+
+def test_drop_in_command_line_matches_oracle(capi, tmp_path):
+    """The `cnF2freq` executable on PlantImpute-format files: rows of the final iteration in
+    --output must be the oracle's normalised dosage rows to the 5 printed decimals."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    ped = synth.make_f2(5, 30, 2, seed=99, chrom_cm=50.0, missing=0.1)
+    names = ped.names
+    with open(tmp_path / "x.map", "w") as f:
+        f.write("\n".join("%.10g" % p for p in ped.pos) + "\n")
+    with open(tmp_path / "x.ped", "w") as f:
+        f.write("A 0 0\nB 0 0\n")
+        for r in ped.dous:
+            f.write("%s A B 2\n" % names[r])
+    tok = {(1, 1): "0", (1, 2): "1", (2, 2): "2", (0, 0): "9"}
+    with open(tmp_path / "x.gen", "w") as f:
+        for r in [0, 1] + list(ped.dous):
+            a = ped.allele[ped.row_of[r]]
+            f.write(names[r] + " " + " ".join(tok[(int(x[0]), int(x[1]))] for x in a) + "\n")
+    exe = os.path.join(ROOT, "cnf2freq_amd", "cnF2freq")
+    subprocess.run([exe, "--mapfile", str(tmp_path / "x.map"), "--pedfile", str(tmp_path / "x.ped"), "--genfile",
+                    str(tmp_path / "x.gen"), "--output", str(tmp_path / "out.txt"), "--count", "2", "--quiet"],
+                   check=True, capture_output=True)
+    text = open(tmp_path / "out.txt").read().split("\n")
+    o = oracle_ped(ped)
+    pos = 0
+    for c in range(2):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)["dosage"]
+        for j, r in enumerate(ped.dous):
+            assert text[pos] == "%s:%d" % (names[r], c + 1)
+            pos += 1
+            for m in range(last - first + 1):
+                got = [float(x) for x in text[pos].split("\t")]
+                assert len(got) == 3
+                assert np.allclose(got, want[j, m], atol=6e-6)
+                pos += 1
+            assert text[pos] == ""
+            pos += 1
+    # then the per-individual dump: "n name" followed by one line per marker (cnF2freq.cpp:8168-8186)
+    assert text[pos] == "1 A"
+    assert text[pos + 1].startswith("0.500000\t1\t1\t\t0.000000\t0.020000 0.020000 0.500000\t1\t1\t")
