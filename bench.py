@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this process's CPU share)")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank control flow on one GPU (posteriors staged through the host)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
 
@@ -182,8 +185,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local = 0
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
     torch.cuda.set_device(local)
@@ -211,9 +219,11 @@ def main():
     dosage = torch.empty((n, M, 3), dtype=torch.float64, device=device)
     gather_list = gather_ll = None
     do_gather = world > 1 and not args.no_gather
+    staged = world > 1 and args.backend == "gloo"
     if do_gather and rank == 0:
-        gather_list = [torch.empty_like(dosage) for _ in range(world)]
-        gather_ll = [torch.empty_like(loglik) for _ in range(world)]
+        gdev = torch.device("cpu") if staged else device
+        gather_list = [torch.empty(dosage.shape, dtype=dosage.dtype, device=gdev) for _ in range(world)]
+        gather_ll = [torch.empty(loglik.shape, dtype=loglik.dtype, device=gdev) for _ in range(world)]
 
     kernel_ms = []
 
@@ -223,8 +233,8 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
             # the one collective of the path: posteriors to rank 0 over xGMI (RCCL)
-            cdist.gather_to_root(loglik, 0, gather_ll if rank == 0 else None)
-            cdist.gather_to_root(dosage, 0, gather_list if rank == 0 else None)
+            cdist.gather_to_root(loglik.cpu() if staged else loglik, 0, gather_ll if rank == 0 else None)
+            cdist.gather_to_root(dosage.cpu() if staged else dosage, 0, gather_list if rank == 0 else None)
 
     for _ in range(args.warmup):
         step()
@@ -239,7 +249,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if staged else device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
