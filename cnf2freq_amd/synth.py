@@ -343,3 +343,60 @@ def make_random_windows(n_windows, n_markers, seed=4242):
                    pos, np.array([0, M], np.int32), np.array(dous, np.int32))
     ped.founder_flags()
     return ped
+
+
+def make_ail(n_f1, n_per_gen, n_gen, markers_per_chrom, n_chrom=1, seed=2024, chrom_cm=100.0,
+             sure=0.02, missing=0.0):
+    """Advanced intercross (config C3): 2 inbred founders, `n_f1` genotyped F1 (ped generation 1),
+    then `n_gen` random-mating generations of `n_per_gen` analysed individuals (ped generation
+    >= 2, explicit parents: readalphaped's direct-parent branch, cnF2freq.cpp:6528-6533).
+    Everyone genotyped.  Small populations make full/half-sib matings common, i.e. windows where
+    one heterozygous ancestor occupies several slots (the all-or-none rule of ignoreflag2)."""
+    pos, starts = make_map(n_chrom, markers_per_chrom, chrom_cm)
+    M = len(pos)
+    rs = np.random.RandomState(seed)
+    names, par, gen = ["A", "B"], [[-1, -1], [-1, -1]], [0, 0]
+    hap = [np.ones((M, 2), np.uint8), np.full((M, 2), 2, np.uint8)]
+    prev = []
+    stream = 100
+
+    def child(p0, p1, g, nm):
+        nonlocal stream
+        idx = len(names)
+        names.append(nm)
+        par.append([p0, p1])
+        gen.append(g)
+        h = np.empty((M, 2), np.uint8)
+        for k, p in enumerate((p0, p1)):
+            s = _meiosis(seed, stream, 1, pos, starts)[0]
+            stream += 1
+            h[:, k] = np.where(s == 0, hap[p][:, 0], hap[p][:, 1])
+        hap.append(h)
+        return idx
+
+    for i in range(n_f1):
+        prev.append(child(0, 1, 1, "F1_%d" % i))
+    dous = []
+    for g in range(n_gen):
+        cur = []
+        for i in range(n_per_gen):
+            p0, p1 = rs.choice(prev, 2, replace=False)
+            cur.append(child(int(p0), int(p1), 2 + g, "G%d_%d" % (g + 2, i)))
+        dous += cur
+        prev = cur
+    R = len(names)
+    hap = np.stack(hap)
+    d = (hap == 2).sum(axis=2)
+    allele = np.zeros((R + 1, M, 2), np.uint8)
+    allele[1:, :, 0] = np.where(d == 2, 2, 1)
+    allele[1:, :, 1] = np.where(d == 0, 1, 2)
+    if missing > 0:
+        miss = uniform(seed, (np.uint64(14) << np.uint64(40)) + np.arange(R * M, dtype=np.uint64)).reshape(R, M) < missing
+        allele[1:][miss] = 0
+    sr = np.zeros((R + 1, M, 2))
+    sr[1:] = np.where(allele[1:] != 0, sure, 0.0)
+    hw = np.full((R + 1, M), 0.5)
+    ped = Pedigree(names, np.array(par, np.int32), np.array(gen, np.int32), np.zeros(R, np.uint8),
+                   np.arange(1, R + 1, dtype=np.int32), allele, sr, hw, pos, starts, np.array(dous, np.int32))
+    ped.founder_flags()
+    return ped

@@ -214,3 +214,69 @@ def test_drop_in_command_line_matches_oracle(capi, tmp_path):
     # then the per-individual dump: "n name" followed by one line per marker (cnF2freq.cpp:8168-8186)
     assert text[pos] == "1 A"
     assert text[pos + 1].startswith("0.500000\t1\t1\t\t0.000000\t0.020000 0.020000 0.500000\t1\t1\t")
+
+
+def test_advanced_intercross_with_active_ties_against_oracle(capi):
+    """BASELINE config 3 shape: deeper pedigree, explicit parents, sib matings => heterozygous
+    ancestors in several window slots (general kernel) next to untied windows (fast kernel)."""
+    ped = synth.make_ail(6, 10, 4, 40, 2, seed=11, chrom_cm=60.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    tied = sum(1 for j in range(len(ped.dous)) if (ctx.window_info(j)["tie"] >= 0).any())
+    assert 0 < tied < len(ped.dous), "the fixture should mix tied and untied windows"
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    for c in range(2):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
+
+
+def test_reference_fanout_semantics_on_tied_windows(capi):
+    """Same as above against oracle mode 0 (the reference's own (g, s, path) fan-out) on a few
+    individuals: ties are where the closed form is least obvious."""
+    ped = synth.make_ail(4, 6, 3, 6, 1, seed=5, chrom_cm=20.0)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    raw = ctx.sweep(raw=True)
+    o = oracle_ped(ped)
+    checked = 0
+    for j, ind in enumerate(ped.dous):
+        if not (ctx.window_info(j)["tie"] >= 0).any():
+            continue
+        r0 = o.sweep_ind(int(ind), int(ped.gen[ind]), mode=0)
+        if r0["ok"]:
+            np.testing.assert_allclose(raw["dosage"][j], r0["dosage"], rtol=1e-7, atol=1e-12)
+            checked += 1
+    assert checked > 0
+    ctx.close()
+
+
+def test_full_length_chromosome_properties(capi):
+    """Size-independent checks at BASELINE config 2's chromosome length (2 501 markers), where the
+    oracle would be slow: rows are distributions, results do not depend on how individuals are
+    batched or on the job's position in the grid, likelihoods are finite and negative."""
+    ped = synth.make_f2(300, 2500, 1, seed=2, chrom_cm=100.0)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    full = ctx.sweep()
+    s = full["dosage"].sum(axis=2)
+    assert np.allclose(s, 1.0, atol=1e-12)
+    assert np.all(full["dosage"] >= 0)
+    assert np.all(np.isfinite(full["loglik"])) and np.all(full["loglik"] < 0)
+    a = ctx.sweep(0, 7)
+    b = ctx.sweep(7, 300)
+    assert np.array_equal(np.concatenate([a["dosage"], b["dosage"]]), full["dosage"])
+    assert np.array_equal(np.concatenate([a["loglik"], b["loglik"]]), full["loglik"])
+    # logsumexp identity between the per-mode and the total likelihoods
+    f = full["factors"][:, 0]
+    mx = f.max(axis=1, keepdims=True)
+    assert np.allclose(mx[:, 0] + np.log(np.exp(f - mx).sum(axis=1)), full["loglik"][:, 0], rtol=1e-12)
+    # spot check 3 individuals against the oracle at full length
+    o = oracle_ped(ped)
+    want = o.sweep_batch(ped.dous[:3], ped.gen[ped.dous[:3]], mode=2)
+    np.testing.assert_allclose(full["dosage"][:3], want["dosage"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(full["loglik"][:3, 0], want["factor"], rtol=1e-10)
+    ctx.close()
