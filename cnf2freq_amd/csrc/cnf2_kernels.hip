@@ -68,12 +68,15 @@ __device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
 
-// sum over the 8 lanes of a chain (lanes differing in bits 0-2); result in every lane
+// sum over the 8 lanes of a chain (lanes differing in bits 0-2); result in every lane.
+// Third step pairs lane i with lane 7-i of its group of 8 (row_half_mirror): after the two quad
+// steps every lane of a quad holds the quad total, so any quad<->quad pairing finishes the sum,
+// and this one is a plain DPP move (no trip through the LDS crossbar on the critical path).
 __device__ __forceinline__ double chain_sum(double v)
 {
     v += lane_xor1(v);
     v += lane_xor2(v);
-    v += lane_xor4(v);
+    v += dpp_mov_all<0x141>(v);
     return v;
 }
 // sum over the 8 chains of values that are already uniform inside each chain
@@ -99,13 +102,22 @@ __device__ __forceinline__ void transition(double (&a)[8], double r0, double r1)
 {
     // bit t uses genrec[TYPEGENS[t]], TYPEGENS = {1,0,0,1,0,0} (settings.h:23)
     const double k0 = 1.0 - r0, k1 = 1.0 - r1;
-    // bits 0..2: lanes
+    // bits 0..2: lanes.  All partner values of a stage are requested before any is used, so the
+    // eight exchanges overlap (the xor-4 stage goes through the LDS crossbar: one latency, not eight).
+    double q[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = k1 * a[j] + r1 * lane_xor1(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_xor1(a[j]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * lane_xor2(a[j]);
+    for (int j = 0; j < 8; j++) a[j] = k1 * a[j] + r1 * q[j];
 #pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * lane_xor4(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_xor2(a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * q[j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = lane_xor4(a[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * q[j];
     // bits 3..5: registers
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
@@ -230,19 +242,19 @@ __device__ __forceinline__ double scale_chain(double (&v)[8], double* mant, int*
 {
     double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     sum        = chain_sum(sum);
-    if (inv_out) *inv_out = 1.0;
-    if (sum <= 0.0) {
-        *dead = true;               // probs stay as they are (all zero), factor = MINFACTOR
-    } else {
-        double inv = fast_rcp(sum);
-        if (inv_out) *inv_out = inv;
+    // sum <= 0: probs stay as they are (they are all zero), factor = MINFACTOR (cnF2freq.cpp:1656-1660);
+    // written branch-free: a dead step scales by 1 and leaves the running scale alone
+    const bool   ok  = sum > 0.0;
+    const double ss  = ok ? sum : 1.0;
+    const double inv = fast_rcp(ss);
+    if (!ok) *dead = true;
+    if (inv_out) *inv_out = inv;
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] *= inv;
-        int    ex;
-        double mm = frexp(*mant * sum, &ex);
-        *mant     = mm;
-        *expo += ex;
-    }
+    for (int j = 0; j < 8; j++) v[j] *= inv;
+    int    ex;
+    double mm = frexp(*mant * ss, &ex);
+    *mant     = mm;
+    *expo += ex;
     return sum;
 }
 
