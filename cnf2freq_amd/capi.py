@@ -22,7 +22,8 @@ SYMBOLS = [
     "cnf2_device_count", "cnf2_ctx_create", "cnf2_ctx_destroy", "cnf2_last_error", "cnf2_version",
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
-    "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_emission",
+    "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
+    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
 ]
 
@@ -59,6 +60,9 @@ def load():
         L.cnf2_sweep.argtypes = [vp, i32, i32, vp, vp, vp, C.c_uint32]
         L.cnf2_sync.argtypes = [vp]
         L.cnf2_fwbw_store.argtypes = [vp, i32, i32, vp, vp]
+        L.cnf2_locked_query.argtypes = [vp, i32, i32, i32, vp]
+        L.cnf2_turn_scan.argtypes = [vp, i32, i32, i32, vp]
+        L.cnf2_state_posterior.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
@@ -189,6 +193,22 @@ class Context:
         ff = np.zeros((8, mc, 3))
         self._chk(self.L.cnf2_fwbw_store(self.h, ind, chrom, _p(fw), _p(ff)), "cnf2_fwbw_store")
         return fw, ff
+
+    def locked_query(self, ind, chrom, marker):
+        v = np.zeros((8, 64, 128))
+        self._chk(self.L.cnf2_locked_query(self.h, ind, chrom, marker, _p(v)), "cnf2_locked_query")
+        return v
+
+    def turn_scan(self, ind, chrom, marker):
+        v = np.zeros((128, 8))
+        self._chk(self.L.cnf2_turn_scan(self.h, ind, chrom, marker, _p(v)), "cnf2_turn_scan")
+        return v
+
+    def state_posterior(self, ind, chrom=0, ties=True):
+        mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
+        v = np.zeros((mc, 64))
+        self._chk(self.L.cnf2_state_posterior(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_state_posterior")
+        return v
 
     def emission(self, ind, marker):
         e = np.zeros((8, 64))

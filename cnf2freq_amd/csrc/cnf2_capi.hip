@@ -526,18 +526,19 @@ size_t cnf2_workspace_bytes(cnf2_ctx* ctx)
            (ctx->factors_cap + ctx->loglik_cap + ctx->dosage_cap + ctx->scratch_cap) * sizeof(double);
 }
 
-int cnf2_fwbw_store(cnf2_ctx* ctx, int ind, int chrom, double* fwbw_out, double* fwbwfactors_out)
+// Runs fb_kernel<true> for one individual x chromosome and leaves the reference-layout store in the
+// context's scratch buffer; fills the Stage2Params view of it.  extra = doubles reserved after it.
+static int run_store(cnf2_ctx* ctx, int ind, int chrom, Stage2Params* q, size_t extra, double** extra_ptr)
 {
     int rc = ready(ctx);
     if (rc) return rc;
-    if (ind < 0 || ind >= (int)ctx->windows.size() || chrom < 0 || chrom >= ctx->n_chrom || !fwbw_out || !fwbwfactors_out)
-        return fail(ctx, CNF2_ERR_ARG, "bad fwbw_store arguments");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ind < 0 || ind >= (int)ctx->windows.size() || chrom < 0 || chrom >= ctx->n_chrom)
+        return fail(ctx, CNF2_ERR_ARG, "individual or chromosome out of range");
     const int    first = ctx->chromstarts[chrom], last = ctx->chromstarts[chrom + 1] - 1, len = last - first + 1;
     const size_t nfw = (size_t)8 * len * 3 * 64, nff = (size_t)8 * len * 3;
     const size_t stride = (size_t)len * 512;
-    // scratch: fwbw | factors | spill(4 waves) | out factors(8) | loglik(1) | dosage(n_markers*3) | job
-    const size_t total = nfw + nff + stride * CNF2_WAVES_PER_BLOCK + 16 + (size_t)ctx->n_markers * 3 + 8;
+    // scratch: fwbw | factors | spill(4 waves) | out factors(8) | loglik(8) | dosage(n_markers*3) | job(8) | extra
+    const size_t total = nfw + nff + stride * CNF2_WAVES_PER_BLOCK + 16 + (size_t)ctx->n_markers * 3 + 8 + extra;
     if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, total))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, (nfw + nff) * sizeof(double), ctx->stream));
     double* d_fw  = ctx->d_scratch;
@@ -547,6 +548,7 @@ int cnf2_fwbw_store(cnf2_ctx* ctx, int ind, int chrom, double* fwbw_out, double*
     double* d_l   = d_f + 8;
     double* d_d   = d_l + 8;
     Job*    d_job = (Job*)(d_d + (size_t)ctx->n_markers * 3);
+    if (extra_ptr) *extra_ptr = d_d + (size_t)ctx->n_markers * 3 + 8;
     Job     jb;
     jb.ind = 0;
     jb.first = first;
@@ -570,8 +572,75 @@ int cnf2_fwbw_store(cnf2_ctx* ctx, int ind, int chrom, double* fwbw_out, double*
     p.dbg_factors  = d_ff;
     launch_fb(p, 1, true, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(fwbw_out, d_fw, nfw * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(fwbwfactors_out, d_ff, nff * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    q->kp          = p;
+    q->fwbw        = d_fw;
+    q->fwbwfactors = d_ff;
+    q->factors     = d_f;
+    q->loglik      = d_l;
+    q->first       = first;
+    q->len         = len;
+    return CNF2_OK;
+}
+
+int cnf2_fwbw_store(cnf2_ctx* ctx, int ind, int chrom, double* fwbw_out, double* fwbwfactors_out)
+{
+    if (!ctx || !fwbw_out || !fwbwfactors_out) return fail(ctx, CNF2_ERR_ARG, "bad fwbw_store arguments");
+    Stage2Params q;
+    int rc = run_store(ctx, ind, chrom, &q, 0, nullptr);
+    if (rc) return rc;
+    const size_t nfw = (size_t)8 * q.len * 3 * 64, nff = (size_t)8 * q.len * 3;
+    HIP_TRY(ctx, hipMemcpyAsync(fwbw_out, q.fwbw, nfw * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(fwbwfactors_out, q.fwbwfactors, nff * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_locked_query(cnf2_ctx* ctx, int ind, int chrom, int marker, double* val_out)
+{
+    if (!ctx || !val_out) return fail(ctx, CNF2_ERR_ARG, "bad locked_query arguments");
+    Stage2Params q;
+    double*      d_out = nullptr;
+    const size_t n = (size_t)8 * 64 * 128;
+    int rc = run_store(ctx, ind, chrom, &q, n, &d_out);
+    if (rc) return rc;
+    if (marker < q.first || marker >= q.first + q.len) return fail(ctx, CNF2_ERR_ARG, "marker not on this chromosome");
+    launch_locked_query(q, marker, d_out, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(val_out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_turn_scan(cnf2_ctx* ctx, int ind, int chrom, int marker, double* rawervals_out)
+{
+    if (!ctx || !rawervals_out) return fail(ctx, CNF2_ERR_ARG, "bad turn_scan arguments");
+    Stage2Params q;
+    double*      d_out = nullptr;
+    const size_t n = 128 * 8;
+    int rc = run_store(ctx, ind, chrom, &q, n, &d_out);
+    if (rc) return rc;
+    if (marker < q.first || marker >= q.first + q.len) return fail(ctx, CNF2_ERR_ARG, "marker not on this chromosome");
+    launch_turn_scan(q, marker, d_out, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(rawervals_out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_state_posterior(cnf2_ctx* ctx, int ind, int chrom, double* rows_out, uint32_t flags)
+{
+    if (!ctx || !rows_out) return fail(ctx, CNF2_ERR_ARG, "bad state_posterior arguments");
+    Stage2Params q;
+    double*      d_out = nullptr;
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (chrom < 0 || chrom >= ctx->n_chrom) return fail(ctx, CNF2_ERR_ARG, "chromosome out of range");
+    const size_t n = (size_t)(ctx->chromstarts[chrom + 1] - ctx->chromstarts[chrom]) * 64;
+    rc = run_store(ctx, ind, chrom, &q, n, &d_out);
+    if (rc) return rc;
+    launch_state_rows(q, (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0, d_out, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(rows_out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNF2_OK;
 }

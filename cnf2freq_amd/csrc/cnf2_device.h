@@ -51,6 +51,18 @@ struct KernelParams {
     double*        dbg_factors;  // [8][len][3]
 };
 
+// Inputs of the stage-2 parity kernels: the reference-layout store of ONE individual x chromosome.
+struct Stage2Params {
+    KernelParams  kp;          // windows (already offset to the individual), rows, n_markers
+    const double* fwbw;        // [8][len][3][64]
+    const double* fwbwfactors; // [8][len][3]
+    const double* factors;     // [8]
+    const double* loglik;      // [1]
+    int           first, len;
+};
+void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStream_t stream);
+void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_t stream);
+void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
 void launch_fb_fast(const KernelParams& p, int grid, hipStream_t stream);
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,

@@ -818,6 +818,158 @@ __global__ __launch_bounds__(64) void xor_selftest_kernel(double* out)
     out[5 * 64 + lane] = lane_xor32(v);
 }
 
+
+// =====================================================================================
+// Stage-2 consumers of the alpha/beta store, parity level:
+// they read the reference-layout store that fb_kernel<true> leaves for ONE individual and
+// chromosome and answer the queries of HOT LOOP 2 / 3 in bulk.  Not tuned; one thread per answer.
+// =====================================================================================
+__device__ __forceinline__ double s2_fw(const Stage2Params& q, int s, int ml, int slot, int g)
+{
+    return q.fwbw[(((size_t)s * q.len + ml) * 3 + slot) * 64 + g];
+}
+__device__ __forceinline__ double s2_ff(const Stage2Params& q, int s, int ml, int slot)
+{
+    return q.fwbwfactors[((size_t)s * q.len + ml) * 3 + slot];
+}
+
+// Terms of the two lines of state g under shift mode s for root allele f.
+__device__ __forceinline__ void s2_lines(const Stage2Params& q, const Window& w, int m, int g, int s, int f,
+                                         LaneJob* L0, LaneJob* L1, LineTerms* T0, LineTerms* T1, double* cf, bool* attop)
+{
+    const KernelParams& p = q.kp;
+    const Slot root = load_slot(p, w.row[0], m);
+    *attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    RootTerms R;
+    root_terms(root, *attop, f, &R);
+    *cf = R.cbase * phase_weight(root, f ^ (s & 1));
+    make_lane(w, (0 << 5) | (f << 4) | (((s >> 1) & 1) << 3) | (g & 7), L0);
+    make_lane(w, (1 << 5) | (f << 4) | (((s >> 2) & 1) << 3) | (g >> 3), L1);
+    line_terms(L0->cfg, load_slot(p, L0->row_par, m), load_slot(p, L0->row_tr, m), load_slot(p, L0->row_ot, m),
+               R.inmv0, R.sv0, R.inmv0 == 2, T0);
+    line_terms(L1->cfg, load_slot(p, L1->row_par, m), load_slot(p, L1->row_tr, m), load_slot(p, L1->row_ot, m),
+               R.inmv1, R.sv1, false, T1);
+}
+
+// One allele assignment (path) of a line: parent allele fp, traced / other grandparent alleles.
+__device__ __forceinline__ double s2_path_term(const LineCfg& c, const LineTerms& T, int fp, int fg_tr, int fg_ot)
+{
+    const bool par_line = !(c.par & SLOT_PRESENT) || (c.par & SLOT_FOUNDER);
+    if (!(c.par & SLOT_PRESENT)) fp = 0;                 // 1 + secondval, whatever the path bits say
+    if (par_line || !(c.tr & SLOT_PRESENT)) fg_tr = 0;
+    if (par_line || !(c.ot & SLOT_PRESENT)) fg_ot = 0;
+    return (T.base[fp] * T.ot[fp][fg_ot]) * T.tr[fp][fg_tr];
+}
+
+// val(s, g, flag2) = exp(doanalyze(classicstop(q, g), flag2) - factor) of cnF2freq.cpp:5499-5508 for one
+// marker: out[s][g][flag2]; 0 where the reference would not count it (not finite or <= -200).
+__global__ __launch_bounds__(128) void locked_query_kernel(Stage2Params q, int marker, double* out)
+{
+    const int flag2 = threadIdx.x;            // 0..127
+    const int g     = blockIdx.x & 63;
+    const int s     = blockIdx.x >> 6;
+    const Window w  = q.kp.windows[0];
+    const int ml    = marker - q.first;
+    const int f     = flag2 & 1;
+    LaneJob   L0, L1;
+    LineTerms T0, T1;
+    double    cf;
+    bool      attop;
+    s2_lines(q, w, marker, g, s, f, &L0, &L1, &T0, &T1, &cf, &attop);
+    double e;
+    if (attop) e = cf;
+    else {
+        const int fp0 = (flag2 >> 1) & 1, fp1 = (flag2 >> 4) & 1;
+        const int a0 = (flag2 >> (2 + L0.cfg.firstpar)) & 1, o0 = (flag2 >> (2 + (L0.cfg.firstpar ^ 1))) & 1;
+        const int a1 = (flag2 >> (5 + L1.cfg.firstpar)) & 1, o1 = (flag2 >> (5 + (L1.cfg.firstpar ^ 1))) & 1;
+        e = (cf * s2_path_term(L1.cfg, T1, fp1, a1, o1)) * s2_path_term(L0.cfg, T0, fp0, a0, o0);
+    }
+    const double factor = q.loglik[0];
+    const double am = s2_fw(q, s, ml, 0, g), be = s2_fw(q, s, ml, 1, g);
+    // cnF2freq.cpp:1960-2016: alpha-minus filtered to g, emission of the path, beta of g
+    double lv = s2_ff(q, s, ml, 0) + log(am * e) + s2_ff(q, s, ml, 1) + log(be) - factor;
+    double v  = (isfinite(lv) && lv > -200.0) ? exp(lv) : 0.0;
+    out[((size_t)s * 64 + g) * 128 + flag2] = v;
+}
+
+// rawervals[turn][s] of cnF2freq.cpp:5686-5752 for one marker (aroundturner, cnF2freq.cpp:498-554):
+// alpha (after emission) of mode s, states XOR-permuted by turn & 54, times beta of the turned mode.
+__global__ __launch_bounds__(64) void turn_scan_kernel(Stage2Params q, int marker, double* out)
+{
+    const int k    = threadIdx.x;
+    const int s    = blockIdx.x & 7;
+    const int turn = blockIdx.x >> 3;
+    const int ml   = marker - q.first;
+    const int xorturn = turn & 54;                                                      // cnF2freq.cpp:508
+    const int shiftx  = (turn >> 6) | ((turn & 1) ? 2 : 0) | ((turn & 8) ? 4 : 0);     // cnF2freq.cpp:509-510
+    const int s2      = s ^ shiftx;
+    double v = s2_fw(q, s, ml, 2, k ^ xorturn) * s2_fw(q, s2, ml, 1, k);
+    v += lane_xor1(v);
+    v += lane_xor2(v);
+    v += dpp_mov_all<0x141>(v);
+    v += lane_xor8(v);
+    v += lane_xor16(v);
+    v += lane_xor32(v);
+    if (k == 0) {
+        double r = (v > 0.0) ? s2_ff(q, s, ml, 2) + s2_ff(q, s2, ml, 1) + log(v) : (double)CNF2_MINFACTOR_F;
+        out[turn * 8 + s] = r - q.loglik[0];
+    }
+}
+
+// statereporter row (cnF2freq.cpp:3540-3546): sum of val over shift modes and paths, by state g,
+// for every marker of the chromosome: out[len][64] (un-normalised like the reference's reporter).
+__global__ __launch_bounds__(64) void state_rows_kernel(Stage2Params q, uint32_t flags, double* out)
+{
+    const int g  = threadIdx.x;
+    const int ml = blockIdx.x;
+    const int m  = q.first + ml;
+    const Window w = q.kp.windows[0];
+    const double factor = q.loglik[0];
+    const int n_combo = (flags & KP_NO_TIES) ? 1 : (1 << w.n_groups);
+    double acc = 0.0;
+    for (int s = 0; s < 8; s++) {
+        if ((s & w.shiftignore) || s >= w.shiftend) continue;
+        if (factor - q.factors[s] > 40.0) continue;                                    // cnF2freq.cpp:5421
+        double e = 0.0;
+        for (int f = 0; f < 2; f++) {
+            LaneJob   L0, L1;
+            LineTerms T0, T1;
+            double    cf;
+            bool      attop;
+            s2_lines(q, w, m, g, s, f, &L0, &L1, &T0, &T1, &cf, &attop);
+            if (attop) {
+                e += cf;
+                continue;
+            }
+            for (int combo = 0; combo < n_combo; combo++) {
+                const bool nt = (flags & KP_NO_TIES) != 0;
+                double r0, r1, t2;
+                line_restricted(L0.cfg, T0, nt ? -1 : tie_force(L0.tie_par, combo), nt ? -1 : tie_force(L0.tie_tr, combo),
+                                nt ? -1 : tie_force(L0.tie_ot, combo), &r0, &t2);
+                line_restricted(L1.cfg, T1, nt ? -1 : tie_force(L1.tie_par, combo), nt ? -1 : tie_force(L1.tie_tr, combo),
+                                nt ? -1 : tie_force(L1.tie_ot, combo), &r1, &t2);
+                e += (cf * r1) * r0;
+            }
+        }
+        const double sc = exp(s2_ff(q, s, ml, 0) + s2_ff(q, s, ml, 1) - factor);
+        acc += s2_fw(q, s, ml, 0, g) * s2_fw(q, s, ml, 1, g) * sc * e;
+    }
+    out[(size_t)ml * 64 + g] = acc;
+}
+
+void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(locked_query_kernel, dim3(512), dim3(128), 0, stream, q, marker, out);
+}
+void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(turn_scan_kernel, dim3(1024), dim3(64), 0, stream, q, marker, out);
+}
+void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(state_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
+}
+
 void launch_fb_fast(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(fb_fast_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);

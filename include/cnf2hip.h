@@ -124,6 +124,20 @@ int cnf2_sync(cnf2_ctx *ctx);
  * cumulative log scales; mc = markers on the chromosome.  Masked modes are left zero. */
 int cnf2_fwbw_store(cnf2_ctx *ctx, int ind, int chrom, double *fwbw_out, double *fwbwfactors_out);
 
+/* Stage-2 consumers of the alpha/beta store (parity level, one individual x chromosome per call;
+ * not tuned).  They answer in bulk the queries that doit<> issues one by one:
+ *  cnf2_locked_query    val_out[8][64][128]: exp(doanalyze(classicstop(q, g), flag2) - factor) for
+ *                       every shift mode, state g and path flag2 at `marker` (cnF2freq.cpp:5499-5508;
+ *                       0 where the reference would not count the term).  No ignoreflag2 pruning
+ *                       is applied (cnF2freq.cpp:5464): the caller masks.
+ *  cnf2_turn_scan       rawervals_out[128][8]: doanalyze<aroundturner>(turn, classicstop(q, -1)) - factor
+ *                       (cnF2freq.cpp:5686-5724) for every turn and shift mode, unmasked.
+ *  cnf2_state_posterior rows_out[mc][64]: what statereporter::addval accumulates (cnF2freq.cpp:3540-3546),
+ *                       i.e. sum of val over shift modes and admissible paths by state, per marker. */
+int cnf2_locked_query(cnf2_ctx *ctx, int ind, int chrom, int marker, double *val_out);
+int cnf2_turn_scan(cnf2_ctx *ctx, int ind, int chrom, int marker, double *rawervals_out);
+int cnf2_state_posterior(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
+
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
 int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);

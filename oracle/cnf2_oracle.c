@@ -787,6 +787,34 @@ int cnf2o_sweep_ind(const cnf2o_ped *P, int ind, int gen, int first, int last,
     return ok;
 }
 
+/* All the terms of HOT LOOP 2 at one marker (cpp:5416-5508): out[s][g][flag2] = val, or -1 where
+ * the reference skips the term (masked shift mode, factor gap > 40, ignoreflag2) and 0 where the
+ * query is below the -200 threshold.  mapval_out (optional) receives mapval per entry. */
+void cnf2o_val_table(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                     double *out, int *mapval_out)
+{
+    cnf2o_fwbw *W = cnf2o_fwbw_new(P->n_markers);
+    double factors[NUMSHIFTS], factor;
+    cnf2o_sweep_ind(P, ind, gen, first, last, factors, &factor, NULL, 0, W);
+    cnf2o_tree T;
+    cnf2o_fixtrees(P, ind, &T);
+    int shiftend = gen < 2 ? 2 : NUMSHIFTS;
+    for (int s = 0; s < NUMSHIFTS; s++)
+        for (int g = 0; g < NUMTYPES; g++)
+            for (int flag2 = 0; flag2 < NUMPATHS; flag2++) {
+                size_t idx = ((size_t)s * NUMTYPES + g) * NUMPATHS + flag2;
+                out[idx] = -1;
+                if (mapval_out) mapval_out[idx] = -1;
+                if (s >= shiftend || (s & T.shiftignore)) continue;
+                if (factor - factors[s] > 40) continue;
+                if (cnf2o_ignoreflag2(P, &T, flag2, g, s, marker)) continue;
+                double val = cnf2o_query(P, ind, s, first, last, marker, g, flag2, W, -200 + factor) - factor;
+                out[idx] = (isfinite(val) && val > -200) ? exp(val) : 0.0;
+                if (mapval_out) mapval_out[idx] = cnf2o_mapval(P, ind, marker, g, flag2, s, NULL);
+            }
+    cnf2o_fwbw_free(W);
+}
+
 int cnf2o_sweep_batch(const cnf2o_ped *P, const int *inds, const int *gens, int n_ind,
                       int first, int last, double *factors_out, double *factor_out,
                       double *dosage_out, int mode, int n_threads)

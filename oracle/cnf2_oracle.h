@@ -158,6 +158,10 @@ typedef struct cnf2o_emtab {
 void cnf2o_emission_tables(const cnf2o_ped *P, int ind, int marker, int shift,
                            int flag2ignore, cnf2o_emtab *out);
 
+/* HOT LOOP 2 terms at one marker: out[8][64][128] (see cnf2_oracle.c). */
+void cnf2o_val_table(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                     double *out, int *mapval_out);
+
 /* Batch driver used as the CPU baseline: OpenMP over individuals (cpp:5294),
  * per-thread private store.  inds[n_ind] record indices, gens[n_ind].
  * dosage_out [n_ind][last-first+1][3] normalised rows (or NULL).

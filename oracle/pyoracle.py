@@ -98,6 +98,7 @@ def lib():
                                       C.c_void_p, C.c_int, C.POINTER(_Fwbw)]
         L.cnf2o_sweep_ind.restype = C.c_int
         L.cnf2o_emission_tables.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_EmTab)]
+        L.cnf2o_val_table.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
@@ -204,6 +205,14 @@ class OraclePed:
                                                       turn, W, -50000 + factor[0]) - factor[0]
         lib().cnf2o_fwbw_free(W)
         return out
+
+    def val_table(self, ind, marker, gen=2, first=0, last=None):
+        """(val[8][64][128], mapval[8][64][128]) of HOT LOOP 2 at one marker; -1 = term skipped."""
+        last = self.M - 1 if last is None else last
+        v = np.zeros((NUMSHIFTS, NUMTYPES, NUMPATHS))
+        mv = np.zeros((NUMSHIFTS, NUMTYPES, NUMPATHS), np.int32)
+        lib().cnf2o_val_table(C.byref(self.c), ind, gen, first, last, marker, _ptr(v), _ptr(mv))
+        return v, mv
 
     def sweep_batch(self, inds, gens=None, first=0, last=None, mode=2, dosage=True, n_threads=0):
         last = self.M - 1 if last is None else last

@@ -280,3 +280,49 @@ def test_full_length_chromosome_properties(capi):
     np.testing.assert_allclose(full["dosage"][:3], want["dosage"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(full["loglik"][:3, 0], want["factor"], rtol=1e-10)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_turn_scan_matches_reference(capi, case):
+    """rawervals[turn][s] (HOT LOOP 3, aroundturner) against the reference's own values."""
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j in range(len(ped.dous)):
+        if not z["ok"][j]:
+            continue
+        for ti, m in enumerate(z["turn_markers"]):
+            got = ctx.turn_scan(j, 0, int(m))
+            want = z["rawervals"][j, ti]
+            live = ~np.isnan(want)
+            np.testing.assert_allclose(got[live], want[live], rtol=1e-9, atol=1e-8)
+    ctx.close()
+
+
+def test_locked_queries_and_state_rows_against_oracle(capi):
+    """Every term of HOT LOOP 2 at a marker (val for each shift mode, state and path) against the
+    oracle's doanalyze(classicstop(q, g), flag2); their sums by class must give the dosage row and
+    their sums by state the statereporter row."""
+    ped = synth.make_random_windows(10, 5, seed=123)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    o = oracle_ped(ped)
+    raw = ctx.sweep(raw=True)
+    checked = 0
+    for j, ind in enumerate(ped.dous):
+        gen = int(ped.gen[ind])
+        if not o.sweep_ind(int(ind), gen, mode=2)["ok"]:
+            continue
+        state_rows = ctx.state_posterior(j, 0)
+        for m in (0, 3):
+            want, mapval = o.val_table(int(ind), m, gen)
+            got = ctx.locked_query(j, 0, m)
+            live = want >= 0
+            np.testing.assert_allclose(got[live], want[live], rtol=1e-8, atol=1e-13)
+            row = np.array([got[live & (mapval == d)].sum() for d in range(3)])
+            np.testing.assert_allclose(row, raw["dosage"][j, m], rtol=1e-8, atol=1e-12)
+            by_state = np.where(live, got, 0.0).sum(axis=(0, 2))
+            np.testing.assert_allclose(state_rows[m], by_state, rtol=1e-8, atol=1e-12)
+            checked += 1
+    assert checked >= 6
+    ctx.close()
