@@ -443,11 +443,25 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         int cap = ctx->n_cu * per_cu;
         return g > cap ? cap : g;
     };
-    const int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
-    const int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
-    const int grid      = grid_fast > grid_gen ? grid_fast : grid_gen;
+    int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
+    int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
     const size_t stride = (size_t)max_chrom_len(ctx) * 520;   // SPILL_ROW of the fast kernel (general kernel uses 512)
-    const size_t need   = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
+    {
+        // One spill slot per resident wave.  Long chromosomes make slots big: keep the spill within
+        // ~60 % of what is free (plus what the context already holds) by running fewer waves.
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        const size_t budget   = (size_t)((double)(free_b + ctx->spill_bytes) * 0.6);
+        const size_t per_blk  = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
+        const size_t max_blks = budget / per_blk;
+        if (max_blks < 1)
+            return fail(ctx, CNF2_ERR_NOMEM, "a chromosome of %d markers needs %zu MB of spill per block, %zu MB free",
+                        max_chrom_len(ctx), per_blk >> 20, free_b >> 20);
+        if ((size_t)grid_fast > max_blks) grid_fast = (int)max_blks;
+        if ((size_t)grid_gen > max_blks) grid_gen = (int)max_blks;
+    }
+    const int    grid = grid_fast > grid_gen ? grid_fast : grid_gen;
+    const size_t need = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
     {
         size_t capd = ctx->spill_bytes / sizeof(double);
         rc = ensure(ctx, &ctx->d_spill, &capd, need);
