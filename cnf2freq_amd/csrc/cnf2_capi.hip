@@ -21,7 +21,8 @@ using namespace cnf2;
 struct cnf2_ctx {
     int         device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;   // tied windows (general kernel) run beside the fast kernel
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool        timed = false;
     std::string err;
     int         n_cu = 0;
@@ -117,8 +118,10 @@ int cnf2_ctx_create(int device, cnf2_ctx** out)
     ctx->device   = device;
     hipError_t e  = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+    if (e == hipSuccess) e = hipStreamCreate(&ctx->stream2);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -152,6 +155,8 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     hipFree(ctx->d_scratch);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
+    hipEventDestroy(ctx->ev2);
+    hipStreamDestroy(ctx->stream2);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -460,7 +465,18 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         if ((size_t)grid_fast > max_blks) grid_fast = (int)max_blks;
         if ((size_t)grid_gen > max_blks) grid_gen = (int)max_blks;
     }
-    const int    grid = grid_fast > grid_gen ? grid_fast : grid_gen;
+    if (n_fast > 0 && n_general > 0) {
+        // both kernels run side by side on two streams with disjoint spill slots: share the budget
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        const size_t budget   = (size_t)((double)(free_b + ctx->spill_bytes) * 0.6);
+        const size_t per_blk  = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
+        while ((size_t)(grid_fast + grid_gen) * per_blk > budget && grid_fast + grid_gen > 2) {
+            if (grid_fast > 1) grid_fast--;
+            if (grid_gen > 1 && (size_t)(grid_fast + grid_gen) * per_blk > budget) grid_gen--;
+        }
+    }
+    const int    grid = grid_fast + grid_gen;
     const size_t need = (size_t)grid * CNF2_WAVES_PER_BLOCK * stride;
     {
         size_t capd = ctx->spill_bytes / sizeof(double);
@@ -503,10 +519,15 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_general > 0) {
+        // second stream, own spill slots behind the fast kernel's: no ordering between the two kernels
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev0, 0));
         p.jobs   = ctx->d_jobs + n_fast;
         p.n_jobs = (int)n_general;
-        launch_fb(p, grid_gen, false, ctx->stream);
+        p.spill  = ctx->d_spill + (size_t)(n_fast > 0 ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
+        launch_fb(p, grid_gen, false, ctx->stream2);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2, 0));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
