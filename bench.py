@@ -284,7 +284,7 @@ def main():
                          "algorithmic_bytes_per_unit": B_UNIT},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # CPU baseline leg: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(sample, pos, starts, args)
                 out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
