@@ -15,6 +15,14 @@ cases = {
     "outbred 3-gen, 20% missing (config 5 shape), 2000 kids x 2501": lambda: synth.make_outbred3(500, 4, 2500, 1, seed=2, missing=0.2),
     "advanced intercross (config 3 shape), 1600 ind x 2501": lambda: synth.make_ail(64, 200, 8, 2500, 1, seed=3),
 }
+if "--full" in sys.argv:
+    # BASELINE configs 3 and 5 at their stated sizes (config 5: M = 10 000 as assumed in SURVEY section 8)
+    cases = {
+        "config 3: AIL 2 founders + 64 F1 + 8 x 625 analysed, 8 x 2500 SNPs (+dummies)":
+            lambda: synth.make_ail(64, 625, 8, 2500, 8, seed=3),
+        "config 5 shape: outbred 3-gen, 20% missing, 10 000 analysed x 10 000 SNPs (4 x 2500)":
+            lambda: synth.make_outbred3(2500, 4, 2500, 4, seed=2, missing=0.2),
+    }
 for name, mk in cases.items():
     t0 = time.time()
     ped = mk()
