@@ -23,7 +23,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_emission",
+    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
 ]
 
@@ -63,6 +63,7 @@ def load():
         L.cnf2_locked_query.argtypes = [vp, i32, i32, i32, vp]
         L.cnf2_turn_scan.argtypes = [vp, i32, i32, i32, vp]
         L.cnf2_state_posterior.argtypes = [vp, i32, i32, vp, C.c_uint32]
+        L.cnf2_haplos.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
@@ -208,6 +209,12 @@ class Context:
         mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
         v = np.zeros((mc, 64))
         self._chk(self.L.cnf2_state_posterior(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_state_posterior")
+        return v
+
+    def haplos(self, ind, chrom=0, ties=True):
+        mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
+        v = np.zeros((mc, 7, 2))
+        self._chk(self.L.cnf2_haplos(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_haplos")
         return v
 
     def emission(self, ind, marker):

@@ -957,6 +957,107 @@ __global__ __launch_bounds__(64) void state_rows_kernel(Stage2Params q, uint32_t
     out[(size_t)ml * 64 + g] = acc;
 }
 
+
+// HAPLOS accumulators of HOT LOOP 2 (cnF2freq.cpp:5554-5556 -> updatehaplo 1561-1575 -> trackpossible<HAPLOS>
+// 1347-1350), per marker and window slot: out[len][7][2], out[..][k][phase] = sum of val over states,
+// shift modes and admissible paths on which the individual in slot k is used with that phase
+// (allele index ^ firstpar ^ localshift).  A slot that is homozygous with equal sure at the marker,
+// or that the recursion does not reach, stays 0.  (movehaplos, cnF2freq.cpp:3601-3616, then turns the
+// pair into haplobase/haplocount on the host, summed per individual.)
+__global__ __launch_bounds__(64) void haplos_rows_kernel(Stage2Params q, uint32_t flags, double* out)
+{
+    const int g  = threadIdx.x;
+    const int ml = blockIdx.x;
+    const int m  = q.first + ml;
+    const Window w = q.kp.windows[0];
+    const double factor = q.loglik[0];
+    const bool   nt = (flags & KP_NO_TIES) != 0;
+    const int    n_combo = nt ? 1 : (1 << w.n_groups);
+    double acc[7][2];
+#pragma unroll
+    for (int k = 0; k < 7; k++) acc[k][0] = acc[k][1] = 0.0;
+    bool upd[7];                                   // doupdatehaplo of the slot at this marker
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        upd[k] = false;
+        if (w.flags[k] & SLOT_PRESENT) {
+            const Slot d = load_slot(q.kp, w.row[k], m);
+            upd[k] = !(d.a0 == d.a1 && d.s0 == d.s1);          // cnF2freq.cpp:1235-1239
+        }
+    }
+    const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;
+    for (int s = 0; s < 8 && !skip; s++) {
+        if ((s & w.shiftignore) || s >= w.shiftend) continue;
+        if (factor - q.factors[s] > 40.0) continue;
+        const double wg = s2_fw(q, s, ml, 0, g) * s2_fw(q, s, ml, 1, g) *
+                          exp(s2_ff(q, s, ml, 0) + s2_ff(q, s, ml, 1) - factor);
+        for (int f = 0; f < 2; f++) {
+            LaneJob   L[2];
+            LineTerms T[2];
+            double    cf;
+            bool      attop;
+            s2_lines(q, w, m, g, s, f, &L[0], &L[1], &T[0], &T[1], &cf, &attop);
+            // root: phase = f ^ shift bit 0 (firstpar is 0 at the root, cnF2freq.cpp:1156,1227)
+            if (attop) {
+                if (upd[0]) acc[0][f ^ (s & 1)] += wg * cf;
+                continue;
+            }
+            for (int combo = 0; combo < n_combo; combo++) {
+                int    force[2][3];                // [line][par, tr, ot]
+                double r[2], t2;
+                for (int P = 0; P < 2; P++) {
+                    force[P][0] = nt ? -1 : tie_force(L[P].tie_par, combo);
+                    force[P][1] = nt ? -1 : tie_force(L[P].tie_tr, combo);
+                    force[P][2] = nt ? -1 : tie_force(L[P].tie_ot, combo);
+                    line_restricted(L[P].cfg, T[P], force[P][0], force[P][1], force[P][2], &r[P], &t2);
+                }
+                const double e = (cf * r[1]) * r[0];
+                if (upd[0]) acc[0][f ^ (s & 1)] += wg * e;
+                for (int P = 0; P < 2; P++) {
+                    const LineCfg& c = L[P].cfg;
+                    if (!(c.par & SLOT_PRESENT)) continue;
+                    const int  slot_par = 1 + 3 * P;
+                    const int  ls = P ? (s >> 2) & 1 : (s >> 1) & 1;      // the parent's localshift
+                    const bool interior = !(c.par & SLOT_FOUNDER);
+                    for (int x = 0; x < 3; x++) {                          // 0 parent, 1 traced gp, 2 other gp
+                        int slot;
+                        if (x == 0) slot = slot_par;
+                        else {
+                            if (!interior) continue;
+                            if (!((x == 1 ? c.tr : c.ot) & SLOT_PRESENT)) continue;
+                            slot = slot_par + 1 + (x == 1 ? c.firstpar : (c.firstpar ^ 1));
+                        }
+                        if (!upd[slot]) continue;
+                        for (int psi = 0; psi < 2; psi++) {
+                            if (force[P][x] >= 0 && force[P][x] != psi) continue;   // tied slot: this combination fixes it
+                            int fo[3] = {force[P][0], force[P][1], force[P][2]};
+                            fo[x] = psi;
+                            double rr;
+                            line_restricted(c, T[P], fo[0], fo[1], fo[2], &rr, &t2);
+                            const double ev = P ? (cf * rr) * r[0] : (cf * r[1]) * rr;
+                            const int phase = (x == 0) ? (psi ^ ls) : psi;         // grandparents have localshift 0
+                            acc[slot][phase] += wg * ev;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+#pragma unroll
+        for (int ph = 0; ph < 2; ph++) {
+            double v = acc[k][ph];
+            v += lane_xor1(v);
+            v += lane_xor2(v);
+            v += dpp_mov_all<0x141>(v);
+            v += lane_xor8(v);
+            v += lane_xor16(v);
+            v += lane_xor32(v);
+            if (g == 0) out[((size_t)ml * 7 + k) * 2 + ph] = v;
+        }
+}
+
 void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(locked_query_kernel, dim3(512), dim3(128), 0, stream, q, marker, out);
@@ -964,6 +1065,10 @@ void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStre
 void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(turn_scan_kernel, dim3(1024), dim3(64), 0, stream, q, marker, out);
+}
+void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(haplos_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
 }
 void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
 {

@@ -137,6 +137,11 @@ int cnf2_fwbw_store(cnf2_ctx *ctx, int ind, int chrom, double *fwbw_out, double 
 int cnf2_locked_query(cnf2_ctx *ctx, int ind, int chrom, int marker, double *val_out);
 int cnf2_turn_scan(cnf2_ctx *ctx, int ind, int chrom, int marker, double *rawervals_out);
 int cnf2_state_posterior(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
+/*  cnf2_haplos          rows_out[mc][7][2]: the HAPLOS accumulators HOT LOOP 2 leaves per window slot
+ *                       (slot order of cnf2_window_info) before movehaplos: sum of val by the phase with
+ *                       which the slot's individual is used (cnF2freq.cpp:1347-1350, 1561-1575, 5556).
+ *                       An individual occupying several slots gets the sum of its slots in the reference. */
+int cnf2_haplos(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */

@@ -59,9 +59,21 @@ static const double *rec_sure(const cnf2o_ped *P, int rec, int marker)
 
 /* ------------------------------------------------------------- emission */
 
+/* Side-effect sink of the update modes (trackpossibleparams + tb.haplos, cpp:559-571, 1347-1350).
+ * Only HAPLOS (= 1, cpp:792) is restated: haplos[rec][phase] += updateval. */
+typedef struct {
+    int     update;      /* 0 or HAPLOS */
+    double  updateval;
+    double *haplos;      /* [n_rec][2] */
+} tp_sink;
+#define UPD_HAPLOS 1
+
 static double recurse_tp(const cnf2o_ped *P, int mother, int markerval, double secondval,
                          int marker, int upflag, int upflag2, int upshift, unsigned genwidth,
-                         int firstpar, int zeropropagate, int *gstr);
+                         int firstpar, int zeropropagate, int *gstr, const tp_sink *sink);
+static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secondval,
+                      int marker, unsigned flag, int flag99, int localshift,
+                      unsigned genwidth, int zeropropagate, int *gstr, const tp_sink *sink);
 
 /* cpp:1075-1359, update == 0 (no HAPLOS/GENOS/HOMOZYGOUS/GENOSPROBE side effects),
  * SELFING = RELSKEWSTATES = DOIMPOSSIBLE = false (set:11-16). */
@@ -69,6 +81,16 @@ double cnf2o_trackpossible(const cnf2o_ped *P, int rec, int inmarkerval, double 
                            int marker, unsigned flag, int flag99, int localshift,
                            unsigned genwidth, int zeropropagate, int *gstr)
 {
+    return tp_core(P, rec, inmarkerval, secondval, marker, flag, flag99, localshift, genwidth,
+                   zeropropagate, gstr, NULL);
+}
+
+/* cpp:1075-1359 with update in {0, HAPLOS}. */
+static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secondval,
+                      int marker, unsigned flag, int flag99, int localshift,
+                      unsigned genwidth, int zeropropagate, int *gstr, const tp_sink *sink)
+{
+    const int update = sink ? sink->update : 0;
     const int rootgen  = (genwidth == (1u << (CNF2O_NUMGEN - 1)));          /* cpp:1116 */
     const int attopnow = (genwidth == 1) || P->founder[rec];                 /* cpp:1120 (HAPLOTYPING==1) */
     const int32_t *themarker     = rec_allele(P, rec, marker);               /* cpp:1137 */
@@ -109,20 +131,24 @@ double cnf2o_trackpossible(const cnf2o_ped *P, int rec, int inmarkerval, double 
             mainsecondval = effectivemarkersure * effectivesecondval;
         }
 
-        if (attopnow) {                                                      /* cpp:1213-1221; update==0 */
+        /* cpp:1213: `update & (GENOS || GENOSPROBE)` is `update & 1`, i.e. true in HAPLOS mode */
+        if (attopnow || (update & 1)) {                                      /* cpp:1213-1221 */
             baseval += mainsecondval;
             mainsecondval = 0;
         } else {
             if (mainsecondval) mainsecondval /= baseval;
         }
 
+        int doupdatehaplo = 1;                                               /* cpp:1224 */
         f2n ^= ((firstpar ^ localshift) & 1);                                /* cpp:1227 */
 
         if (zeropropagate || !genwidth) {                                    /* cpp:1229-1233 */
             baseval *= 0.5;
+            doupdatehaplo = 0;
         } else if (allthesame &&
                    (P->correction_inference || (themarkersure[0] == themarkersure[1]))) {
             baseval *= (f2n ? 1.0 : 0.0);                                    /* cpp:1235-1239 */
+            doupdatehaplo = 0;
         } else {
             baseval *= fabs((f2n ? 1.0 : 0.0) - haploweight);                /* cpp:1245 */
         }
@@ -141,14 +167,17 @@ double cnf2o_trackpossible(const cnf2o_ped *P, int rec, int inmarkerval, double 
                     secsecondval = themarkersure[!realf2n] / (1 - themarkersure[!realf2n]);
                 }
                 baseval *= recurse_tp(P, rec, secmark, secsecondval, marker, upflag, upflag2,
-                                      upshift, genwidth, !firstpar, zeropropagate, gstr); /* cpp:1322 */
+                                      upshift, genwidth, !firstpar, zeropropagate, gstr, sink); /* cpp:1322 */
             }
             if (baseval)                                                     /* cpp:1336-1340 */
                 baseval *= recurse_tp(P, rec, markerval, mainsecondval, marker, upflag, upflag2,
-                                      upshift, genwidth, firstpar, zeropropagate, gstr);
+                                      upshift, genwidth, firstpar, zeropropagate, gstr, sink);
         }
 
-        if (baseval) ok += baseval;                                          /* cpp:1343-1345 */
+        if (baseval) {                                                       /* cpp:1343-1350 */
+            ok += baseval;
+            if ((update & UPD_HAPLOS) && doupdatehaplo) sink->haplos[rec * 2 + f2n] += sink->updateval;
+        }
     }
     return ok;
 }
@@ -156,15 +185,15 @@ double cnf2o_trackpossible(const cnf2o_ped *P, int rec, int inmarkerval, double 
 /* cpp:955-1058 recursetrackpossible: ctor (984-986) + operator double (1035-1057). */
 static double recurse_tp(const cnf2o_ped *P, int mother, int markerval, double secondval,
                          int marker, int upflag, int upflag2, int upshift, unsigned genwidth,
-                         int firstpar, int zeropropagate, int *gstr)
+                         int firstpar, int zeropropagate, int *gstr, const tp_sink *sink)
 {
     int upflagr  = upflagit(upflag, firstpar, genwidth);
     int upflag2r = upflagit(upflag2, firstpar, genwidth);      /* NUMGEN-NUMFLAG2GEN == 0 */
     int upshiftr = upflagit(upshift, firstpar, genwidth >> 1); /* NUMGEN-NUMSHIFTGEN == 1 */
     int par = P->par[mother * 2 + firstpar];
     if (par < 0) return 1 + secondval;                          /* cpp:1043-1046 */
-    return cnf2o_trackpossible(P, par, markerval, secondval, marker, (unsigned)upflagr, upflag2r,
-                               upshiftr, genwidth >> 1, zeropropagate, gstr);
+    return tp_core(P, par, markerval, secondval, marker, (unsigned)upflagr, upflag2r,
+                   upshiftr, genwidth >> 1, zeropropagate, gstr, sink);
 }
 
 /* cpp:1380-1385 */
@@ -812,6 +841,43 @@ void cnf2o_val_table(const cnf2o_ped *P, int ind, int gen, int first, int last, 
                 out[idx] = (isfinite(val) && val > -200) ? exp(val) : 0.0;
                 if (mapval_out) mapval_out[idx] = cnf2o_mapval(P, ind, marker, g, flag2, s, NULL);
             }
+    cnf2o_fwbw_free(W);
+}
+
+/* What HOT LOOP 2 leaves in the thread-private `haplos` for one marker before movehaplos
+ * (cpp:5416-5556 -> updatehaplo cpp:1561-1575 -> trackpossible<HAPLOS> cpp:1347-1350):
+ * out[n_rec][2], out[r][phase] = sum of val over (g, s, path) whose path uses phase `phase`
+ * (allele index ^ firstpar ^ localshift) of individual r; individuals that are homozygous with
+ * equal sure at the marker never accumulate. */
+void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                      double *out)
+{
+    cnf2o_fwbw *W = cnf2o_fwbw_new(P->n_markers);
+    double factors[NUMSHIFTS], factor;
+    cnf2o_sweep_ind(P, ind, gen, first, last, factors, &factor, NULL, 0, W);
+    cnf2o_tree T;
+    cnf2o_fixtrees(P, ind, &T);
+    memset(out, 0, sizeof(double) * 2 * P->n_rec);
+    int shiftend = gen < 2 ? 2 : NUMSHIFTS;
+    int okind = !(isnan(factor) || factor < CNF2O_MINFACTOR);
+    for (int g = 0; okind && g < NUMTYPES; g++)
+        for (int s = 0; s < shiftend; s++) {
+            if (s & T.shiftignore) continue;
+            if (factor - factors[s] > 40) continue;
+            for (int flag2 = 0; flag2 < NUMPATHS; flag2++) {
+                if (cnf2o_ignoreflag2(P, &T, flag2, g, s, marker)) continue;
+                double val = cnf2o_query(P, ind, s, first, last, marker, g, flag2, W, -200 + factor) - factor;
+                if (!(isfinite(val) && val > -200)) continue;
+                val = exp(val);
+                /* updatehaplo, cpp:1561-1575 */
+                double ok = cnf2o_emission(P, ind, marker, g, flag2, s);
+                if (ok) {
+                    tp_sink sink = {UPD_HAPLOS, val, out};
+                    tp_core(P, ind, UNKNOWN, 0, marker, (unsigned)(g * 2), flag2, s,
+                            1u << (CNF2O_NUMGEN - 1), 0, NULL, &sink);
+                }
+            }
+        }
     cnf2o_fwbw_free(W);
 }
 

@@ -162,6 +162,10 @@ void cnf2o_emission_tables(const cnf2o_ped *P, int ind, int marker, int shift,
 void cnf2o_val_table(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
                      double *out, int *mapval_out);
 
+/* HAPLOS accumulators of HOT LOOP 2 at one marker: out[n_rec][2] (see cnf2_oracle.c). */
+void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                      double *out);
+
 /* Batch driver used as the CPU baseline: OpenMP over individuals (cpp:5294),
  * per-thread private store.  inds[n_ind] record indices, gens[n_ind].
  * dosage_out [n_ind][last-first+1][3] normalised rows (or NULL).

@@ -99,6 +99,7 @@ def lib():
         L.cnf2o_sweep_ind.restype = C.c_int
         L.cnf2o_emission_tables.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_EmTab)]
         L.cnf2o_val_table.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.cnf2o_haplos_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
@@ -213,6 +214,13 @@ class OraclePed:
         mv = np.zeros((NUMSHIFTS, NUMTYPES, NUMPATHS), np.int32)
         lib().cnf2o_val_table(C.byref(self.c), ind, gen, first, last, marker, _ptr(v), _ptr(mv))
         return v, mv
+
+    def haplos_row(self, ind, marker, gen=2, first=0, last=None):
+        """haplos[n_rec][2] accumulated by HOT LOOP 2 at one marker (before movehaplos)."""
+        last = self.M - 1 if last is None else last
+        h = np.zeros((self.R, 2))
+        lib().cnf2o_haplos_row(C.byref(self.c), ind, gen, first, last, marker, _ptr(h))
+        return h
 
     def sweep_batch(self, inds, gens=None, first=0, last=None, mode=2, dosage=True, n_threads=0):
         last = self.M - 1 if last is None else last

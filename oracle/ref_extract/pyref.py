@@ -42,6 +42,7 @@ def lib(ieee=True):
         L.ref_turn_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
         L.ref_turn_query.restype = C.c_double
         L.ref_dosage_rows.argtypes = [C.c_void_p]
+        L.ref_haplos_row.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.ref_sweep_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _libs[key] = L
     return _libs[key]
@@ -109,6 +110,12 @@ class RefPed:
         rows = np.zeros((n_rows, 3))
         self.L.ref_dosage_rows(rows.ctypes.data)
         return rows
+
+    def haplos_row(self, marker):
+        """HAPLOS accumulators at one marker for the individual of the last sweep(): [n_rec][2]."""
+        h = np.zeros((self.ped.n_rec, 2))
+        self.L.ref_haplos_row(marker, self.ped.n_rec, h.ctypes.data)
+        return h
 
     def sweep_batch(self, recs, first=0, last=None, threads=0):
         last = self.M - 1 if last is None else last

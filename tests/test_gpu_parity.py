@@ -464,3 +464,50 @@ def test_update_rows_between_sweeps_and_tie_activation(capi):
         np.testing.assert_allclose(after["loglik"][j, 0], r["factor"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(after["dosage"][j], r["dosage"], rtol=1e-7, atol=1e-12)
     ctx.close()
+
+
+def test_haplos_accumulators_against_oracle(capi):
+    """What HOT LOOP 2 leaves in `haplos` per window member (the input of movehaplos): GPU rows per
+    slot, summed per individual, against the oracle's update-mode (HAPLOS) fan-out, which itself is
+    pinned bit-exact on the reference's updatehaplo."""
+    for ped in (synth.make_random_windows(14, 4, seed=41), synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+                synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2)):
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        o = oracle_ped(ped)
+        checked = 0
+        for j, ind in enumerate(ped.dous):
+            gen = int(ped.gen[ind])
+            if not o.sweep_ind(int(ind), gen, mode=2)["ok"]:
+                continue
+            rows = ctx.haplos(j, 0)
+            slots = ctx.window_info(j)["slots"]
+            for m in (0, ped.n_markers - 1):
+                want = o.haplos_row(int(ind), m, gen)
+                got = np.zeros_like(want)
+                for k, r in enumerate(slots):
+                    if r >= 0:
+                        got[r] += rows[m, k]
+                np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12)
+                checked += 1
+        assert checked > 0
+        ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_haplos_accumulators_match_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j in range(len(ped.dous)):
+        if not z["ok"][j]:
+            continue
+        rows = ctx.haplos(j, 0)
+        slots = ctx.window_info(j)["slots"]
+        for ti, m in enumerate(z["turn_markers"]):
+            got = np.zeros((ped.n_rec, 2))
+            for k, r in enumerate(slots):
+                if r >= 0:
+                    got[r] += rows[int(m), k]
+            np.testing.assert_allclose(got, z["haplos"][j, ti], rtol=1e-8, atol=1e-12)
+    ctx.close()

@@ -92,3 +92,15 @@ def test_rank2_tables_reproduce_emission():
                     e = o.emission(int(ind), m, g, -1, s)
                     e2 = sum(T["c"][f] * T["A"][f][g & 7] * T["B"][f][g >> 3] for f in range(2))
                     assert abs(e - e2) <= 1e-14 * max(abs(e), 1e-300) + 1e-300
+
+
+def test_haplos_accumulators(golden):
+    """HAPLOS update mode (updatehaplo) of HOT LOOP 2 against the reference's thread-private haplos."""
+    ped, z = golden
+    o = oracle_ped(ped)
+    for j, ind in enumerate(ped.dous):
+        if not z["ok"][j]:
+            continue
+        for ti, m in enumerate(z["turn_markers"]):
+            got = o.haplos_row(int(ind), int(m), int(ped.gen[ind]))
+            np.testing.assert_allclose(got, z["haplos"][j, ti], rtol=1e-12, atol=1e-15)
