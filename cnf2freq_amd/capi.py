@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnf2hip.so")
 
-OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES = 1, 2, 4, 8
+OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL = 1, 2, 4, 8, 16
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -154,13 +154,14 @@ class Context:
         self.upload_pedigree(ped.par, ped.empty, ped.gen, ped.row_of, ped.dous if dous is None else dous)
 
     # -- the sweep -------------------------------------------------------------
-    def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True):
+    def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
         loglik = np.zeros((n, self.n_chrom))
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
-        flags = (0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
+        flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
+                 | (FULL_SPILL if full_spill else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
         return dict(factors=factors, loglik=loglik, dosage=dos)

@@ -450,7 +450,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     };
     int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
     int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
-    const size_t stride = (size_t)max_chrom_len(ctx) * 520;   // SPILL_ROW of the fast kernel (general kernel uses 512)
+    const size_t stride = (size_t)max_chrom_len(ctx) * 528;   // covers every layout: 520 or 528 doubles per (pair of) marker(s), 512 in the general kernel
     {
         // One spill slot per resident wave.  Long chromosomes make slots big: keep the spill within
         // ~60 % of what is free (plus what the context already holds) by running fewer waves.
@@ -515,7 +515,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (n_fast > 0) {
-        launch_fb_fast(p, grid_fast, ctx->stream);
+        launch_fb_fast(p, grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_general > 0) {

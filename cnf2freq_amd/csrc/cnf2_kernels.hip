@@ -542,8 +542,13 @@ __device__ __forceinline__ void emission_from_row(const double* row, const FastC
     for (int j = 0; j < 8; j++) e[j] = cA0 * B0[j] + cA1 * B1[j];
 }
 
+// HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
+// with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
+// spill traffic for ~15 % more arithmetic.
+template <bool HALF>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
+    constexpr int ROW = HALF ? 528 : SPILL_ROW;   // doubles per spill row: 512 alpha-minus + reciprocals (8, or 8 + 8 for the pair)
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
 
     const int lane  = threadIdx.x & 63;
@@ -591,16 +596,19 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 emission_from_row(tab + (m - m0) * TAB_STRIDE, c, e);
                 const double2 r = rf_next;
                 if (m < last) rf_next = p.rho[m + 1];
-                double* sp = spill + (size_t)(m - first) * SPILL_ROW + lane;
+                const int ml = m - first;
+                double*   sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
+                if (!HALF || !(ml & 1)) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+                    for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) a[j] *= e[j];
                 double inv;
                 scale_chain(a, &mant, &expo, &dead, &inv);
                 // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
-                // forward scale before each marker without a reduction
-                if (c.lo == 0) sp[512 - lane + s] = inv;
+                // forward scale before each marker without a reduction (and redo the forward step)
+                if (c.lo == 0) sp[512 - lane + ((HALF && (ml & 1)) ? 8 : 0) + s] = inv;
                 if (m < last) transition(a, r.x, r.y);
             }
             wave_lds_fence();
@@ -642,23 +650,24 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         const bool   chain_on = c.active && !skip && !dead && !(factor - fs > 40.0);   // cnF2freq.cpp:5420-5421
         // software pipeline: the spill row, the reciprocals and the recombination fractions of the NEXT
         // marker (m-1) are requested before the current marker is processed
-        double am_next[8], inv_next;
+        double am_next[8], inv_next, inv_odd = 1.0;   // HALF: am_next / inv_next belong to the even marker of the pair
         double2 r_next = make_double2(0.0, 0.0);
         {
-            const double* sp = spill + (size_t)(last - first) * SPILL_ROW + lane;
+            const int     mll = last - first;
+            const double* sp  = spill + (size_t)(HALF ? (mll >> 1) : mll) * ROW + lane;
 #pragma unroll
             for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
             inv_next = sp[512 - lane + s];
+            if (HALF) inv_odd = sp[520 - lane + s];
             if (last > first) r_next = p.rho[last - 1];
         }
+        load_raw(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
-            {
-                // (no tile-ahead request here: the class tables already use the register budget)
-                RawSlots rawb;
-                load_raw(p, c, m0, first, last, &rawb);
-                produce_tile<true>(p, c, tab, m0, last, rawb);
-            }
+            produce_tile<true>(p, c, tab, m0, last, raw);
+#ifdef CNF2_BWD_RAW_PREFETCH
+            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);          // next tile's inputs, a tile ahead
+#endif
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = mend; m >= m0; m--) {
@@ -666,16 +675,36 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 double        e[8];
                 emission_from_row(row, c, e);
                 double        wj[8];
+                const double2 r_m = r_next;
+                const int     ml  = m - first;
+                double        inv_m;
+                if (HALF && (ml & 1)) {
+                    // odd marker: alpha-minus(m) = T( alpha-minus(m-1) * e(m-1) * inv(m-1) ), exactly the
+                    // forward step (cnF2freq.cpp:2238-2367); marker m-1 is the previous row of this tile
+                    double ep[8];
+                    emission_from_row(row - TAB_STRIDE, c, ep);
 #pragma unroll
-                for (int j = 0; j < 8; j++) wj[j] = am_next[j] * b[j];
-                const double  inv_m = inv_next;
-                const double2 r_m   = r_next;
-                if (m > first) {
-                    const double* sp = spill + (size_t)(m - 1 - first) * SPILL_ROW + lane;
+                    for (int j = 0; j < 8; j++) wj[j] = am_next[j] * ep[j];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
-                    inv_next = sp[512 - lane + s];
+                    for (int j = 0; j < 8; j++) wj[j] *= inv_next;
+                    transition(wj, r_m.x, r_m.y);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) wj[j] *= b[j];
+                    inv_m = inv_odd;
                     if (m - 1 > first) r_next = p.rho[m - 2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) wj[j] = am_next[j] * b[j];
+                    inv_m = inv_next;
+                    if (m > first) {
+                        const int     mlp = ml - 1;
+                        const double* sp  = spill + (size_t)(HALF ? (mlp >> 1) : mlp) * ROW + lane;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
+                        inv_next = sp[512 - lane + s];
+                        if (HALF) inv_odd = sp[520 - lane + s];
+                        if (m - 1 > first) r_next = p.rho[m - 2];
+                    }
                 }
                 {
                     int ex;
@@ -728,6 +757,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
             }
             wave_lds_fence();
+#ifndef CNF2_BWD_RAW_PREFETCH
+            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);          // requested before the epilogue's LDS work
+#endif
             // tile epilogue: lane mi < 8 finishes marker m0 + mi: 3 x 16 partials, normalise, store
             if (lane < 8 && m0 + lane <= last) {
                 const double* red = tab + lane * TAB_STRIDE + TAB_R;
@@ -1075,9 +1107,10 @@ void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipSt
     hipLaunchKernelGGL(state_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
 }
 
-void launch_fb_fast(const KernelParams& p, int grid, hipStream_t stream)
+void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fb_fast_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    if (half_spill) hipLaunchKernelGGL(fb_fast_kernel<true>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(fb_fast_kernel<false>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
@@ -1089,7 +1122,7 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
 int fb_fast_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fb_fast_kernel, CNF2_BLOCK, 0) != hipSuccess) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fb_fast_kernel<true>, CNF2_BLOCK, 0) != hipSuccess) n = 2;
     return n < 1 ? 1 : n;
 }
 

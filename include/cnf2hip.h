@@ -49,7 +49,9 @@ enum {
     CNF2_OUT_DEVICE   = 1u << 0, /* output pointers are device pointers (no D2H copy, no sync) */
     CNF2_NO_DOSAGE    = 1u << 1, /* HOT LOOP 1 only: factors/loglik, skip the per-locus rows    */
     CNF2_RAW_DOSAGE   = 1u << 2, /* rows un-normalised (sum of val by class, cnF2freq.cpp:3523) */
-    CNF2_NO_TIES      = 1u << 3  /* drop ignoreflag2's all-or-none rule (cnF2freq.cpp:3484-3486) */
+    CNF2_NO_TIES      = 1u << 3, /* drop ignoreflag2's all-or-none rule (cnF2freq.cpp:3484-3486) */
+    CNF2_FULL_SPILL   = 1u << 4  /* store alpha-minus at every marker instead of every second one and
+                                    recomputing the others in the backward pass (same results) */
 };
 
 typedef struct cnf2_ctx cnf2_ctx;

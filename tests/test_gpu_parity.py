@@ -511,3 +511,25 @@ def test_haplos_accumulators_match_reference(capi, case):
                     got[r] += rows[int(m), k]
             np.testing.assert_allclose(got, z["haplos"][j, ti], rtol=1e-8, atol=1e-12)
     ctx.close()
+
+
+def test_half_spill_recompute_equals_full_spill(capi):
+    """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
+    pass by one forward step.  Must give exactly what storing every marker gives (even and odd
+    chromosome lengths, one-marker chromosome)."""
+    ped = synth.make_outbred3(3, 3, 21, 1, seed=12, missing=0.15, random_hw=True, random_sure=True)
+    ped.chromstarts = np.array([0, 1, 9, 22], np.int32)              # lengths 1, 8 (even), 13 (odd)
+    ped.pos = np.concatenate([[0.0], np.arange(8) * 0.9, np.arange(13) * 1.7])
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    half = ctx.sweep(raw=True)
+    full = ctx.sweep(raw=True, full_spill=True)
+    assert np.array_equal(half["factors"], full["factors"])
+    np.testing.assert_allclose(half["dosage"], full["dosage"], rtol=1e-12, atol=1e-15)
+    o = oracle_ped(ped)
+    for c in range(3):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        d = ctx.sweep()["dosage"][:, first:last + 1]
+        np.testing.assert_allclose(d, want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
