@@ -33,6 +33,8 @@ struct cnf2_ctx {
     std::vector<int32_t> chromstarts;
     double               genrec[3] = {-0.02, -0.02, -0.02};
     double2*             d_rho = nullptr;
+    double2*             d_tq = nullptr;
+    double*              d_logk = nullptr;
 
     // rows
     int      n_rows = 0;
@@ -142,6 +144,8 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->d_rho);
+    hipFree(ctx->d_tq);
+    hipFree(ctx->d_logk);
     hipFree(ctx->d_allele8);
     hipFree(ctx->d_sure);
     hipFree(ctx->d_hw);
@@ -203,6 +207,24 @@ int cnf2_upload_map(cnf2_ctx* ctx, const double* pos, int n_markers, const int32
     ctx->d_rho = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rho, sizeof(double2) * n_markers));
     HIP_TRY(ctx, hipMemcpy(ctx->d_rho, rho.data(), sizeof(double2) * n_markers, hipMemcpyHostToDevice));
+    // fast kernel: butterflies x' = x + t * partner with t = r / (1 - r); the dropped scalar
+    // (1-r0)^4 (1-r1)^2 per gap (bits with TYPEGENS 0: four, TYPEGENS 1: two, settings.h:23) is
+    // accounted for in the log-likelihoods through its logarithm summed over each chromosome
+    std::vector<double2> tq(n_markers);
+    std::vector<double>  logk(n_chrom, 0.0);
+    for (int c = 0; c < n_chrom; c++)
+        for (int m = chromstarts[c]; m < chromstarts[c + 1]; m++) {
+            tq[m] = make_double2(rho[m].x / (1.0 - rho[m].x), rho[m].y / (1.0 - rho[m].y));
+            if (m + 1 < chromstarts[c + 1]) logk[c] += 4.0 * log1p(-rho[m].x) + 2.0 * log1p(-rho[m].y);
+        }
+    if (ctx->d_tq) HIP_TRY(ctx, hipFree(ctx->d_tq));
+    if (ctx->d_logk) HIP_TRY(ctx, hipFree(ctx->d_logk));
+    ctx->d_tq = nullptr;
+    ctx->d_logk = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tq, sizeof(double2) * n_markers));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_logk, sizeof(double) * n_chrom));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tq, tq.data(), sizeof(double2) * n_markers, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_logk, logk.data(), sizeof(double) * n_chrom, hipMemcpyHostToDevice));
     return CNF2_OK;
 }
 
@@ -388,6 +410,8 @@ static void base_params(cnf2_ctx* ctx, KernelParams* p)
     p->sure      = ctx->d_sure;
     p->hw        = ctx->d_hw;
     p->rho       = ctx->d_rho;
+    p->tq        = ctx->d_tq;
+    p->chrom_logk = ctx->d_logk;
     p->n_markers = ctx->n_markers;
     p->n_chrom   = ctx->n_chrom;
 }

@@ -35,6 +35,8 @@ struct KernelParams {
     const double*  hw;         // [n_rows][n_markers]
     const double2* rho;        // [n_markers] recombination fraction of gap m -> m+1 for
                                //             genrec[0] (.x) and genrec[1] (.y); 0 when dist <= 0
+    const double2* tq;         // [n_markers] r / (1 - r) of the same gaps (fast kernel's scaled butterflies)
+    const double*  chrom_logk; // [n_chrom] sum over the chromosome's gaps of 4 log(1-r0) + 2 log(1-r1)
     int            n_jobs;
     int            n_markers;
     int            n_chrom;

@@ -140,6 +140,48 @@ __device__ __forceinline__ void transition(double (&a)[8], double r0, double r1)
     }
 }
 
+// Same operator up to a per-gap constant: with t = r / (1 - r) every butterfly is x' = x + t * partner
+// and the dropped factor (1-r0)^4 (1-r1)^2 is a scalar common to all states and shift modes, so it
+// only moves the normaliser of the step.  The host adds its logarithm, summed over the chromosome,
+// to the reported log-likelihoods; ratios (the per-locus rows) never see it.  One fused multiply-add
+// per element and stage instead of a multiply and an FMA.
+__device__ __forceinline__ void transition_scaled(double (&a)[8], double t0, double t1)
+{
+    double q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = lane_xor1(a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = fma(t1, q[j], a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = lane_xor2(a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = fma(t0, q[j], a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = lane_xor4(a[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = fma(t0, q[j], a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const double x = a[j], y = a[j + 1];
+        a[j]     = fma(t1, y, x);
+        a[j + 1] = fma(t1, x, y);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j & 2) continue;
+        const double x = a[j], y = a[j + 2];
+        a[j]     = fma(t0, y, x);
+        a[j + 2] = fma(t0, x, y);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double x = a[j], y = a[j + 4];
+        a[j]     = fma(t0, y, x);
+        a[j + 4] = fma(t0, x, y);
+    }
+}
+
 // ------------------------------------------------------------------ per-job lane state
 struct LaneCtx {
     LaneJob L;            // producer role
@@ -582,7 +624,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         double mant = 1.0;
         int    expo = 0;
         bool   dead = false;
-        double2 rf_next = p.rho[first];
+        double2 rf_next = p.tq[first];
         RawSlots raw;
         load_raw(p, c, first, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
@@ -595,7 +637,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 double e[8];
                 emission_from_row(tab + (m - m0) * TAB_STRIDE, c, e);
                 const double2 r = rf_next;
-                if (m < last) rf_next = p.rho[m + 1];
+                if (m < last) rf_next = p.tq[m + 1];
                 const int ml = m - first;
                 double*   sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
                 if (!HALF || !(ml & 1)) {
@@ -609,12 +651,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
                 // forward scale before each marker without a reduction (and redo the forward step)
                 if (c.lo == 0) sp[512 - lane + ((HALF && (ml & 1)) ? 8 : 0) + s] = inv;
-                if (m < last) transition(a, r.x, r.y);
+                if (m < last) transition_scaled(a, r.x, r.y);
             }
             wave_lds_fence();
         }
 
         // ---------------------------------------------------------------- likelihoods
+        // the butterflies dropped (1-r0)^4 (1-r1)^2 per gap: its logarithm over the chromosome comes back here
+        const double logk = p.chrom_logk[jb.chrom];
         double fs = dead ? (double)CNF2_MINFACTOR_F : (log(mant) + (double)expo * 0.69314718055994530942);
         if (!c.active) fs = CNF2_IGNORED_D;
         double fmaxv = across_chains_max(fs);
@@ -622,8 +666,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         double term  = c.active ? exp(fs - fmaxv) : 0.0;
         double real  = across_chains_sum(term);
         double factor = fmaxv + log(real);
-        if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = fs;
-        if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = factor;
+        if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = (c.active && !dead) ? fs + logk : fs;
+        if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = (fmaxv > -1e14) ? factor + logk : factor;
         const bool   skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;
         const double ws   = (c.active && !skip && !(factor - fs > 40.0)) ? exp(fs - factor) : 0.0;
         if (p.flags & KP_NO_DOSAGE) continue;
@@ -659,7 +703,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
             inv_next = sp[512 - lane + s];
             if (HALF) inv_odd = sp[520 - lane + s];
-            if (last > first) r_next = p.rho[last - 1];
+            if (last > first) r_next = p.tq[last - 1];
         }
         load_raw(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
@@ -687,11 +731,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                     for (int j = 0; j < 8; j++) wj[j] = am_next[j] * ep[j];
 #pragma unroll
                     for (int j = 0; j < 8; j++) wj[j] *= inv_next;
-                    transition(wj, r_m.x, r_m.y);
+                    transition_scaled(wj, r_m.x, r_m.y);
 #pragma unroll
                     for (int j = 0; j < 8; j++) wj[j] *= b[j];
                     inv_m = inv_odd;
-                    if (m - 1 > first) r_next = p.rho[m - 2];
+                    if (m - 1 > first) r_next = p.tq[m - 2];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; j++) wj[j] = am_next[j] * b[j];
@@ -703,7 +747,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                         for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
                         inv_next = sp[512 - lane + s];
                         if (HALF) inv_odd = sp[520 - lane + s];
-                        if (m - 1 > first) r_next = p.rho[m - 2];
+                        if (m - 1 > first) r_next = p.tq[m - 2];
                     }
                 }
                 {
@@ -753,7 +797,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #pragma unroll
                     for (int j = 0; j < 8; j++) b[j] *= e[j];
                     scale_chain(b, &bmant, &bexpo, &bdead);
-                    transition(b, r_m.x, r_m.y);
+                    transition_scaled(b, r_m.x, r_m.y);
                 }
             }
             wave_lds_fence();
