@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this process's CPU share)")
+    ap.add_argument("--full-spill", action="store_true", help="A/B: store alpha-minus at every marker (CNF2_FULL_SPILL)")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow on one GPU (posteriors staged through the host)")
@@ -228,7 +229,8 @@ def main():
     kernel_ms = []
 
     def step():
-        ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr())
+        ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(),
+                         capi.FULL_SPILL if args.full_spill else 0)
         ctx.sync()
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
@@ -280,7 +282,7 @@ def main():
                            world, ", one RCCL gather of posteriors to rank 0" if do_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
-                         "kernel": "cnf2::fb_fast_kernel", "kernel_ms": k_ms,
+                         "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": B_UNIT},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
         }
