@@ -646,8 +646,12 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) a[j] *= e[j];
-                double inv;
-                scale_chain(a, &mant, &expo, &dead, &inv);
+                // HALF: the vector is rescaled at every second marker only (and at the last one, where the
+                // likelihood is read off); two emission products in a row cannot underflow a double.  A
+                // skipped step has normaliser 1 (the reference rescales at every marker, cnF2freq.cpp:1664-1668;
+                // only the bookkeeping of the scale differs, not the normalised values it is divided out of)
+                double inv = 1.0;
+                if (!HALF || !(ml & 1) || m == last) scale_chain(a, &mant, &expo, &dead, &inv);
                 // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
                 // forward scale before each marker without a reduction (and redo the forward step)
                 if (c.lo == 0) sp[512 - lane + ((HALF && (ml & 1)) ? 8 : 0) + s] = inv;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 if (m > first) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) b[j] *= e[j];
-                    scale_chain(b, &bmant, &bexpo, &bdead);
+                    if (!HALF || !(ml & 1)) scale_chain(b, &bmant, &bexpo, &bdead);
                     transition_scaled(b, r_m.x, r_m.y);
                 }
             }
