@@ -654,7 +654,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 if (!HALF || !(ml & 1) || m == last) scale_chain(a, &mant, &expo, &dead, &inv);
                 // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
                 // forward scale before each marker without a reduction (and redo the forward step)
-                if (c.lo == 0) sp[512 - lane + ((HALF && (ml & 1)) ? 8 : 0) + s] = inv;
+                if (HALF) {
+                    // odd markers are not rescaled: only the last marker of an even-length chromosome has
+                    // a reciprocal worth storing in the odd slot
+                    if (c.lo == 0 && (!(ml & 1) || m == last)) sp[512 - lane + ((ml & 1) ? 8 : 0) + s] = inv;
+                } else if (c.lo == 0) sp[512 - lane + s] = inv;
                 if (m < last) transition_scaled(a, r.x, r.y);
             }
             wave_lds_fence();
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                         if (m - 1 > first) r_next = p.tq[m - 2];
                     }
                 }
-                {
+                if (!HALF || !(ml & 1) || m == last) {     // skipped (odd) steps have normaliser 1
                     int ex;
                     fmant = frexp(fmant * inv_m, &ex);
                     fexpo += ex;
