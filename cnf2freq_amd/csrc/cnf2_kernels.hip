@@ -27,14 +27,6 @@
 namespace cnf2 {
 
 // ------------------------------------------------------------------ lane exchange helpers
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ double dpp_mov(double old, double v)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK_MASK, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK_MASK, false);
-    return __hiloint2double(hi, lo);
-}
-
 // full-wave DPP move without a tied "old" operand (every lane is written, so no copy is needed)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_all(double v)
@@ -55,15 +47,9 @@ __device__ __forceinline__ double swizzle_xor(double v)
 // value of lane (id ^ 1), (id ^ 2), (id ^ 4)
 __device__ __forceinline__ double lane_xor1(double v) { return dpp_mov_all<0xB1>(v); } // quad_perm [1,0,3,2]
 __device__ __forceinline__ double lane_xor2(double v) { return dpp_mov_all<0x4E>(v); } // quad_perm [2,3,0,1]
-#ifdef CNF2_XOR4_DPP
-__device__ __forceinline__ double lane_xor4(double v)
-{
-    double t = dpp_mov<0x104, 0x5>(v, v); // row_shl:4 into banks 0,2 (lanes with bit2 == 0 read lane+4)
-    return dpp_mov<0x114, 0xA>(t, v);     // row_shr:4 into banks 1,3 (lanes with bit2 == 1 read lane-4)
-}
-#else
+// xor 4 has no single DPP form on gfx950 (row_shl/row_shr with bank masks costs two tied moves per
+// dword plus hazard nops); the LDS crossbar does it in one ds_swizzle per dword and runs beside the VALU
 __device__ __forceinline__ double lane_xor4(double v) { return swizzle_xor<4>(v); }
-#endif
 __device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128>(v); } // row_ror:8
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
@@ -676,8 +662,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         double factor = fmaxv + log(real);
         if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = (c.active && !dead) ? fs + logk : fs;
         if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = (fmaxv > -1e14) ? factor + logk : factor;
-        const bool   skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;
-        const double ws   = (c.active && !skip && !(factor - fs > 40.0)) ? exp(fs - factor) : 0.0;
+        const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;     // cnF2freq.cpp:5403
         if (p.flags & KP_NO_DOSAGE) continue;
 
         // ---------------------------------------------------------------- backward + rows
@@ -717,9 +702,6 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
             produce_tile<true>(p, c, tab, m0, last, raw);
-#ifdef CNF2_BWD_RAW_PREFETCH
-            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);          // next tile's inputs, a tile ahead
-#endif
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = mend; m >= m0; m--) {
@@ -809,9 +791,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
             }
             wave_lds_fence();
-#ifndef CNF2_BWD_RAW_PREFETCH
-            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);          // requested before the epilogue's LDS work
-#endif
+            // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
+            // whole marker loop costs more in registers than the extra latency it hides; measured)
+            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);
             // tile epilogue: lane mi < 8 finishes marker m0 + mi: 3 x 16 partials, normalise, store
             if (lane < 8 && m0 + lane <= last) {
                 const double* red = tab + lane * TAB_STRIDE + TAB_R;
