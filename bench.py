@@ -227,6 +227,7 @@ def main():
         gather_ll = [torch.empty(loglik.shape, dtype=loglik.dtype, device=gdev) for _ in range(world)]
 
     kernel_ms = []
+    gather_ms = []
 
     def step():
         ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(),
@@ -235,12 +236,16 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
             # the one collective of the path: posteriors to rank 0 over xGMI (RCCL)
+            tg = time.perf_counter()
             cdist.gather_to_root(loglik.cpu() if staged else loglik, 0, gather_ll if rank == 0 else None)
             cdist.gather_to_root(dosage.cpu() if staged else dosage, 0, gather_list if rank == 0 else None)
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - tg) * 1e3)
 
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    gather_ms.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -285,6 +290,7 @@ def main():
                          "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": B_UNIT},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
+            "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,
         }
         if args.cpu_seconds > 0 and world == 1:      # CPU baseline leg: rank 0 at N = 1 only
             try:
