@@ -273,6 +273,19 @@ def main():
                 traffic = tj.get("bytes_per_launch")
         except Exception:
             traffic = None
+        # size-independent checks on the full output of the last step (outside the timed region):
+        # every row is a distribution, every likelihood is finite and negative, and the logsumexp
+        # identity between per-mode and total likelihoods holds
+        rs = dosage.sum(dim=2)
+        fmx = factors.max(dim=2, keepdim=True).values
+        lse = (fmx.squeeze(2) + torch.log(torch.exp(factors - fmx).sum(dim=2)))
+        checks = {
+            "rows_sum_to_one": bool(((rs - 1.0).abs() < 1e-9).all().item()),
+            "rows_nonnegative": bool((dosage >= 0).all().item()),
+            "loglik_finite_negative": bool((torch.isfinite(loglik) & (loglik < 0)).all().item()),
+            "logsumexp_identity": bool(((lse - loglik).abs() < 1e-9 * loglik.abs().clamp(min=1.0)).all().item()),
+        }
+        del rs, fmx, lse
         ll = loglik.cpu().numpy()
         out = {
             "metric": "individual*marker fwd-bwd steps/sec (all 8 shift modes, forward+backward, dosage rows)",
@@ -290,6 +303,7 @@ def main():
                          "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": B_UNIT},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
+            "checks": checks,
             "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,
         }
         if args.cpu_seconds > 0 and world == 1:      # CPU baseline leg: rank 0 at N = 1 only
