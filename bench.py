@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this process's CPU share)")
     ap.add_argument("--full-spill", action="store_true", help="A/B: store alpha-minus at every marker (CNF2_FULL_SPILL)")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="wait for each step's gather before the next sweep (default: the gather of step k runs "
+                         "beside the sweep of step k+1, double-buffered)")
+    ap.add_argument("--reserve-blocks", type=int, default=16,
+                    help="workgroup slots the sweep leaves free for the RCCL kernels when gathers overlap")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow on one GPU (posteriors staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -216,10 +221,15 @@ def main():
     ctx.upload_pedigree(par, empty, gen, row_of, dous)
 
     factors = torch.empty((n, args.chroms, 8), dtype=torch.float64, device=device)
-    loglik = torch.empty((n, args.chroms), dtype=torch.float64, device=device)
-    dosage = torch.empty((n, M, 3), dtype=torch.float64, device=device)
-    gather_list = gather_ll = None
     do_gather = world > 1 and not args.no_gather
+    overlap = do_gather and not args.no_overlap
+    nbuf = 2 if overlap else 1
+    logliks = [torch.empty((n, args.chroms), dtype=torch.float64, device=device) for _ in range(nbuf)]
+    dosages = [torch.empty((n, M, 3), dtype=torch.float64, device=device) for _ in range(nbuf)]
+    loglik, dosage = logliks[0], dosages[0]
+    gather_list = gather_ll = None
+    if overlap:
+        ctx.set_grid_reserve(args.reserve_blocks)
     staged = world > 1 and args.backend == "gloo"
     if do_gather and rank == 0:
         gdev = torch.device("cpu") if staged else device
@@ -228,22 +238,58 @@ def main():
 
     kernel_ms = []
     gather_ms = []
+    pending = [[] for _ in range(nbuf)]     # outstanding gathers reading buffer i
+    state = {"k": 0}
+
+    def drain(i):
+        for w in pending[i]:
+            w.wait()
+        if pending[i]:
+            torch.cuda.synchronize()
+        pending[i] = []
 
     def step():
-        ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(),
+        i = state["k"] % nbuf
+        state["k"] += 1
+        drain(i)                             # the gather that last read this buffer must be done
+        ll_i, dos_i = logliks[i], dosages[i]
+        ctx.sweep_device(0, n, factors.data_ptr(), ll_i.data_ptr(), dos_i.data_ptr(),
                          capi.FULL_SPILL if args.full_spill else 0)
         ctx.sync()
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
-            # the one collective of the path: posteriors to rank 0 over xGMI (RCCL)
+            # the one collective of the path: posteriors to rank 0 over xGMI (RCCL).  With overlap the
+            # call only enqueues it: it runs beside the next sweep and is awaited before its buffer is
+            # reused (and at the end of the timed region).
             tg = time.perf_counter()
-            cdist.gather_to_root(loglik.cpu() if staged else loglik, 0, gather_ll if rank == 0 else None)
-            cdist.gather_to_root(dosage.cpu() if staged else dosage, 0, gather_list if rank == 0 else None)
-            torch.cuda.synchronize()
+            src_ll = ll_i.cpu() if staged else ll_i
+            src_d = dos_i.cpu() if staged else dos_i
+            if overlap:
+                out_ll = gather_ll if rank == 0 else None
+                out_d = gather_list if rank == 0 else None
+                pending[i].append(dist.gather(src_ll, out_ll, dst=0, async_op=True))
+                pending[i].append(dist.gather(src_d, out_d, dst=0, async_op=True))
+                keep_alive[i] = (src_ll, src_d)
+            else:
+                cdist.gather_to_root(src_ll, 0, gather_ll if rank == 0 else None)
+                cdist.gather_to_root(src_d, 0, gather_list if rank == 0 else None)
+                torch.cuda.synchronize()
             gather_ms.append((time.perf_counter() - tg) * 1e3)
 
+    keep_alive = [None] * nbuf
+
+    def finish():
+        for i in range(nbuf):
+            drain(i)
+
+    if do_gather:
+        # set up the point-to-point connections of the gather before anything is timed
+        tiny = torch.zeros(8, dtype=torch.float64, device=torch.device("cpu") if staged else device)
+        cdist.gather_to_root(tiny, 0)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    finish()
     kernel_ms.clear()
     gather_ms.clear()
     if world > 1:
@@ -252,10 +298,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    loglik, dosage = logliks[(state["k"] - 1) % nbuf], dosages[(state["k"] - 1) % nbuf]
     tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if staged else device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -297,7 +345,8 @@ def main():
                                    % (n, args.chroms * args.snps_per_chrom, args.chroms, args.snps_per_chrom, M),
                        "individuals_per_gpu": n, "markers": M, "shift_modes": 8, "states": 64,
                        "parallelism": "individuals sharded over %d GPU(s)%s" % (
-                           world, ", one RCCL gather of posteriors to rank 0" if do_gather else "")},
+                           world, (", one RCCL gather of posteriors to rank 0 per step" +
+                                   (" (overlapped with the next sweep)" if overlap else "")) if do_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,

@@ -25,6 +25,7 @@ SYMBOLS = [
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
+    "cnf2_set_grid_reserve",
 ]
 
 
@@ -69,6 +70,7 @@ def load():
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
         L.cnf2_workspace_bytes.argtypes = [vp]
         L.cnf2_workspace_bytes.restype = C.c_size_t
+        L.cnf2_set_grid_reserve.argtypes = [vp, i32]
         L.cnf2_stream.argtypes = [vp]
         L.cnf2_stream.restype = vp
         _lib = L
@@ -178,6 +180,9 @@ class Context:
         ms = np.zeros(4, np.float32)
         self._chk(self.L.cnf2_last_kernel_ms(self.h, _p(ms), 4), "cnf2_last_kernel_ms")
         return float(ms[0])
+
+    def set_grid_reserve(self, blocks):
+        self._chk(self.L.cnf2_set_grid_reserve(self.h, blocks), "cnf2_set_grid_reserve")
 
     def workspace_bytes(self):
         return int(self.L.cnf2_workspace_bytes(self.h))

@@ -49,6 +49,7 @@ struct cnf2_ctx {
     bool                windows_dirty = true;   // rows or pedigree changed since the last derivation
     uint8_t*            d_rowflags = nullptr;
     int                 fast_blocks_per_cu = 1;
+    int                 reserve_blocks = 0;     // workgroup slots left free for concurrent kernels (RCCL)
 
     // workspace
     Job*    d_jobs = nullptr;
@@ -166,6 +167,13 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
 }
 
 void* cnf2_stream(cnf2_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int cnf2_set_grid_reserve(cnf2_ctx* ctx, int blocks)
+{
+    if (!ctx || blocks < 0) return CNF2_ERR_ARG;
+    ctx->reserve_blocks = blocks;
+    return CNF2_OK;
+}
 
 int cnf2_sync(cnf2_ctx* ctx)
 {
@@ -469,7 +477,8 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     // grids: one wave per job in flight, capped at what is resident so that the spill stays small
     auto grid_for = [&](size_t nj, int per_cu) {
         int g   = (int)((nj + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-        int cap = ctx->n_cu * per_cu;
+        int cap = ctx->n_cu * per_cu - ctx->reserve_blocks;
+        if (cap < 1) cap = 1;
         return g > cap ? cap : g;
     };
     int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);

@@ -159,6 +159,10 @@ int cnf2_selftest_lane_xor(cnf2_ctx *ctx, double *out384);
 int    cnf2_last_kernel_ms(cnf2_ctx *ctx, float *kernel_ms, int n);
 size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
 void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
+/* The sweep kernels are persistent (one resident wave per job in flight) and normally fill every
+ * workgroup slot of the GPU.  Leaving `blocks` slots free lets another kernel -- the RCCL gather of
+ * the previous sweep's posteriors -- run beside the sweep instead of behind it. */
+int    cnf2_set_grid_reserve(cnf2_ctx *ctx, int blocks);
 
 #ifdef __cplusplus
 }
