@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnf2hip.so")
+# CNF2HIP_LIB: another build of the same library (kernel A/B timing); still the HIP path, never a fallback
+LIB_PATH = os.environ.get("CNF2HIP_LIB") or os.path.join(_HERE, "libcnf2hip.so")
 
 OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL = 1, 2, 4, 8, 16
 MINFACTOR = float(np.float32(-1e15))

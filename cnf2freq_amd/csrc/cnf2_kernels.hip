@@ -20,6 +20,8 @@
 // cnF2freq.cpp:5416-5553) and carries beta.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cnf2_device.h"
 #include "cnf2_lane.h"
 #include "cnf2_emtab.h"
@@ -50,6 +52,19 @@ __device__ __forceinline__ double lane_xor2(double v) { return dpp_mov_all<0x4E>
 // xor 4 has no single DPP form on gfx950 (row_shl/row_shr with bank masks costs two tied moves per
 // dword plus hazard nops); the LDS crossbar does it in one ds_swizzle per dword and runs beside the VALU
 __device__ __forceinline__ double lane_xor4(double v) { return swizzle_xor<4>(v); }
+// State bit 2 does not have to live in lane bit 2.  With lane(lo) = b0 ^ 2 b1 ^ 7 b2 (an invertible
+// GF(2) map of the three low state bits) flipping b2 is "lane i <-> lane 7-i" inside each group of 8 =
+// DPP row_half_mirror, a plain VALU move like the two quad_perm stages: no trip through the LDS pipe.
+#ifndef CNF2_MIRROR_BIT2
+#define CNF2_MIRROR_BIT2 1
+#endif
+#if CNF2_MIRROR_BIT2
+__device__ __forceinline__ double lane_flip_b2(double v) { return dpp_mov_all<0x141>(v); }
+__device__ __forceinline__ int    state_lo(int lane) { return (lane & 7) ^ ((lane & 4) ? 3 : 0); }
+#else
+__device__ __forceinline__ double lane_flip_b2(double v) { return lane_xor4(v); }
+__device__ __forceinline__ int    state_lo(int lane) { return lane & 7; }
+#endif
 __device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128>(v); } // row_ror:8
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
@@ -100,8 +115,10 @@ __device__ __forceinline__ void transition(double (&a)[8], double r0, double r1)
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * q[j];
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = lane_xor4(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_flip_b2(a[j]);
+#if !CNF2_MIRROR_BIT2
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * q[j];
     // bits 3..5: registers
@@ -143,8 +160,10 @@ __device__ __forceinline__ void transition_scaled(double (&a)[8], double t0, dou
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = fma(t0, q[j], a[j]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = lane_xor4(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_flip_b2(a[j]);
+#if !CNF2_MIRROR_BIT2
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = fma(t0, q[j], a[j]);
 #pragma unroll
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
         c.s2 = (s >> 2) & 1;
-        c.lo      = lane & 7;
+        c.lo      = state_lo(lane);
         c.active  = !(s & w.shiftignore) && s < w.shiftend;
         c.n_combo = (p.flags & KP_NO_TIES) ? 1 : (1 << w.n_groups);
         if (p.flags & KP_NO_TIES) c.L.tie_par = c.L.tie_tr = c.L.tie_ot = -1;
@@ -498,6 +517,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 #define SPILL_ROW 520    /* doubles per marker in the spill: 8 x 64 alpha-minus + 8 chain reciprocals */
 #define TAB_STRIDE 202   /* doubles per marker row: 16-B aligned rows, conflict-free producer stores */
 #define TAB_C 64
+#define TAB_T 68     /* double2: r/(1-r) of the gap carried by this row */
 #define TAB_R 72
 #define TAB_2 136
 
@@ -515,8 +535,11 @@ struct RawSlots {
     uint8_t ap[4];
     double2 su[4];
     double  hw[4];
+    double2 tq;      // scaled recombination odds of the gap this marker's row carries (see produce_tile)
 };
 
+// TQ_SHIFT: the forward pass needs the gap after marker m in row m, the backward pass the gap before it
+template <int TQ_SHIFT>
 __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c, int m0, int lo_m, int hi_m, RawSlots* r)
 {
     int m = m0 + c.mi;
@@ -529,6 +552,8 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
         r->su[k] = p.sure[i];
         r->hw[k] = p.hw[i];
     }
+    const int mt = m + TQ_SHIFT;
+    r->tq        = p.tq[mt < 0 ? 0 : mt];
 }
 
 template <bool CLASSES>
@@ -557,6 +582,9 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
             row[TAB_C + c.pc.f * 2 + 0] = cw[0];
             row[TAB_C + c.pc.f * 2 + 1] = cw[1];
         }
+        // the gap's butterfly factors ride in the row: the marker loop never touches vmcnt for them
+        // (a vector load there would make every s_waitcnt drain the spill stores as well)
+        if (c.part == 0) *(double2*)(row + TAB_T) = raw.tq;
     }
 }
 
@@ -569,6 +597,18 @@ __device__ __forceinline__ void emission_from_row(const double* row, const FastC
 #pragma unroll
     for (int j = 0; j < 8; j++) e[j] = cA0 * B0[j] + cA1 * B1[j];
 }
+
+// Running state of the backward pass of one lane (kept in one struct so that the per-marker body can be
+// instantiated for even and odd markers without a merge of differently-defined values between them).
+struct BwdState {
+    double b[8];          // beta
+    double am[8];         // alpha-minus of the row in flight (HALF: of the even marker of the pair)
+    double inv_even;      // reciprocal normaliser stored with that row
+    double inv_odd;       // HALF: the one of an unrescaled odd last marker (else 1)
+    double bmant, fmant;
+    int    bexpo, fexpo;
+    bool   bdead;
+};
 
 // HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
@@ -598,7 +638,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
         c.s2 = (s >> 2) & 1;
-        c.lo = lane & 7;
+        c.lo = state_lo(lane);
         c.active = !(s & w.shiftignore) && s < w.shiftend;
         const int first = jb.first, last = jb.last;
         const int ntile = (last - first + 8) >> 3;
@@ -610,22 +650,21 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         double mant = 1.0;
         int    expo = 0;
         bool   dead = false;
-        double2 rf_next = p.tq[first];
         RawSlots raw;
-        load_raw(p, c, first, first, last, &raw);
+        load_raw<0>(p, c, first, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 8;
             produce_tile<false>(p, c, tab, m0, last, raw);
-            if (t + 1 < ntile) load_raw(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
+            if (t + 1 < ntile) load_raw<0>(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = m0; m <= mend; m++) {
-                double e[8];
-                emission_from_row(tab + (m - m0) * TAB_STRIDE, c, e);
-                const double2 r = rf_next;
-                if (m < last) rf_next = p.tq[m + 1];
-                const int ml = m - first;
-                double*   sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
+                const double* row = tab + (m - m0) * TAB_STRIDE;
+                double        e[8];
+                emission_from_row(row, c, e);
+                const double2 r  = *(const double2*)(row + TAB_T);
+                const int     ml = m - first;
+                double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
                 if (!HALF || !(ml & 1)) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
@@ -671,138 +710,151 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         // Bsuf(m) the backward ones, val summed over paths of class d and states is
         //     exp(-factor) * Fpre_s(m) * Bsuf_s(m) * sum_g alphaminus_s(g) beta_s(g) e^{(d)}_s(g).
         // Scales are carried as mantissa * 2^exponent; Fpre is rebuilt from the stored reciprocals.
-        double b[8];
+        BwdState S;
 #pragma unroll
-        for (int j = 0; j < 8; j++) b[j] = 1.0;
-        double bmant = 1.0;
-        int    bexpo = 0;
-        bool   bdead = false;
-        double fmant = mant;          // becomes Fpre(m) after multiplying the reciprocals of k >= m
-        int    fexpo = expo;
+        for (int j = 0; j < 8; j++) S.b[j] = 1.0;
+        S.bmant = 1.0;
+        S.bexpo = 0;
+        S.bdead = false;
+        S.fmant = mant;          // becomes Fpre(m) after multiplying the reciprocals of k >= m
+        S.fexpo = expo;
         // exp(-factor) = xm * 2^xe
         const double nf  = -factor * 1.4426950408889634074;
         const double nfk = floor(nf);
         const double xm  = exp2(nf - nfk);
         const int    xe  = (int)nfk;
         const bool   chain_on = c.active && !skip && !dead && !(factor - fs > 40.0);   // cnF2freq.cpp:5420-5421
-        // software pipeline: the spill row, the reciprocals and the recombination fractions of the NEXT
-        // marker (m-1) are requested before the current marker is processed
-        double am_next[8], inv_next, inv_odd = 1.0;   // HALF: am_next / inv_next belong to the even marker of the pair
-        double2 r_next = make_double2(0.0, 0.0);
-        {
-            const int     mll = last - first;
-            const double* sp  = spill + (size_t)(HALF ? (mll >> 1) : mll) * ROW + lane;
+        // software pipeline: the spill row (and its reciprocals) is requested one row ahead, straight into
+        // the registers it is used from; nothing else in the marker loop is a vector memory operation
+        auto load_row = [&](int idx) {
+            const double* sp = spill + (size_t)idx * ROW + lane;
 #pragma unroll
-            for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
-            inv_next = sp[512 - lane + s];
-            if (HALF) inv_odd = sp[520 - lane + s];
-            if (last > first) r_next = p.tq[last - 1];
-        }
-        load_raw(p, c, first + (ntile - 1) * 8, first, last, &raw);
+            for (int j = 0; j < 8; j++) S.am[j] = sp[j * 64];
+            S.inv_even = sp[512 - lane + s];
+            if (HALF) S.inv_odd = sp[520 - lane + s];
+        };
+        S.inv_odd = 1.0;
+        load_row(HALF ? ((last - first) >> 1) : (last - first));
+
+        // One marker of the backward pass.  ODD (HALF only): the marker's alpha-minus is rebuilt from the
+        // row of its even neighbour.  LOADS: request the next spill row once this one has been used.
+        auto marker = [&](auto odd_tag, double* row, int m) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            const int      ml  = m - first;
+            double         e[8], wj[8];
+            emission_from_row(row, c, e);
+            const double2 r_m = *(const double2*)(row + TAB_T);     // gap m-1 -> m
+            double        inv_m;
+            if (ODD) {
+                // odd marker: alpha-minus(m) = T( alpha-minus(m-1) * e(m-1) * inv(m-1) ), exactly the
+                // forward step (cnF2freq.cpp:2238-2367); marker m-1 is the previous row of this tile
+                double ep[8];
+                emission_from_row(row - TAB_STRIDE, c, ep);
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] = S.am[j] * ep[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] *= S.inv_even;
+                transition_scaled(wj, r_m.x, r_m.y);
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] *= S.b[j];
+                inv_m = S.inv_odd;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] = S.am[j] * S.b[j];
+                inv_m = S.inv_even;
+                // the row is used up: request the one below it (clamped at the chromosome start, where the
+                // reload is harmless) so that a whole marker, or two, of arithmetic covers the latency.
+                // The empty asm pins "last use, then reload" in that order: otherwise the loads are hoisted
+                // above the products, land in fresh registers and are copied (and waited for) at once.
+                asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wj[4]), "+v"(wj[5]),
+                             "+v"(wj[6]), "+v"(wj[7]), "+v"(inv_m) : : "memory");
+                const int idx = HALF ? (ml >> 1) - 1 : ml - 1;
+                load_row(idx < 0 ? 0 : idx);
+            }
+            if (!HALF || !ODD || m == last) {     // skipped (odd) steps have normaliser 1
+                int ex;
+                S.fmant = frexp(S.fmant * inv_m, &ex);
+                S.fexpo += ex;
+            }
+            double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const int     ia = (0 << 5) | (f << 4) | (c.s1 << 3) | c.lo;
+                const double* Br = row + TAB_R + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                const double* B1 = row + TAB_2 + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                const double  cf = row[TAB_C + f * 2 + c.s0];
+                const double  av = cf * row[TAB_R + ia], a1 = cf * row[TAB_2 + ia];
+                double        sb = 0.0, sb1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    sb += wj[j] * Br[j];
+                    sb1 += wj[j] * B1[j];
+                }
+                n_tot += av * sb;
+                n_a1 += a1 * sb;
+                n_b1 += av * sb1;
+                n_2 += a1 * sb1;
+            }
+            const double scale = chain_on ? ldexp(xm * S.fmant * S.bmant, xe + S.fexpo + S.bexpo) : 0.0;
+            double q2 = scale * n_2;
+            double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
+            double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+            // sum over groups of 4 lanes, then 16 partials per class go to LDS (the class tables of
+            // this marker are dead by now); the tile epilogue finishes the sum over the wave
+            q0 += lane_xor1(q0);
+            q1 += lane_xor1(q1);
+            q2 += lane_xor1(q2);
+            q0 += lane_xor2(q0);
+            q1 += lane_xor2(q1);
+            q2 += lane_xor2(q2);
+            wave_lds_fence();
+            if ((lane & 3) == 0) {
+                double* red = row + TAB_R + (lane >> 2);
+                red[0]  = q0;
+                red[16] = q1;
+                red[32] = q2;
+            }
+            // beta(m-1) = T( beta(m) * e(m) ); at the first marker the result is never used
+#pragma unroll
+            for (int j = 0; j < 8; j++) S.b[j] *= e[j];
+            if (!HALF || !ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
+            transition_scaled(S.b, r_m.x, r_m.y);
+        };
+        using odd_t  = std::integral_constant<bool, true>;
+        using even_t = std::integral_constant<bool, false>;
+
+        load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
             produce_tile<true>(p, c, tab, m0, last, raw);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
-            for (int m = mend; m >= m0; m--) {
-                double*       row = tab + (m - m0) * TAB_STRIDE;
-                double        e[8];
-                emission_from_row(row, c, e);
-                double        wj[8];
-                const double2 r_m = r_next;
-                const int     ml  = m - first;
-                double        inv_m;
-                if (HALF && (ml & 1)) {
-                    // odd marker: alpha-minus(m) = T( alpha-minus(m-1) * e(m-1) * inv(m-1) ), exactly the
-                    // forward step (cnF2freq.cpp:2238-2367); marker m-1 is the previous row of this tile
-                    double ep[8];
-                    emission_from_row(row - TAB_STRIDE, c, ep);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wj[j] = am_next[j] * ep[j];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wj[j] *= inv_next;
-                    transition_scaled(wj, r_m.x, r_m.y);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wj[j] *= b[j];
-                    inv_m = inv_odd;
-                    if (m - 1 > first) r_next = p.tq[m - 2];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wj[j] = am_next[j] * b[j];
-                    inv_m = inv_next;
-                    if (m > first) {
-                        const int     mlp = ml - 1;
-                        const double* sp  = spill + (size_t)(HALF ? (mlp >> 1) : mlp) * ROW + lane;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) am_next[j] = sp[j * 64];
-                        inv_next = sp[512 - lane + s];
-                        if (HALF) inv_odd = sp[520 - lane + s];
-                        if (m - 1 > first) r_next = p.tq[m - 2];
-                    }
+            int       i    = mend - m0;                 // local index; its parity is the parity of m - first
+            if (HALF) {
+                if (!(i & 1)) {                         // an even top marker: only the last tile of a chromosome
+                    marker(even_t(), tab + i * TAB_STRIDE, m0 + i);
+                    i--;
                 }
-                if (!HALF || !(ml & 1) || m == last) {     // skipped (odd) steps have normaliser 1
-                    int ex;
-                    fmant = frexp(fmant * inv_m, &ex);
-                    fexpo += ex;
+                for (; i >= 1; i -= 2) {
+                    marker(odd_t(), tab + i * TAB_STRIDE, m0 + i);
+                    marker(even_t(), tab + (i - 1) * TAB_STRIDE, m0 + i - 1);
                 }
-                double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
-#pragma unroll
-                for (int f = 0; f < 2; f++) {
-                    const int     ia = (0 << 5) | (f << 4) | (c.s1 << 3) | c.lo;
-                    const double* Br = row + TAB_R + ((1 << 5) | (f << 4) | (c.s2 << 3));
-                    const double* B1 = row + TAB_2 + ((1 << 5) | (f << 4) | (c.s2 << 3));
-                    const double  cf = row[TAB_C + f * 2 + c.s0];
-                    const double  av = cf * row[TAB_R + ia], a1 = cf * row[TAB_2 + ia];
-                    double        sb = 0.0, sb1 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        sb += wj[j] * Br[j];
-                        sb1 += wj[j] * B1[j];
-                    }
-                    n_tot += av * sb;
-                    n_a1 += a1 * sb;
-                    n_b1 += av * sb1;
-                    n_2 += a1 * sb1;
-                }
-                const double scale = chain_on ? ldexp(xm * fmant * bmant, xe + fexpo + bexpo) : 0.0;
-                double q2 = scale * n_2;
-                double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
-                double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
-                // sum over groups of 4 lanes, then 16 partials per class go to LDS (the class tables of
-                // this marker are dead by now); the tile epilogue finishes the sum over the wave
-                q0 += lane_xor1(q0);
-                q1 += lane_xor1(q1);
-                q2 += lane_xor1(q2);
-                q0 += lane_xor2(q0);
-                q1 += lane_xor2(q1);
-                q2 += lane_xor2(q2);
-                wave_lds_fence();
-                if ((lane & 3) == 0) {
-                    double* red = row + TAB_R + (lane >> 2);
-                    red[0]  = q0;
-                    red[16] = q1;
-                    red[32] = q2;
-                }
-                if (m > first) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) b[j] *= e[j];
-                    if (!HALF || !(ml & 1)) scale_chain(b, &bmant, &bexpo, &bdead);
-                    transition_scaled(b, r_m.x, r_m.y);
-                }
+            } else {
+                for (; i >= 0; i--) marker(even_t(), tab + i * TAB_STRIDE, m0 + i);
             }
             wave_lds_fence();
             // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
             // whole marker loop costs more in registers than the extra latency it hides; measured)
-            if (t > 0) load_raw(p, c, m0 - 8, first, last, &raw);
+            if (t > 0) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
             // tile epilogue: lane mi < 8 finishes marker m0 + mi: 3 x 16 partials, normalise, store
             if (lane < 8 && m0 + lane <= last) {
                 const double* red = tab + lane * TAB_STRIDE + TAB_R;
                 double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    d0 += red[i];
-                    d1 += red[16 + i];
-                    d2 += red[32 + i];
+                for (int i2 = 0; i2 < 16; i2++) {
+                    d0 += red[i2];
+                    d1 += red[16 + i2];
+                    d2 += red[32 + i2];
                 }
                 if (!(p.flags & KP_RAW_DOSAGE)) {
                     const double tsum = d0 + d1 + d2;
@@ -856,7 +908,7 @@ __global__ __launch_bounds__(64) void emission_kernel(KernelParams p, int ind, i
     c.s0 = s & 1;
     c.s1 = (s >> 1) & 1;
     c.s2 = (s >> 2) & 1;
-    c.lo = lane & 7;
+    c.lo = state_lo(lane);
     c.active = true;
     c.n_combo = 1;
     const Slot root = load_slot(p, c.row_root, marker);
