@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this process's CPU share)")
     ap.add_argument("--full-spill", action="store_true", help="A/B: store alpha-minus at every marker (CNF2_FULL_SPILL)")
+    ap.add_argument("--extra-flags", type=int, default=0,
+                    help="tuning aid: OR into the sweep flags (2 = CNF2_NO_DOSAGE, forward pass only); not the metric")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each step's gather before the next sweep (default: the gather of step k runs "
@@ -254,7 +256,7 @@ def main():
         drain(i)                             # the gather that last read this buffer must be done
         ll_i, dos_i = logliks[i], dosages[i]
         ctx.sweep_device(0, n, factors.data_ptr(), ll_i.data_ptr(), dos_i.data_ptr(),
-                         capi.FULL_SPILL if args.full_spill else 0)
+                         (capi.FULL_SPILL if args.full_spill else 0) | args.extra_flags)
         ctx.sync()
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:

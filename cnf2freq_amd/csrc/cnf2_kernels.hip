@@ -55,15 +55,21 @@ __device__ __forceinline__ double lane_xor4(double v) { return swizzle_xor<4>(v)
 // State bit 2 does not have to live in lane bit 2.  With lane(lo) = b0 ^ 2 b1 ^ 7 b2 (an invertible
 // GF(2) map of the three low state bits) flipping b2 is "lane i <-> lane 7-i" inside each group of 8 =
 // DPP row_half_mirror, a plain VALU move like the two quad_perm stages: no trip through the LDS pipe.
-#ifndef CNF2_MIRROR_BIT2
-#define CNF2_MIRROR_BIT2 1
+// CNF2_XCHG (A/B timing): 0 = all three lane stages on DPP; 1 = bit 2, 2 = bits 1 and 2 through the LDS
+// crossbar (ds_swizzle: fewer VALU slots, longer latency).
+#ifndef CNF2_XCHG
+#define CNF2_XCHG 0
 #endif
-#if CNF2_MIRROR_BIT2
+__device__ __forceinline__ int state_lo(int lane) { return (lane & 7) ^ ((lane & 4) ? 3 : 0); }
+#if CNF2_XCHG == 0
+__device__ __forceinline__ double lane_flip_b1(double v) { return lane_xor2(v); }
 __device__ __forceinline__ double lane_flip_b2(double v) { return dpp_mov_all<0x141>(v); }
-__device__ __forceinline__ int    state_lo(int lane) { return (lane & 7) ^ ((lane & 4) ? 3 : 0); }
+#elif CNF2_XCHG == 1
+__device__ __forceinline__ double lane_flip_b1(double v) { return lane_xor2(v); }
+__device__ __forceinline__ double lane_flip_b2(double v) { return swizzle_xor<7>(v); }
 #else
-__device__ __forceinline__ double lane_flip_b2(double v) { return lane_xor4(v); }
-__device__ __forceinline__ int    state_lo(int lane) { return lane & 7; }
+__device__ __forceinline__ double lane_flip_b1(double v) { return swizzle_xor<2>(v); }
+__device__ __forceinline__ double lane_flip_b2(double v) { return swizzle_xor<7>(v); }
 #endif
 __device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128>(v); } // row_ror:8
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
@@ -111,12 +117,12 @@ __device__ __forceinline__ void transition(double (&a)[8], double r0, double r1)
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = k1 * a[j] + r1 * q[j];
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = lane_xor2(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_flip_b1(a[j]);
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = k0 * a[j] + r0 * q[j];
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = lane_flip_b2(a[j]);
-#if !CNF2_MIRROR_BIT2
+#if CNF2_XCHG >= 1
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -156,12 +162,12 @@ __device__ __forceinline__ void transition_scaled(double (&a)[8], double t0, dou
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = fma(t1, q[j], a[j]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = lane_xor2(a[j]);
+    for (int j = 0; j < 8; j++) q[j] = lane_flip_b1(a[j]);
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = fma(t0, q[j], a[j]);
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = lane_flip_b2(a[j]);
-#if !CNF2_MIRROR_BIT2
+#if CNF2_XCHG >= 1
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -654,8 +660,13 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         load_raw<0>(p, c, first, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 8;
-            produce_tile<false>(p, c, tab, m0, last, raw);
-            if (t + 1 < ntile) load_raw<0>(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
+#ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
+            if (t == 0)
+#endif
+            {
+                produce_tile<false>(p, c, tab, m0, last, raw);
+                if (t + 1 < ntile) load_raw<0>(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
+            }
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             for (int m = m0; m <= mend; m++) {
@@ -665,10 +676,12 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 const double2 r  = *(const double2*)(row + TAB_T);
                 const int     ml = m - first;
                 double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
+#ifndef CNF2_X_NOSTORE   /* timing ablation only: results are wrong */
                 if (!HALF || !(ml & 1)) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
                 }
+#endif
 #pragma unroll
                 for (int j = 0; j < 8; j++) a[j] *= e[j];
                 // HALF: the vector is rescaled at every second marker only (and at the last one, where the
@@ -728,6 +741,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         // the registers it is used from; nothing else in the marker loop is a vector memory operation
         auto load_row = [&](int idx) {
             const double* sp = spill + (size_t)idx * ROW + lane;
+#ifdef CNF2_X_NOLOAD     /* timing ablation only: results are wrong */
+            if (idx >= 0) return;
+#endif
 #pragma unroll
             for (int j = 0; j < 8; j++) S.am[j] = sp[j * 64];
             S.inv_even = sp[512 - lane + s];
@@ -752,8 +768,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 emission_from_row(row - TAB_STRIDE, c, ep);
 #pragma unroll
                 for (int j = 0; j < 8; j++) wj[j] = S.am[j] * ep[j];
-#pragma unroll
-                for (int j = 0; j < 8; j++) wj[j] *= S.inv_even;
+                // the normaliser inv(m-1) is a per-chain scalar and everything below is linear in wj:
+                // it is applied to the three class sums (`scale`) instead of to the eight states
                 transition_scaled(wj, r_m.x, r_m.y);
 #pragma unroll
                 for (int j = 0; j < 8; j++) wj[j] *= S.b[j];
@@ -795,25 +811,17 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 n_b1 += av * sb1;
                 n_2 += a1 * sb1;
             }
-            const double scale = chain_on ? ldexp(xm * S.fmant * S.bmant, xe + S.fexpo + S.bexpo) : 0.0;
+            const double sc0   = ODD ? xm * S.inv_even : xm;
+            const double scale = chain_on ? ldexp(sc0 * S.fmant * S.bmant, xe + S.fexpo + S.bexpo) : 0.0;
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
-            // sum over groups of 4 lanes, then 16 partials per class go to LDS (the class tables of
-            // this marker are dead by now); the tile epilogue finishes the sum over the wave
-            q0 += lane_xor1(q0);
-            q1 += lane_xor1(q1);
-            q2 += lane_xor1(q2);
-            q0 += lane_xor2(q0);
-            q1 += lane_xor2(q1);
-            q2 += lane_xor2(q2);
+            // every lane parks its three class partials in this marker's row (all of it is dead by now:
+            // tables, root weights and gap factors have been read); the tile epilogue sums them
             wave_lds_fence();
-            if ((lane & 3) == 0) {
-                double* red = row + TAB_R + (lane >> 2);
-                red[0]  = q0;
-                red[16] = q1;
-                red[32] = q2;
-            }
+            row[lane]       = q0;
+            row[64 + lane]  = q1;
+            row[128 + lane] = q2;
             // beta(m-1) = T( beta(m) * e(m) ); at the first marker the result is never used
 #pragma unroll
             for (int j = 0; j < 8; j++) S.b[j] *= e[j];
@@ -826,6 +834,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
+#ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
+            if (t == ntile - 1)
+#endif
             produce_tile<true>(p, c, tab, m0, last, raw);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
@@ -845,28 +856,37 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             wave_lds_fence();
             // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
             // whole marker loop costs more in registers than the extra latency it hides; measured)
+#ifndef CNF2_X_NOPRODUCE
             if (t > 0) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
-            // tile epilogue: lane mi < 8 finishes marker m0 + mi: 3 x 16 partials, normalise, store
-            if (lane < 8 && m0 + lane <= last) {
-                const double* red = tab + lane * TAB_STRIDE + TAB_R;
+#endif
+            // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
+            // of the tile's markers, lane sub == 0 normalises and stores the row
+            {
+                const int     mi2 = lane >> 3, sub = lane & 7;
+                const double* red = tab + mi2 * TAB_STRIDE + sub * 8;
                 double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
-                for (int i2 = 0; i2 < 16; i2++) {
+                for (int i2 = 0; i2 < 8; i2++) {
                     d0 += red[i2];
-                    d1 += red[16 + i2];
-                    d2 += red[32 + i2];
+                    d1 += red[64 + i2];
+                    d2 += red[128 + i2];
                 }
-                if (!(p.flags & KP_RAW_DOSAGE)) {
-                    const double tsum = d0 + d1 + d2;
-                    const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
-                    d0 *= inv;
-                    d1 *= inv;
-                    d2 *= inv;
+                d0 = chain_sum(d0);
+                d1 = chain_sum(d1);
+                d2 = chain_sum(d2);
+                if (sub == 0 && m0 + mi2 <= last) {
+                    if (!(p.flags & KP_RAW_DOSAGE)) {
+                        const double tsum = d0 + d1 + d2;
+                        const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
+                        d0 *= inv;
+                        d1 *= inv;
+                        d2 *= inv;
+                    }
+                    double* out = p.dosage + ((size_t)jb.ind * p.n_markers + (m0 + mi2)) * 3;
+                    out[0] = d0;
+                    out[1] = d1;
+                    out[2] = d2;
                 }
-                double* out = p.dosage + ((size_t)jb.ind * p.n_markers + (m0 + lane)) * 3;
-                out[0] = d0;
-                out[1] = d1;
-                out[2] = d2;
             }
             wave_lds_fence();
         }
