@@ -311,6 +311,24 @@ __device__ __forceinline__ double scale_chain(double (&v)[8], double* mant, int*
     return sum;
 }
 
+// Same bookkeeping, but the vector is left as it is: returns the reciprocal for the caller to fold into
+// the next emission product (it is a per-chain scalar and every step is linear), which takes the
+// reduction -> reciprocal chain off the critical path and saves six of the eight multiplies.
+__device__ __forceinline__ double chain_normaliser(const double (&v)[8], double* mant, int* expo, bool* dead)
+{
+    double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    sum        = chain_sum(sum);
+    const bool   ok  = sum > 0.0;
+    const double ss  = ok ? sum : 1.0;
+    const double inv = fast_rcp(ss);
+    if (!ok) *dead = true;
+    int    ex;
+    double mm = frexp(*mant * ss, &ex);
+    *mant     = mm;
+    *expo += ex;
+    return inv;
+}
+
 template <bool DEBUG_STORE>
 __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 {
@@ -594,10 +612,10 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
     }
 }
 
-__device__ __forceinline__ void emission_from_row(const double* row, const FastCtx& c, double (&e)[8])
+__device__ __forceinline__ void emission_from_row(const double* row, const FastCtx& c, double (&e)[8], double k = 1.0)
 {
-    const double cA0 = row[TAB_C + 0 + c.s0] * row[(0 << 5) | (0 << 4) | (c.s1 << 3) | c.lo];
-    const double cA1 = row[TAB_C + 2 + c.s0] * row[(0 << 5) | (1 << 4) | (c.s1 << 3) | c.lo];
+    const double cA0 = row[TAB_C + 0 + c.s0] * row[(0 << 5) | (0 << 4) | (c.s1 << 3) | c.lo] * k;
+    const double cA1 = row[TAB_C + 2 + c.s0] * row[(0 << 5) | (1 << 4) | (c.s1 << 3) | c.lo] * k;
     const double* B0 = row + ((1 << 5) | (0 << 4) | (c.s2 << 3));
     const double* B1 = row + ((1 << 5) | (1 << 4) | (c.s2 << 3));
 #pragma unroll
@@ -649,6 +667,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         const int first = jb.first, last = jb.last;
         const int ntile = (last - first + 8) >> 3;
 
+        using odd_t  = std::integral_constant<bool, true>;
+        using even_t = std::integral_constant<bool, false>;
+
         // ---------------------------------------------------------------- forward
         double a[8];
 #pragma unroll
@@ -656,6 +677,41 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         double mant = 1.0;
         int    expo = 0;
         bool   dead = false;
+        double pend = 1.0;     // reciprocal normaliser not yet applied to a[] (folded into the next emission)
+        // One marker of the forward pass.  ODD (HALF only): nothing is spilled and, except at the last
+        // marker of the chromosome, nothing is rescaled: two emission products in a row cannot underflow a
+        // double.  A skipped step has normaliser 1 (the reference rescales at every marker,
+        // cnF2freq.cpp:1664-1668; only the bookkeeping of the scale differs, not the normalised values).
+        auto fwd_step = [&](auto odd_tag, const double* row, int m) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            double         e[8];
+            emission_from_row(row, c, e, pend);
+            const double2 r  = *(const double2*)(row + TAB_T);
+            const int     ml = m - first;
+            double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
+            if (!ODD) {
+#ifndef CNF2_X_NOSTORE   /* timing ablation only: results are wrong */
+#pragma unroll
+                for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+#endif
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] *= e[j];
+            pend = 1.0;
+            if (!ODD || m == last) {
+                // reciprocal of this step's normaliser, per chain: stored so that the backward pass can
+                // rebuild the forward scale before each marker without a reduction (and redo the forward step)
+                double inv;
+                if (HALF) {
+                    inv  = chain_normaliser(a, &mant, &expo, &dead);
+                    pend = inv;
+                } else {
+                    scale_chain(a, &mant, &expo, &dead, &inv);     // full spill: the stored rows are normalised at once
+                }
+                if (c.lo == 0) sp[512 - lane + (ODD ? 8 : 0) + s] = inv;
+            }
+            if (m < last) transition_scaled(a, r.x, r.y);
+        };
         RawSlots raw;
         load_raw<0>(p, c, first, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
@@ -669,35 +725,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             }
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
-            for (int m = m0; m <= mend; m++) {
-                const double* row = tab + (m - m0) * TAB_STRIDE;
-                double        e[8];
-                emission_from_row(row, c, e);
-                const double2 r  = *(const double2*)(row + TAB_T);
-                const int     ml = m - first;
-                double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
-#ifndef CNF2_X_NOSTORE   /* timing ablation only: results are wrong */
-                if (!HALF || !(ml & 1)) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+            if (HALF) {
+                const int itop = mend - m0;
+                for (int i = 0; i <= itop; i += 2) {
+                    fwd_step(even_t(), tab + i * TAB_STRIDE, m0 + i);
+                    if (i < itop) fwd_step(odd_t(), tab + (i + 1) * TAB_STRIDE, m0 + i + 1);
                 }
-#endif
-#pragma unroll
-                for (int j = 0; j < 8; j++) a[j] *= e[j];
-                // HALF: the vector is rescaled at every second marker only (and at the last one, where the
-                // likelihood is read off); two emission products in a row cannot underflow a double.  A
-                // skipped step has normaliser 1 (the reference rescales at every marker, cnF2freq.cpp:1664-1668;
-                // only the bookkeeping of the scale differs, not the normalised values it is divided out of)
-                double inv = 1.0;
-                if (!HALF || !(ml & 1) || m == last) scale_chain(a, &mant, &expo, &dead, &inv);
-                // reciprocal of this step's normaliser, per chain: lets the backward pass rebuild the
-                // forward scale before each marker without a reduction (and redo the forward step)
-                if (HALF) {
-                    // odd markers are not rescaled: only the last marker of an even-length chromosome has
-                    // a reciprocal worth storing in the odd slot
-                    if (c.lo == 0 && (!(ml & 1) || m == last)) sp[512 - lane + ((ml & 1) ? 8 : 0) + s] = inv;
-                } else if (c.lo == 0) sp[512 - lane + s] = inv;
-                if (m < last) transition_scaled(a, r.x, r.y);
+            } else {
+                for (int m = m0; m <= mend; m++) fwd_step(even_t(), tab + (m - m0) * TAB_STRIDE, m);
             }
             wave_lds_fence();
         }
@@ -757,8 +792,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         auto marker = [&](auto odd_tag, double* row, int m) {
             constexpr bool ODD = decltype(odd_tag)::value;
             const int      ml  = m - first;
-            double         e[8], wj[8];
-            emission_from_row(row, c, e);
+            double         wj[8];
             const double2 r_m = *(const double2*)(row + TAB_T);     // gap m-1 -> m
             double        inv_m;
             if (ODD) {
@@ -816,6 +850,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+            // this marker's own emission is only needed for the beta step: formed here, after the sums, so
+            // that it does not occupy registers across them
+            double e[8];
+            emission_from_row(row, c, e);
             // every lane parks its three class partials in this marker's row (all of it is dead by now:
             // tables, root weights and gap factors have been read); the tile epilogue sums them
             wave_lds_fence();
@@ -825,12 +863,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // beta(m-1) = T( beta(m) * e(m) ); at the first marker the result is never used
 #pragma unroll
             for (int j = 0; j < 8; j++) S.b[j] *= e[j];
+            // (deferring this normaliser like the forward one was measured slower here: the row scale and the
+            // emission of the next step would both wait for the reciprocal)
             if (!HALF || !ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
             transition_scaled(S.b, r_m.x, r_m.y);
         };
-        using odd_t  = std::integral_constant<bool, true>;
-        using even_t = std::integral_constant<bool, false>;
-
         load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
