@@ -538,7 +538,6 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 // LDS per wave: 8 markers x TAB_STRIDE doubles: [0,64) tot, [64,68) root weights c[f][s0],
 // and for the backward pass [72,136) restricted totals, [136,200) class-2 parts.
 // =====================================================================================
-#define SPILL_ROW 520    /* doubles per marker in the spill: 8 x 64 alpha-minus + 8 chain reciprocals */
 #define TAB_STRIDE 202   /* doubles per marker row: 16-B aligned rows, conflict-free producer stores */
 #define TAB_C 64
 #define TAB_T 68     /* double2: r/(1-r) of the gap carried by this row */
@@ -640,7 +639,10 @@ struct BwdState {
 template <bool HALF>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
-    constexpr int ROW = HALF ? 528 : SPILL_ROW;   // doubles per spill row: 512 alpha-minus + reciprocals (8, or 8 + 8 for the pair)
+    // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
+    // per lane and k), then [chain][2] = reciprocal normaliser of the (even) marker and, HALF only, of
+    // an odd last marker.
+    constexpr int ROW = 528;
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
 
     const int lane  = threadIdx.x & 63;
@@ -688,11 +690,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             emission_from_row(row, c, e, pend);
             const double2 r  = *(const double2*)(row + TAB_T);
             const int     ml = m - first;
-            double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW + lane;
+            double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW;
             if (!ODD) {
 #ifndef CNF2_X_NOSTORE   /* timing ablation only: results are wrong */
 #pragma unroll
-                for (int j = 0; j < 8; j++) sp[j * 64] = a[j];
+                for (int k = 0; k < 4; k++) *(double2*)(sp + k * 128 + lane * 2) = make_double2(a[2 * k], a[2 * k + 1]);
 #endif
             }
 #pragma unroll
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 } else {
                     scale_chain(a, &mant, &expo, &dead, &inv);     // full spill: the stored rows are normalised at once
                 }
-                if (c.lo == 0) sp[512 - lane + (ODD ? 8 : 0) + s] = inv;
+                if (c.lo == 0) sp[512 + 2 * s + (ODD ? 1 : 0)] = inv;
             }
             if (m < last) transition_scaled(a, r.x, r.y);
         };
@@ -775,14 +777,19 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         // software pipeline: the spill row (and its reciprocals) is requested one row ahead, straight into
         // the registers it is used from; nothing else in the marker loop is a vector memory operation
         auto load_row = [&](int idx) {
-            const double* sp = spill + (size_t)idx * ROW + lane;
+            const double* sp = spill + (size_t)idx * ROW;
 #ifdef CNF2_X_NOLOAD     /* timing ablation only: results are wrong */
             if (idx >= 0) return;
 #endif
 #pragma unroll
-            for (int j = 0; j < 8; j++) S.am[j] = sp[j * 64];
-            S.inv_even = sp[512 - lane + s];
-            if (HALF) S.inv_odd = sp[520 - lane + s];
+            for (int k = 0; k < 4; k++) {
+                const double2 v = *(const double2*)(sp + k * 128 + lane * 2);
+                S.am[2 * k]     = v.x;
+                S.am[2 * k + 1] = v.y;
+            }
+            const double2 iv = *(const double2*)(sp + 512 + 2 * s);
+            S.inv_even       = iv.x;
+            S.inv_odd        = iv.y;
         };
         S.inv_odd = 1.0;
         load_row(HALF ? ((last - first) >> 1) : (last - first));
