@@ -915,9 +915,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                     d1 += red[64 + i2];
                     d2 += red[128 + i2];
                 }
-                d0 = chain_sum(d0);
-                d1 = chain_sum(d1);
-                d2 = chain_sum(d2);
+                // class 0 and 1 are formed by inclusion-exclusion of non-negative sums: a true zero can come
+                // out as -1e-16; the reference adds non-negative terms (cnF2freq.cpp:3536), so clamp
+                d0 = fmax(chain_sum(d0), 0.0);
+                d1 = fmax(chain_sum(d1), 0.0);
+                d2 = fmax(chain_sum(d2), 0.0);
                 if (sub == 0 && m0 + mi2 <= last) {
                     if (!(p.flags & KP_RAW_DOSAGE)) {
                         const double tsum = d0 + d1 + d2;
