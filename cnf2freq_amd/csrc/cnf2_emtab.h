@@ -55,64 +55,65 @@ CNF2_HD void match_affine(int inmv, int mf, double sf, double* Bv, double* K, do
     *C  = (!miss && bound) ? effms : 0.0;
 }
 
-// Grandparent (top of a line) as seen with incoming allele v:  per allele index fg the pair
-// (t0, t1) with value = sum_fg w(fg ^ bit) * (t0[fg] + sv * t1[fg]).
+// Grandparent (top of a line) as seen with incoming allele v.  Per allele index fg the products
+//     p0[fg][bit] = w(fg ^ bit) * t0[fg],   p1[fg][bit] = w(fg ^ bit) * t1[fg]
+// so that the leaf's value for state bit `bit` and incoming odds sv is sum_fg (p0 + sv * p1), with the
+// restrictions applied as 0/1 factors on the fg terms (no selects in the combination):
+//     m1  = 0 if the slot is restricted to allele index 0 (flag2ignore), else 1      -> kinds 1, 2: fg = 1 term
+//     i2[fg] = 1 if allele fg is 2 (class of the line), else 0                        -> kind 2
+// A missing grandparent (recursetrackpossible on a null parent: 1 + secondval, cnF2freq.cpp:1043-1046) is the
+// same form with t0 = t1 = (1, 0) and both weights 1; its class flag is the parent's allele (the parent is
+// then the top of the traced line, cnF2freq.cpp:1260-1268).
 struct Leaf {
-    double t0[2], t1[2];
-    bool   is2[2];    // allele fg of this ancestor is 2 (class of the line)
-    double w[2];      // phase weight for phase 0 / 1
-    bool   present;
-    bool   restrict0;
+    double p0[2][2], p1[2][2];
+    double m1, i2[2];
 };
 
-CNF2_HD void leaf_prepare(const Slot& d, uint32_t flags, Leaf* L)
+CNF2_HD void leaf_make(const Slot& d, uint32_t flags, int v, bool parent_is2, Leaf* L)
 {
-    L->present   = (flags & SLOT_PRESENT) != 0;
-    L->restrict0 = (flags & SLOT_RESTRICT0) != 0;
-    L->w[0] = phase_weight(d, 0);
-    L->w[1] = phase_weight(d, 1);
-    L->is2[0] = d.a0 == 2;
-    L->is2[1] = d.a1 == 2;
-}
-
-CNF2_HD void leaf_match(const Slot& d, int v, Leaf* L)
-{
+    const bool present = (flags & SLOT_PRESENT) != 0;
+    const bool r0      = (flags & SLOT_RESTRICT0) != 0;
+    const double w0 = present ? phase_weight(d, 0) : 1.0;
+    const double w1 = present ? phase_weight(d, 1) : 1.0;
+    double t0[2], t1[2];
 #pragma unroll
     for (int fg = 0; fg < 2; fg++) {
         double Bv, K, C;
         int    mv;
         match_affine(v, fg ? d.a1 : d.a0, fg ? d.s1 : d.s0, &Bv, &K, &C, &mv);
-        L->t0[fg] = Bv + C;
-        L->t1[fg] = K;
+        const double miss = fg ? 0.0 : 1.0;
+        t0[fg] = present ? Bv + C : miss;
+        t1[fg] = present ? K : miss;
     }
+    L->p0[0][0] = w0 * t0[0];      // fg = 0, bit 0 -> weight of phase 0
+    L->p0[0][1] = w1 * t0[0];
+    L->p0[1][0] = w1 * t0[1];      // fg = 1, bit 0 -> phase 1
+    L->p0[1][1] = w0 * t0[1];
+    L->p1[0][0] = w0 * t1[0];
+    L->p1[0][1] = w1 * t1[0];
+    L->p1[1][0] = w1 * t1[1];
+    L->p1[1][1] = w0 * t1[1];
+    L->m1    = (present && r0) ? 0.0 : 1.0;
+    L->i2[0] = (present ? d.a0 == 2 : parent_is2) ? 1.0 : 0.0;
+    L->i2[1] = (present && d.a1 == 2 && !r0) ? 1.0 : 0.0;
 }
 
-// (V0, V1) of the leaf for state bit `bit`; kind 0 = all alleles, 1 = restricted, 2 = class-2 part
-// of restricted.  parent_is2: used when the grandparent is missing and the parent is the top of
-// the traced line (cnF2freq.cpp:1260-1268).
-CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, bool parent_is2, double* v0, double* v1)
+// (V0, V1) of the leaf for state bit `bit`; kind 0 = all alleles, 1 = restricted, 2 = class-2 part of restricted
+CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1)
 {
-    if (!L.present) {                      // recursetrackpossible on a null parent: 1 + secondval
-        const double z = (kind == 2 && !parent_is2) ? 0.0 : 1.0;
-        *v0 = z;
-        *v1 = z;
-        return;
+    if (kind == 0) {
+        *v0 = L.p0[0][bit] + L.p0[1][bit];
+        *v1 = L.p1[0][bit] + L.p1[1][bit];
+    } else if (kind == 1) {
+        *v0 = L.p0[0][bit] + L.m1 * L.p0[1][bit];
+        *v1 = L.p1[0][bit] + L.m1 * L.p1[1][bit];
+    } else {
+        *v0 = L.i2[0] * L.p0[0][bit] + L.i2[1] * L.p0[1][bit];
+        *v1 = L.i2[0] * L.p1[0][bit] + L.i2[1] * L.p1[1][bit];
     }
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int fg = 0; fg < 2; fg++) {
-        bool ok = true;
-        if (kind >= 1 && L.restrict0 && fg == 1) ok = false;
-        if (kind == 2 && !L.is2[fg]) ok = false;
-        const double w = ok ? L.w[fg ^ bit] : 0.0;
-        a0 += w * L.t0[fg];
-        a1 += w * L.t1[fg];
-    }
-    *v0 = a0;
-    *v1 = a1;
 }
 
-// The 8 entries of one lane.  Output index e = sp*4 + bit_a + 2*bit_b.
+// The 8 entries of one lane.  Output index e = sp*4 + bit_ot*2 + bit_tr (see part_entry_index).
 // tot: unrestricted (forward/backward recursion); rtot/two only if CLASSES.
 // cw[s0] = root weight c_f(s0) (written by every lane; identical across parts with equal f).
 template <bool CLASSES>
@@ -210,19 +211,18 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
     Leaf Ltr[2], Lot[2];     // per parent allele fp
 #pragma unroll
     for (int fp = 0; fp < 2; fp++) {
-        leaf_prepare(trs, c.tr, &Ltr[fp]);
-        leaf_prepare(ots, c.ot, &Lot[fp]);
-        leaf_match(trs, vtr[fp], &Ltr[fp]);
-        leaf_match(ots, vot[fp], &Lot[fp]);
+        leaf_make(trs, c.tr, vtr[fp], pis2[fp], &Ltr[fp]);
+        leaf_make(ots, c.ot, vot[fp], false, &Lot[fp]);
     }
-    double wl[2][2];         // [sp][fp]: parent phase weight, zeroed where !baseval (cnF2freq.cpp:1271)
-#pragma unroll
-    for (int sp = 0; sp < 2; sp++)
-#pragma unroll
-        for (int fp = 0; fp < 2; fp++) {
-            const double w = c.firstpar ? pw[(fp ^ sp) ^ 1] : pw[fp ^ sp];   // no dynamic register indexing
-            wl[sp][fp] = (bzero[fp] || w == 0.0) ? 0.0 : w;
-        }
+    // parent phase weight of allele fp under shift bit sp: pw[fp ^ sp ^ firstpar], zeroed where !baseval
+    // (cnF2freq.cpp:1271); wq folds firstpar so that the index below is static
+    const double wq0 = c.firstpar ? pw[1] : pw[0], wq1 = c.firstpar ? pw[0] : pw[1];
+    double wl[2][2];         // [sp][fp]
+    wl[0][0] = (bzero[0] || wq0 == 0.0) ? 0.0 : wq0;
+    wl[0][1] = (bzero[1] || wq1 == 0.0) ? 0.0 : wq1;
+    wl[1][0] = (bzero[0] || wq1 == 0.0) ? 0.0 : wq1;
+    wl[1][1] = (bzero[1] || wq0 == 0.0) ? 0.0 : wq0;
+    const double pm1 = par_r0 ? 0.0 : 1.0;     // the parent's own restriction: kinds 1, 2 drop fp = 1
     const int KINDS = CLASSES ? 3 : 1;
     // one kind at a time (0 tot, 1 restricted, 2 class-2 part): keeps few values live
 #pragma unroll
@@ -234,9 +234,9 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
 #pragma unroll
             for (int bit = 0; bit < 2; bit++) {
                 double t0, t1, o0, o1;
-                leaf_value(Ltr[fp], bit, kind, pis2[fp], &t0, &t1);
+                leaf_value(Ltr[fp], bit, kind, &t0, &t1);
                 // the other line never carries the class: kinds 1 and 2 use its restricted total
-                leaf_value(Lot[fp], bit, kind == 2 ? 1 : kind, false, &o0, &o1);
+                leaf_value(Lot[fp], bit, kind == 2 ? 1 : kind, &o0, &o1);
                 G[bit]  = alpha[fp] * t0 + beta[fp] * t1;
                 OO[bit] = (1.0 - so_p[fp]) * o0 + so_p[fp] * o1;
             }
@@ -246,19 +246,17 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
                 for (int bt = 0; bt < 2; bt++) H[fp][bo][bt] = OO[bo] * G[bt];
         }
         double* out = kind == 0 ? tot : (kind == 1 ? rtot : two);
+        // Output order: e = sp*4 + bit_ot*2 + bit_tr (the caller maps it to the table index: the traced
+        // grandparent is pars[firstpar], so (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr) : (bit_tr, bit_ot))
 #pragma unroll
-        for (int sp = 0; sp < 2; sp++)
+        for (int sp = 0; sp < 2; sp++) {
+            const double w1 = kind >= 1 ? pm1 * wl[sp][1] : wl[sp][1];
 #pragma unroll
-            for (int bb = 0; bb < 2; bb++)
+            for (int bo = 0; bo < 2; bo++)
 #pragma unroll
-                for (int ba = 0; ba < 2; ba++) {
-                    // traced grandparent = pars[firstpar]: (bit_ot, bit_tr) = firstpar ? (ba, bb) : (bb, ba);
-                    // selects between statically indexed registers (no dynamic indexing => no scratch)
-                    const double h0 = c.firstpar ? H[0][ba][bb] : H[0][bb][ba];
-                    const double h1 = c.firstpar ? H[1][ba][bb] : H[1][bb][ba];
-                    const double w1 = (kind >= 1 && par_r0) ? 0.0 : wl[sp][1];
-                    out[sp * 4 + ba + 2 * bb] = wl[sp][0] * h0 + w1 * h1;
-                }
+                for (int bt = 0; bt < 2; bt++)
+                    out[sp * 4 + bo * 2 + bt] = wl[sp][0] * H[0][bo][bt] + w1 * H[1][bo][bt];
+        }
     }
 }
 
@@ -281,11 +279,13 @@ CNF2_HD void make_part(const Window& w, int part, PartCfg* c, int32_t* row_par, 
     *row_ot  = w.row[slot_ot] < 0 ? 0 : w.row[slot_ot];
 }
 
-// table index of entry e (= sp*4 + bit_a + 2*bit_b) of a part
+// table index of entry e (= sp*4 + bit_ot*2 + bit_tr) of a part: (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr)
+// : (bit_tr, bit_ot), k = firstpar | bit_a << 1 | bit_b << 2
 CNF2_HD int part_entry_index(int part, int e)
 {
     const int P = part >> 2, f = (part >> 1) & 1, firstpar = part & 1;
-    const int sp = e >> 2, ba = e & 1, bb = (e >> 1) & 1;
+    const int sp = e >> 2, bo = (e >> 1) & 1, bt = e & 1;
+    const int ba = firstpar ? bo : bt, bb = firstpar ? bt : bo;
     return (P << 5) | (f << 4) | (sp << 3) | (firstpar | (ba << 1) | (bb << 2));
 }
 

@@ -494,9 +494,10 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
                 n_b1  = chain_sum(n_b1);
                 n_2   = chain_sum(n_2);
                 const double scale = (D > 0.0) ? ws / D : 0.0;
-                double d2 = across_chains_sum(scale * n_2);
-                double d1 = across_chains_sum(scale * (n_a1 + n_b1 - 2.0 * n_2));
-                double d0 = across_chains_sum(scale * (n_tot - n_a1 - n_b1 + n_2));
+                // (inclusion-exclusion of non-negative sums: a true zero can come out as -1e-16; clamp)
+                double d2 = fmax(across_chains_sum(scale * n_2), 0.0);
+                double d1 = fmax(across_chains_sum(scale * (n_a1 + n_b1 - 2.0 * n_2)), 0.0);
+                double d0 = fmax(across_chains_sum(scale * (n_tot - n_a1 - n_b1 + n_2)), 0.0);
                 if (lane == 0) {
                     if (!(p.flags & KP_RAW_DOSAGE)) {
                         double tsum = d0 + d1 + d2;
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 struct FastCtx {
     PartCfg pc;
     int     part, mi;
+    int     idx_base, idx_k01, idx_k10;   // where this lane's entries go in a table row (produce_tile)
     int32_t row_root, row_par, row_tr, row_ot;
     int     s0, s1, s2, lo;
     bool    active;
@@ -592,13 +594,26 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
         double tot[8], rtot[8], two[8], cw[2];
         emtab_part<CLASSES>(c.pc, root, par, tr, ot, tot, rtot, two, cw);
         double* row = tab + c.mi * TAB_STRIDE;
+        // entry e = sp*4 + bit_ot*2 + bit_tr goes to table index base + sp*8 + k: k = firstpar | 6 bit for the
+        // two diagonal entries, and the two off-diagonal ones swap places with firstpar (part_entry_index);
+        // the two lane-dependent offsets are per-job constants, so no value is ever selected
+        double* rb = row + c.idx_base;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int idx = part_entry_index(c.part, e);
-            row[idx] = tot[e];
+        for (int sp = 0; sp < 2; sp++) {
+            double* r8 = rb + sp * 8;
+            r8[0]         = tot[sp * 4 + 0];
+            r8[c.idx_k01] = tot[sp * 4 + 1];
+            r8[c.idx_k10] = tot[sp * 4 + 2];
+            r8[6]         = tot[sp * 4 + 3];
             if (CLASSES) {
-                row[TAB_R + idx] = rtot[e];
-                row[TAB_2 + idx] = two[e];
+                r8[TAB_R + 0]         = rtot[sp * 4 + 0];
+                r8[TAB_R + c.idx_k01] = rtot[sp * 4 + 1];
+                r8[TAB_R + c.idx_k10] = rtot[sp * 4 + 2];
+                r8[TAB_R + 6]         = rtot[sp * 4 + 3];
+                r8[TAB_2 + 0]         = two[sp * 4 + 0];
+                r8[TAB_2 + c.idx_k01] = two[sp * 4 + 1];
+                r8[TAB_2 + c.idx_k10] = two[sp * 4 + 2];
+                r8[TAB_2 + 6]         = two[sp * 4 + 3];
             }
         }
         if ((c.part & 5) == 0) {                    // P == 0, firstpar == 0: one writer per f
@@ -659,6 +674,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         c.part = lane >> 3;
         c.mi   = lane & 7;
         make_part(w, c.part, &c.pc, &c.row_par, &c.row_tr, &c.row_ot);
+        c.idx_base  = part_entry_index(c.part, 0);          // (sp, bit_ot, bit_tr) = (0, 0, 0)
+        c.idx_k01   = part_entry_index(c.part, 1) - c.idx_base;
+        c.idx_k10   = part_entry_index(c.part, 2) - c.idx_base;
         c.row_root  = w.row[0];
         const int s = lane >> 3;
         c.s0 = s & 1;
