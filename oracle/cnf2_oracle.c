@@ -59,21 +59,26 @@ static const double *rec_sure(const cnf2o_ped *P, int rec, int marker)
 
 /* ------------------------------------------------------------- emission */
 
-/* Side-effect sink of the update modes (trackpossibleparams + tb.haplos, cpp:559-571, 1347-1350).
- * Only HAPLOS (= 1, cpp:792) is restated: haplos[rec][phase] += updateval. */
+/* Side-effect sink of the update modes (trackpossibleparams + tb.haplos / tb.infprobs, cpp:559-571,
+ * 1347-1354).  Modes (cpp:792-795): HAPLOS = 1: haplos[rec][phase] += updateval; GENOS = 2:
+ * infprobs[rec][allele index][markerval] += updateval; HOMOZYGOUS = 4 and GENOSPROBE = 8 only change what
+ * is evaluated.  The mode travels as an argument because the recursion strips HOMOZYGOUS (cpp:1280,1322). */
 typedef struct {
-    int     update;      /* 0 or HAPLOS */
     double  updateval;
-    double *haplos;      /* [n_rec][2] */
+    double *haplos;      /* [n_rec][2]            (HAPLOS) */
+    double *infprobs;    /* [n_rec][2][2], last index = markerval - 1 for markerval 1, 2 (GENOS) */
 } tp_sink;
 #define UPD_HAPLOS 1
+#define UPD_GENOS 2
+#define UPD_HOMOZYGOUS 4
+#define UPD_GENOSPROBE 8
 
 static double recurse_tp(const cnf2o_ped *P, int mother, int markerval, double secondval,
                          int marker, int upflag, int upflag2, int upshift, unsigned genwidth,
-                         int firstpar, int zeropropagate, int *gstr, const tp_sink *sink);
+                         int firstpar, int zeropropagate, int *gstr, int update, const tp_sink *sink);
 static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secondval,
                       int marker, unsigned flag, int flag99, int localshift,
-                      unsigned genwidth, int zeropropagate, int *gstr, const tp_sink *sink);
+                      unsigned genwidth, int zeropropagate, int *gstr, int update, const tp_sink *sink);
 
 /* cpp:1075-1359, update == 0 (no HAPLOS/GENOS/HOMOZYGOUS/GENOSPROBE side effects),
  * SELFING = RELSKEWSTATES = DOIMPOSSIBLE = false (set:11-16). */
@@ -82,17 +87,17 @@ double cnf2o_trackpossible(const cnf2o_ped *P, int rec, int inmarkerval, double 
                            unsigned genwidth, int zeropropagate, int *gstr)
 {
     return tp_core(P, rec, inmarkerval, secondval, marker, flag, flag99, localshift, genwidth,
-                   zeropropagate, gstr, NULL);
+                   zeropropagate, gstr, 0, NULL);
 }
 
-/* cpp:1075-1359 with update in {0, HAPLOS}. */
+/* cpp:1075-1359 with update in {0, HAPLOS, GENOS, HOMOZYGOUS, GENOSPROBE}. */
 static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secondval,
                       int marker, unsigned flag, int flag99, int localshift,
-                      unsigned genwidth, int zeropropagate, int *gstr, const tp_sink *sink)
+                      unsigned genwidth, int zeropropagate, int *gstr, int update, const tp_sink *sink)
 {
-    const int update = sink ? sink->update : 0;
     const int rootgen  = (genwidth == (1u << (CNF2O_NUMGEN - 1)));          /* cpp:1116 */
-    const int attopnow = (genwidth == 1) || P->founder[rec];                 /* cpp:1120 (HAPLOTYPING==1) */
+    const int attopnow = !(update & UPD_HOMOZYGOUS) &&
+                         ((genwidth == 1) || P->founder[rec]);               /* cpp:1120 (HAPLOTYPING==1) */
     const int32_t *themarker     = rec_allele(P, rec, marker);               /* cpp:1137 */
     const double  *themarkersure = rec_sure(P, rec, marker);                 /* cpp:1138 */
     const double   haploweight   = P->hw[(size_t)rec * P->n_markers + marker];
@@ -159,24 +164,34 @@ static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secon
 
         if (!baseval || attopnow) {                                          /* cpp:1271 */
         } else {
-            if (!zeropropagate || rootgen) {                                 /* cpp:1291 (prelok always true) */
+            const int down = update & ~UPD_HOMOZYGOUS;                       /* cpp:1280, 1322 */
+            if ((!zeropropagate || rootgen) && !(update & UPD_GENOS)) {      /* cpp:1291 (prelok always true) */
                 double secsecondval = 0;
                 int secmark = themarker[!realf2n];
-                if (themarkersure[!realf2n]) {                               /* cpp:1298-1302 */
+                if (!(update & UPD_HOMOZYGOUS)) {
+                    if (themarkersure[!realf2n]) {                           /* cpp:1298-1302 */
+                        baseval *= (1 - themarkersure[!realf2n]);
+                        secsecondval = themarkersure[!realf2n] / (1 - themarkersure[!realf2n]);
+                    }
+                } else if (markerval != secmark) {                           /* cpp:1304-1313 */
+                    if (secmark != UNKNOWN) baseval *= themarkersure[!realf2n];
+                    secmark = markerval;
+                } else {                                                     /* cpp:1314-1318 */
                     baseval *= (1 - themarkersure[!realf2n]);
-                    secsecondval = themarkersure[!realf2n] / (1 - themarkersure[!realf2n]);
                 }
                 baseval *= recurse_tp(P, rec, secmark, secsecondval, marker, upflag, upflag2,
-                                      upshift, genwidth, !firstpar, zeropropagate, gstr, sink); /* cpp:1322 */
+                                      upshift, genwidth, !firstpar, zeropropagate, gstr, down, sink); /* cpp:1322 */
             }
             if (baseval)                                                     /* cpp:1336-1340 */
                 baseval *= recurse_tp(P, rec, markerval, mainsecondval, marker, upflag, upflag2,
-                                      upshift, genwidth, firstpar, zeropropagate, gstr, sink);
+                                      upshift, genwidth, firstpar, zeropropagate, gstr, down, sink);
         }
 
-        if (baseval) {                                                       /* cpp:1343-1350 */
+        if (baseval) {                                                       /* cpp:1343-1354 */
             ok += baseval;
             if ((update & UPD_HAPLOS) && doupdatehaplo) sink->haplos[rec * 2 + f2n] += sink->updateval;
+            if ((update & UPD_GENOS) && (markerval == 1 || markerval == 2))
+                sink->infprobs[(rec * 2 + realf2n) * 2 + (markerval - 1)] += sink->updateval;
         }
     }
     return ok;
@@ -185,7 +200,7 @@ static double tp_core(const cnf2o_ped *P, int rec, int inmarkerval, double secon
 /* cpp:955-1058 recursetrackpossible: ctor (984-986) + operator double (1035-1057). */
 static double recurse_tp(const cnf2o_ped *P, int mother, int markerval, double secondval,
                          int marker, int upflag, int upflag2, int upshift, unsigned genwidth,
-                         int firstpar, int zeropropagate, int *gstr, const tp_sink *sink)
+                         int firstpar, int zeropropagate, int *gstr, int update, const tp_sink *sink)
 {
     int upflagr  = upflagit(upflag, firstpar, genwidth);
     int upflag2r = upflagit(upflag2, firstpar, genwidth);      /* NUMGEN-NUMFLAG2GEN == 0 */
@@ -193,7 +208,7 @@ static double recurse_tp(const cnf2o_ped *P, int mother, int markerval, double s
     int par = P->par[mother * 2 + firstpar];
     if (par < 0) return 1 + secondval;                          /* cpp:1043-1046 */
     return tp_core(P, par, markerval, secondval, marker, (unsigned)upflagr, upflag2r,
-                   upshiftr, genwidth >> 1, zeropropagate, gstr, sink);
+                   upshiftr, genwidth >> 1, zeropropagate, gstr, update, sink);
 }
 
 /* cpp:1380-1385 */
@@ -872,10 +887,63 @@ void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last,
                 /* updatehaplo, cpp:1561-1575 */
                 double ok = cnf2o_emission(P, ind, marker, g, flag2, s);
                 if (ok) {
-                    tp_sink sink = {UPD_HAPLOS, val, out};
+                    tp_sink sink = {val, out, NULL};
                     tp_core(P, ind, UNKNOWN, 0, marker, (unsigned)(g * 2), flag2, s,
-                            1u << (CNF2O_NUMGEN - 1), 0, NULL, &sink);
+                            1u << (CNF2O_NUMGEN - 1), 0, NULL, UPD_HAPLOS, &sink);
                 }
+            }
+        }
+    cnf2o_fwbw_free(W);
+}
+
+/* What HOT LOOP 2 leaves in the thread-private `infprobs` (before moveinfprobs, cpp:3577-3597) and adds to
+ * the analysed individual's `homozyg[marker]` for one marker (cpp:5513-5577, DOINFPROBS):
+ *   sidevals[side][i-1] = trackpossible<GENOSPROBE>(allele i on the root's side `side`)      cpp:5519-5528
+ *   homozyg[i-1]        = trackpossible<HOMOZYGOUS>(allele i)                                cpp:5531-5537
+ *   trackpossible<GENOS>(allele i, side) with updateval = val * sidevals / sidevalsums[side]  cpp:5560-5568
+ *   hz_out[i-1]        += val * homozyg[i-1] / sidevalsums[0]                                 cpp:5571-5575
+ * inf_out[n_rec][2][2]: [individual][allele index][markerval - 1].  Divisions by a zero sidevalsum give
+ * the reference's own NaN/inf. */
+void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                        double *inf_out, double *hz_out)
+{
+    cnf2o_fwbw *W = cnf2o_fwbw_new(P->n_markers);
+    double factors[NUMSHIFTS], factor;
+    cnf2o_sweep_ind(P, ind, gen, first, last, factors, &factor, NULL, 0, W);
+    cnf2o_tree T;
+    cnf2o_fixtrees(P, ind, &T);
+    memset(inf_out, 0, sizeof(double) * 4 * P->n_rec);
+    hz_out[0] = hz_out[1] = 0;
+    const unsigned gw = 1u << (CNF2O_NUMGEN - 1);
+    int shiftend = gen < 2 ? 2 : NUMSHIFTS;
+    int okind = !(isnan(factor) || factor < CNF2O_MINFACTOR);
+    for (int g = 0; okind && g < NUMTYPES; g++)
+        for (int s = 0; s < shiftend; s++) {
+            if (s & T.shiftignore) continue;
+            if (factor - factors[s] > 40) continue;
+            for (int flag2 = 0; flag2 < NUMPATHS; flag2++) {
+                if (cnf2o_ignoreflag2(P, &T, flag2, g, s, marker)) continue;
+                double val = cnf2o_query(P, ind, s, first, last, marker, g, flag2, W, -200 + factor) - factor;
+                if (!(isfinite(val) && val > -200)) continue;
+                val = exp(val);
+                double sidevals[2][2] = {{0, 0}, {0, 0}}, sums[2] = {0, 0}, homozyg[2] = {0, 0};
+                for (int side = 0; side < 2; side++)
+                    for (int i = 1; i <= 2; i++) {
+                        double sv = tp_core(P, ind, i, 0, marker, (unsigned)(g * 2 + side), flag2 ^ side, s, gw,
+                                            0, NULL, UPD_GENOSPROBE, NULL);
+                        sidevals[side][i - 1] += sv;
+                        sums[side] += sv;
+                    }
+                for (int i = 1; i <= 2; i++)
+                    homozyg[i - 1] += tp_core(P, ind, i, 0, marker, (unsigned)(g * 2), flag2, s, gw, 0, NULL,
+                                              UPD_HOMOZYGOUS, NULL);
+                for (int side = 0; side < 2; side++)
+                    for (int i = 1; i <= 2; i++) {
+                        tp_sink sink = {val * sidevals[side][i - 1] / sums[side], NULL, inf_out};
+                        tp_core(P, ind, i, 0, marker, (unsigned)(g * 2 + side), flag2 ^ side, s, gw, 0, NULL,
+                                UPD_GENOS, &sink);
+                    }
+                for (int i = 1; i <= 2; i++) hz_out[i - 1] += val * homozyg[i - 1] / sums[0];
             }
         }
     cnf2o_fwbw_free(W);

@@ -166,6 +166,11 @@ void cnf2o_val_table(const cnf2o_ped *P, int ind, int gen, int first, int last, 
 void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
                       double *out);
 
+/* thread-private infprobs [n_rec][2][2] and the homozyg[2] increments HOT LOOP 2 makes at one marker
+ * (cpp:5513-5577); see the .c file */
+void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
+                        double *inf_out, double *hz_out);
+
 /* Batch driver used as the CPU baseline: OpenMP over individuals (cpp:5294),
  * per-thread private store.  inds[n_ind] record indices, gens[n_ind].
  * dosage_out [n_ind][last-first+1][3] normalised rows (or NULL).

@@ -100,6 +100,7 @@ def lib():
         L.cnf2o_emission_tables.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_EmTab)]
         L.cnf2o_val_table.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cnf2o_haplos_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.cnf2o_infprobs_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
@@ -221,6 +222,15 @@ class OraclePed:
         h = np.zeros((self.R, 2))
         lib().cnf2o_haplos_row(C.byref(self.c), ind, gen, first, last, marker, _ptr(h))
         return h
+
+    def infprobs_row(self, ind, marker, gen=2, first=0, last=None):
+        """infprobs [n_rec][allele index][markerval - 1] and the homozyg[2] increments of HOT LOOP 2 at one
+        marker (before moveinfprobs)."""
+        last = self.M - 1 if last is None else last
+        inf = np.zeros((self.R, 2, 2))
+        hz = np.zeros(2)
+        lib().cnf2o_infprobs_row(C.byref(self.c), ind, gen, first, last, marker, _ptr(inf), _ptr(hz))
+        return inf, hz
 
     def sweep_batch(self, inds, gens=None, first=0, last=None, mode=2, dosage=True, n_threads=0):
         last = self.M - 1 if last is None else last

@@ -43,6 +43,7 @@ def lib(ieee=True):
         L.ref_turn_query.restype = C.c_double
         L.ref_dosage_rows.argtypes = [C.c_void_p]
         L.ref_haplos_row.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_infprobs_row.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_sweep_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _libs[key] = L
     return _libs[key]
@@ -116,6 +117,14 @@ class RefPed:
         h = np.zeros((self.ped.n_rec, 2))
         self.L.ref_haplos_row(marker, self.ped.n_rec, h.ctypes.data)
         return h
+
+    def infprobs_row(self, marker):
+        """infprobs [n_rec][allele index][markerval - 1] and homozyg[2] left by HOT LOOP 2 at one marker for
+        the individual of the last sweep()."""
+        inf = np.zeros((self.ped.n_rec, 2, 2))
+        hz = np.zeros(2)
+        self.L.ref_infprobs_row(marker, self.ped.n_rec, inf.ctypes.data, hz.ctypes.data)
+        return inf, hz
 
     def sweep_batch(self, recs, first=0, last=None, threads=0):
         last = self.M - 1 if last is None else last

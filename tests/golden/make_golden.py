@@ -15,6 +15,8 @@ seeds) and the reference's outputs for them -- data only, no reference text:
   G6 fixtrees outputs, founder flags, ignoreflag2 samples                (cpp:3099-3187,3462-3496)
   G7 mapval(g,flag2,s) samples                                           (cpp:5511-5512)
   G8 haplos[n][2] left by HOT LOOP 2 (updatehaplo, HAPLOS mode) at the turn_markers  (cpp:1561-1575,5556)
+  G9 infprobs[n][allele index][markerval 1,2] and the homozyg[2] increments of HOT LOOP 2 (GENOSPROBE /
+     HOMOZYGOUS / GENOS modes) at the turn_markers                                       (cpp:5513-5577)
 """
 import os
 import sys
@@ -65,6 +67,8 @@ def generate(name):
     turn_markers = np.array(sorted(set([0, M // 2, M - 1])), np.int32)
     rawer = np.full((n, len(turn_markers), 128, 8), np.nan)
     haplos = np.zeros((n, len(turn_markers), ped.n_rec, 2))
+    infprobs = np.zeros((n, len(turn_markers), ped.n_rec, 2, 2))
+    homozyg = np.zeros((n, len(turn_markers), 2))
     em_idx, em_val, mv_idx, mv_val, ig_idx, ig_val = [], [], [], [], [], []
     for j, ind in enumerate(ped.dous):
         ind = int(ind)
@@ -81,6 +85,7 @@ def generate(name):
             dosage[j] = R.dosage_rows(M)
             for ti, m in enumerate(turn_markers):
                 haplos[j, ti] = R.haplos_row(int(m))
+                infprobs[j, ti], homozyg[j, ti] = R.infprobs_row(int(m))
                 for turn in range(128):
                     if turn & (t["flag2ignore"] >> 1):
                         continue
@@ -107,7 +112,7 @@ def generate(name):
             ig_val[k] = R.L.ref_ignoreflag2(f2, g, s, m)
     out.update(fixtrees=fix, rel=rel, ordered=ordered, factors=factors, factor=factor, ok=ok,
                fwbw=fwbw, fwbwfactors=fwbwf, dosage=dosage, turn_markers=turn_markers, rawervals=rawer,
-               haplos=haplos,
+               haplos=haplos, infprobs=infprobs, homozyg=homozyg,
                em_idx=np.array(em_idx, np.int32), em_val=np.array(em_val),
                mv_idx=np.array(mv_idx, np.int32), mv_val=np.array(mv_val, np.int32),
                ig_idx=np.array(ig_idx, np.int32), ig_val=np.array(ig_val, np.uint8))

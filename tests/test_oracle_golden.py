@@ -104,3 +104,17 @@ def test_haplos_accumulators(golden):
         for ti, m in enumerate(z["turn_markers"]):
             got = o.haplos_row(int(ind), int(m), int(ped.gen[ind]))
             np.testing.assert_allclose(got, z["haplos"][j, ti], rtol=1e-12, atol=1e-15)
+
+
+def test_infprobs_homozyg_accumulators(golden):
+    """GENOSPROBE / HOMOZYGOUS / GENOS update modes of HOT LOOP 2 (cnF2freq.cpp:5513-5577) against the
+    reference's thread-private infprobs and its homozyg increments."""
+    ped, z = golden
+    o = oracle_ped(ped)
+    for j, ind in enumerate(ped.dous):
+        if not z["ok"][j]:
+            continue
+        for ti, m in enumerate(z["turn_markers"]):
+            inf, hz = o.infprobs_row(int(ind), int(m), int(ped.gen[ind]))
+            np.testing.assert_allclose(inf, z["infprobs"][j, ti], rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(hz, z["homozyg"][j, ti], rtol=1e-12, atol=1e-15)
