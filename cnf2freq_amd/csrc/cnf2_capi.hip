@@ -731,6 +731,29 @@ int cnf2_haplos(cnf2_ctx* ctx, int ind, int chrom, double* rows_out, uint32_t fl
     return CNF2_OK;
 }
 
+int cnf2_infprobs(cnf2_ctx* ctx, int ind, int chrom, int marker, double* inf_out, double* hz_out, uint32_t flags)
+{
+    if (!ctx || !inf_out || !hz_out) return fail(ctx, CNF2_ERR_ARG, "bad infprobs arguments");
+    Stage2Params q;
+    double*      d_out = nullptr;
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (chrom < 0 || chrom >= ctx->n_chrom) return fail(ctx, CNF2_ERR_ARG, "chromosome out of range");
+    if (marker < ctx->chromstarts[chrom] || marker >= ctx->chromstarts[chrom + 1])
+        return fail(ctx, CNF2_ERR_ARG, "marker not on the chromosome");
+    rc = run_store(ctx, ind, chrom, &q, 32, &d_out);
+    if (rc) return rc;
+    launch_infprobs(q, marker, (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0, d_out, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    double h[30];
+    HIP_TRY(ctx, hipMemcpyAsync(h, d_out, 30 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 28; k++) inf_out[k] = h[k];
+    hz_out[0] = h[28];
+    hz_out[1] = h[29];
+    return CNF2_OK;
+}
+
 int cnf2_emission(cnf2_ctx* ctx, int ind, int marker, double* e_out)
 {
     int rc = ready(ctx);

@@ -1267,6 +1267,159 @@ __global__ __launch_bounds__(64) void haplos_rows_kernel(Stage2Params q, uint32_
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Update-mode trackpossible for ONE path (flag99 >= 0), restated for the device: cnF2freq.cpp:1075-1359 with
+// update in {GENOS = 2, HOMOZYGOUS = 4, GENOSPROBE = 8} (cnF2freq.cpp:792-795), zeropropagate = false,
+// CORRECTIONINFERENCE = false.  A node is a window slot; the recursion depth is the template parameter
+// (genwidth 4 -> 2 -> 1), so it unrolls into straight-line code.  GENOS adds updateval to
+// inf[slot][allele index][markerval - 1] of every visited node of the traced line (cnF2freq.cpp:1351-1354).
+// ---------------------------------------------------------------------------------------------------
+#define TP_GENOS 2
+#define TP_HOMOZYGOUS 4
+#define TP_GENOSPROBE 8
+
+__device__ __forceinline__ int tp_upflagit(int flag, int parnum, int genwidth)      // cnF2freq.cpp:321-329
+{
+    if (flag < 0) return flag;
+    flag >>= parnum * (genwidth - 1);
+    return flag & ((1 << (genwidth - 1)) - 1);
+}
+
+template <int GW>
+__device__ double tp_path(const KernelParams& p, const Window& w, int m, int slot, int inmv, double secondval,
+                          unsigned flag, int flag99, int localshift, int update, double updateval, double* inf)
+{
+    const bool attopnow = !(update & TP_HOMOZYGOUS) && (GW == 1 || (w.flags[slot] & SLOT_FOUNDER));   // cpp:1120
+    const Slot d        = load_slot(p, w.row[slot], m);
+    const int  upflag2  = flag99 >> 1;                                   // cpp:1141-1146 (flag99 != -1)
+    const int  upflag   = (int)(flag >> 1);
+    const int  upshift  = localshift >> 1;
+    const int  firstpar = flag & 1;                                      // cpp:1156
+    const int  realf2n  = flag99 & 1;
+    int        f2n      = realf2n;
+    const int    mf = realf2n ? d.a1 : d.a0, mo = realf2n ? d.a0 : d.a1;
+    const double sf = realf2n ? d.s1 : d.s0, so = realf2n ? d.s0 : d.s1;
+    int    markerval;
+    double baseval, mainsecondval = 0.0;
+    if (markermiss(inmv, mf, &markerval)) {                              // cpp:1198-1202
+        baseval = sf;
+        if (sf != 0.0 && secondval != 0.0) mainsecondval = (1.0 - sf) * secondval;
+    } else {                                                             // cpp:1203-1210
+        const double esv = (inmv == 0 && markerval != 0) ? 1.0 : secondval;
+        baseval          = 1.0 - sf;
+        mainsecondval    = (mf == 0 ? 1.0 : sf) * esv;
+    }
+    if (attopnow) {                                                      // cpp:1213 (`update & 1` is false here)
+        baseval += mainsecondval;
+        mainsecondval = 0.0;
+    } else if (mainsecondval != 0.0) mainsecondval /= baseval;
+    f2n ^= (firstpar ^ localshift) & 1;                                  // cpp:1227
+    if (d.a0 == d.a1 && d.s0 == d.s1) baseval *= (f2n ? 1.0 : 0.0);      // cpp:1235-1239
+    else baseval *= fabs((f2n ? 1.0 : 0.0) - d.hw);                      // cpp:1245
+    if constexpr (GW > 1) {
+        if (baseval != 0.0 && !attopnow) {                               // cpp:1271
+            const int down = update & ~TP_HOMOZYGOUS;                    // cpp:1280, 1322
+            auto recurse = [&](int fp, int mv, double sv) -> double {    // recursetrackpossible, cpp:984-986, 1035-1057
+                const int child = slot == 0 ? (fp ? 4 : 1) : slot + 1 + fp;
+                if (!(w.flags[child] & SLOT_PRESENT)) return 1.0 + sv;   // cpp:1043-1046
+                return tp_path<GW / 2>(p, w, m, child, mv, sv, (unsigned)tp_upflagit(upflag, fp, GW),
+                                       tp_upflagit(upflag2, fp, GW), tp_upflagit(upshift, fp, GW >> 1), down,
+                                       updateval, inf);
+            };
+            if (!(update & TP_GENOS)) {                                  // cpp:1291
+                double secsecondval = 0.0;
+                int    secmark      = mo;
+                if (!(update & TP_HOMOZYGOUS)) {
+                    if (so != 0.0) {                                     // cpp:1298-1302
+                        baseval *= (1.0 - so);
+                        secsecondval = so / (1.0 - so);
+                    }
+                } else if (markerval != secmark) {                       // cpp:1304-1313
+                    if (secmark != 0) baseval *= so;
+                    secmark = markerval;
+                } else {                                                 // cpp:1314-1318
+                    baseval *= (1.0 - so);
+                }
+                baseval *= recurse(firstpar ^ 1, secmark, secsecondval);
+            }
+            if (baseval != 0.0) baseval *= recurse(firstpar, markerval, mainsecondval);      // cpp:1336-1340
+        }
+    }
+    if (baseval != 0.0 && (update & TP_GENOS) && (markerval == 1 || markerval == 2))        // cpp:1351-1354
+        atomicAdd(inf + (slot * 2 + realf2n) * 2 + (markerval - 1), updateval);
+    return baseval;
+}
+
+// infprobs / homozyg accumulators of HOT LOOP 2 at one marker (cnF2freq.cpp:5513-5577, DOINFPROBS), brute
+// force like the reference: one thread per (shift mode, state, path).  out[0..27] = infprobs[slot][allele
+// index][markerval - 1] before moveinfprobs (cnF2freq.cpp:3577-3597), out[28..29] = what is added to the
+// individual's homozyg[marker].  Paths are masked as ignoreflag2 does where that changes a sum
+// (flag2ignore and the all-or-none rule, cnF2freq.cpp:3478-3486; its third rule only drops zero terms).
+__global__ __launch_bounds__(128) void infprobs_kernel(Stage2Params q, int marker, uint32_t flags, double* out)
+{
+    const int flag2 = threadIdx.x;            // 0..127
+    const int g     = blockIdx.x & 63;
+    const int s     = blockIdx.x >> 6;
+    const Window w  = q.kp.windows[0];
+    const double factor = q.loglik[0];
+    if ((s & w.shiftignore) || s >= w.shiftend) return;
+    if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                   // cnF2freq.cpp:5403
+    if (factor - q.factors[s] > 40.0) return;                                         // cnF2freq.cpp:5421
+    if (flag2 & w.flag2ignore) return;                                                // cnF2freq.cpp:3478
+    if (!(flags & KP_NO_TIES)) {
+        for (int t = 0; t < w.n_groups; t++) {                                        // cnF2freq.cpp:3483-3486
+            int mask = 0;
+            for (int k = 0; k < 7; k++)
+                if (w.tie[k] == t) mask |= 1 << k;
+            const int filtered = (flag2 ^ (g * 2)) & mask;
+            if (filtered && filtered != mask) return;
+        }
+    }
+    // val of the path (as locked_query_kernel)
+    const int ml = marker - q.first;
+    const int f  = flag2 & 1;
+    LaneJob   L0, L1;
+    LineTerms T0, T1;
+    double    cf;
+    bool      attop;
+    s2_lines(q, w, marker, g, s, f, &L0, &L1, &T0, &T1, &cf, &attop);
+    double e;
+    if (attop) e = cf;
+    else {
+        const int fp0 = (flag2 >> 1) & 1, fp1 = (flag2 >> 4) & 1;
+        const int a0 = (flag2 >> (2 + L0.cfg.firstpar)) & 1, o0 = (flag2 >> (2 + (L0.cfg.firstpar ^ 1))) & 1;
+        const int a1 = (flag2 >> (5 + L1.cfg.firstpar)) & 1, o1 = (flag2 >> (5 + (L1.cfg.firstpar ^ 1))) & 1;
+        e = (cf * s2_path_term(L1.cfg, T1, fp1, a1, o1)) * s2_path_term(L0.cfg, T0, fp0, a0, o0);
+    }
+    const double am = s2_fw(q, s, ml, 0, g), be = s2_fw(q, s, ml, 1, g);
+    const double lv = s2_ff(q, s, ml, 0) + log(am * e) + s2_ff(q, s, ml, 1) + log(be) - factor;
+    if (!(isfinite(lv) && lv > -200.0)) return;                                       // cnF2freq.cpp:5502
+    const double val = exp(lv);
+
+    const KernelParams& p = q.kp;
+    double sidevals[2][2], sums[2] = {0.0, 0.0}, homozyg[2];
+    for (int side = 0; side < 2; side++)                                              // cnF2freq.cpp:5519-5528
+        for (int i = 1; i <= 2; i++) {
+            const double sv = tp_path<4>(p, w, marker, 0, i, 0.0, (unsigned)(g * 2 + side), flag2 ^ side, s,
+                                         TP_GENOSPROBE, 0.0, nullptr);
+            sidevals[side][i - 1] = sv;
+            sums[side] += sv;
+        }
+    for (int i = 1; i <= 2; i++)                                                      // cnF2freq.cpp:5531-5537
+        homozyg[i - 1] = tp_path<4>(p, w, marker, 0, i, 0.0, (unsigned)(g * 2), flag2, s, TP_HOMOZYGOUS, 0.0, nullptr);
+    for (int side = 0; side < 2; side++)                                              // cnF2freq.cpp:5560-5568
+        for (int i = 1; i <= 2; i++)
+            tp_path<4>(p, w, marker, 0, i, 0.0, (unsigned)(g * 2 + side), flag2 ^ side, s, TP_GENOS,
+                       val * sidevals[side][i - 1] / sums[side], out);
+    for (int i = 1; i <= 2; i++) atomicAdd(out + 28 + (i - 1), val * homozyg[i - 1] / sums[0]);   // cnF2freq.cpp:5571-5575
+}
+
+void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream)
+{
+    hipMemsetAsync(out, 0, 30 * sizeof(double), stream);
+    hipLaunchKernelGGL(infprobs_kernel, dim3(8 * 64), dim3(128), 0, stream, q, marker, flags, out);
+}
+
 void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(locked_query_kernel, dim3(512), dim3(128), 0, stream, q, marker, out);

@@ -144,6 +144,13 @@ int cnf2_state_posterior(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, ui
  *                       which the slot's individual is used (cnF2freq.cpp:1347-1350, 1561-1575, 5556).
  *                       An individual occupying several slots gets the sum of its slots in the reference. */
 int cnf2_haplos(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
+/*  cnf2_infprobs        the other accumulators of HOT LOOP 2 at `marker` (DOINFPROBS, cnF2freq.cpp:5513-5577):
+ *                       inf_out[7][2][2] = thread-private infprobs[slot][allele index][markerval - 1] before
+ *                       moveinfprobs (cnF2freq.cpp:3577-3597; trackpossible<GENOSPROBE> weights, <GENOS>
+ *                       updates, cnF2freq.cpp:1351-1354), hz_out[2] = what is added to the individual's
+ *                       homozyg[marker] (trackpossible<HOMOZYGOUS>, cnF2freq.cpp:1304-1320).  Brute force over
+ *                       (shift mode, state, path) like the reference; sums are accumulated atomically. */
+int cnf2_infprobs(cnf2_ctx *ctx, int ind, int chrom, int marker, double *inf_out, double *hz_out, uint32_t flags);
 
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */

@@ -513,6 +513,53 @@ def test_haplos_accumulators_match_reference(capi, case):
     ctx.close()
 
 
+def _infprobs_by_record(ctx, j, m, n_rec):
+    inf, hz = ctx.infprobs(j, int(m))
+    got = np.zeros((n_rec, 2, 2))
+    for k, r in enumerate(ctx.window_info(j)["slots"]):
+        if r >= 0:
+            got[r] += inf[k]
+    return got, hz
+
+
+def test_infprobs_homozyg_accumulators_against_oracle(capi):
+    """infprobs (GENOSPROBE weights, GENOS updates) and homozyg (HOMOZYGOUS) accumulators of HOT LOOP 2 per
+    window slot, summed per individual, against the oracle's update-mode fan-out (pinned on the reference)."""
+    for ped in (synth.make_random_windows(14, 4, seed=41), synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+                synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2)):
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        o = oracle_ped(ped)
+        checked = 0
+        for j, ind in enumerate(ped.dous):
+            gen = int(ped.gen[ind])
+            if not o.sweep_ind(int(ind), gen, mode=2)["ok"]:
+                continue
+            for m in (0, ped.n_markers - 1):
+                want, want_hz = o.infprobs_row(int(ind), m, gen)
+                got, hz = _infprobs_by_record(ctx, j, m, ped.n_rec)
+                np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12)
+                np.testing.assert_allclose(hz, want_hz, rtol=1e-8, atol=1e-12)
+                checked += 1
+        assert checked > 0
+        ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_infprobs_homozyg_accumulators_match_reference(capi, case):
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j in range(len(ped.dous)):
+        if not z["ok"][j]:
+            continue
+        for ti, m in enumerate(z["turn_markers"]):
+            got, hz = _infprobs_by_record(ctx, j, m, ped.n_rec)
+            np.testing.assert_allclose(got, z["infprobs"][j, ti], rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(hz, z["homozyg"][j, ti], rtol=1e-8, atol=1e-12)
+    ctx.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd
