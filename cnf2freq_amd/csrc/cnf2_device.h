@@ -67,6 +67,7 @@ void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_
 void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream);
+void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream);
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,

@@ -25,6 +25,7 @@
 #include "cnf2_device.h"
 #include "cnf2_lane.h"
 #include "cnf2_emtab.h"
+#include "cnf2_accum.h"
 
 namespace cnf2 {
 
@@ -1412,6 +1413,46 @@ __global__ __launch_bounds__(128) void infprobs_kernel(Stage2Params q, int marke
             tp_path<4>(p, w, marker, 0, i, 0.0, (unsigned)(g * 2 + side), flag2 ^ side, s, TP_GENOS,
                        val * sidevals[side][i - 1] / sums[side], out);
     for (int i = 1; i <= 2; i++) atomicAdd(out + 28 + (i - 1), val * homozyg[i - 1] / sums[0]);   // cnF2freq.cpp:5571-5575
+}
+
+// The same accumulators for every marker of the chromosome through the closed form of cnf2_accum.h (one
+// line at a time instead of 128 paths per state and mode): out[len][30] = infprobs[7][2][2] then homozyg[2].
+__global__ __launch_bounds__(64) void infprobs_rows_kernel(Stage2Params q, uint32_t flags, double* out)
+{
+    const int g  = threadIdx.x;
+    const int ml = blockIdx.x;
+    const int m  = q.first + ml;
+    const Window w = q.kp.windows[0];
+    const double factor = q.loglik[0];
+    double acc[30];
+#pragma unroll
+    for (int k = 0; k < 30; k++) acc[k] = 0.0;
+    Slot slot[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) slot[k] = load_slot(q.kp, w.row[k] < 0 ? 0 : w.row[k], m);
+    const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;              // cnF2freq.cpp:5403
+    for (int s = 0; s < 8 && !skip; s++) {
+        if ((s & w.shiftignore) || s >= w.shiftend) continue;
+        if (factor - q.factors[s] > 40.0) continue;                                    // cnF2freq.cpp:5421
+        const double wg = s2_fw(q, s, ml, 0, g) * s2_fw(q, s, ml, 1, g) *
+                          exp(s2_ff(q, s, ml, 0) + s2_ff(q, s, ml, 1) - factor);
+        if (wg != 0.0) accum_infprobs(w, slot, g, s, wg, (flags & KP_NO_TIES) != 0, acc, acc + 28);
+    }
+    for (int k = 0; k < 30; k++) {
+        double v = acc[k];
+        v += lane_xor1(v);
+        v += lane_xor2(v);
+        v += dpp_mov_all<0x141>(v);
+        v += lane_xor8(v);
+        v += lane_xor16(v);
+        v += lane_xor32(v);
+        if (g == 0) out[(size_t)ml * 30 + k] = v;
+    }
+}
+
+void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(infprobs_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
 }
 
 void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream)

@@ -151,6 +151,11 @@ int cnf2_haplos(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t fl
  *                       homozyg[marker] (trackpossible<HOMOZYGOUS>, cnF2freq.cpp:1304-1320).  Brute force over
  *                       (shift mode, state, path) like the reference; sums are accumulated atomically. */
 int cnf2_infprobs(cnf2_ctx *ctx, int ind, int chrom, int marker, double *inf_out, double *hz_out, uint32_t flags);
+/*  cnf2_infprobs_rows   the same accumulators for every marker of the chromosome, rows_out[mc][30] = infprobs
+ *                       [7][2][2] followed by homozyg[2], through their closed form (cnf2_accum.h: the weight of
+ *                       a path depends on one line of descent only, the other line enters as its restricted
+ *                       total) instead of the 128-path fan-out. */
+int cnf2_infprobs_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */

@@ -5,6 +5,7 @@
 
 #include "cnf2_lane.h"
 #include "cnf2_emtab.h"
+#include "cnf2_accum.h"
 
 using namespace cnf2;
 
@@ -120,6 +121,30 @@ int shim_emtab_fast(int n_rec, const int32_t* par, const uint8_t* empty, const i
         c4[c.f * 2 + 0] = cw[0];
         c4[c.f * 2 + 1] = cw[1];
     }
+    return w.n_groups;
+}
+
+// Closed form of the infprobs / homozyg accumulators (cnf2_accum.h) at one marker: wg[8][64] = weight of
+// (shift mode, state) or 0 where the reference skips the mode; inf_out[7][2][2], hz_out[2].
+int shim_accum_infprobs(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                        const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+                        int n_markers, int rec, int marker, const double* wg, int no_ties, double* inf_out,
+                        double* hz_out)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    Slot slot[7];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot[k] = unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    }
+    for (int k = 0; k < 28; k++) inf_out[k] = 0;
+    hz_out[0] = hz_out[1] = 0;
+    for (int s = 0; s < 8; s++)
+        for (int g = 0; g < 64; g++)
+            if (wg[s * 64 + g] != 0.0) accum_infprobs(w, slot, g, s, wg[s * 64 + g], no_ties != 0, inf_out, hz_out);
     return w.n_groups;
 }
 }

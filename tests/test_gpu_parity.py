@@ -560,6 +560,38 @@ def test_infprobs_homozyg_accumulators_match_reference(capi, case):
     ctx.close()
 
 
+def test_infprobs_rows_closed_form_against_fanout_and_oracle(capi):
+    """cnf2_infprobs_rows (closed form, every marker of the chromosome) against the brute-force hook on the
+    same device and against the oracle; tied (AIL), outbred with missing data, random windows."""
+    for ped in (synth.make_random_windows(10, 4, seed=43), synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+                synth.make_outbred3(2, 2, 9, 1, seed=3, missing=0.2, random_hw=True, random_sure=True)):
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        o = oracle_ped(ped)
+        checked = 0
+        for j, ind in enumerate(ped.dous):
+            gen = int(ped.gen[ind])
+            if not o.sweep_ind(int(ind), gen, mode=2)["ok"]:
+                continue
+            inf, hz = ctx.infprobs_rows(j, 0)
+            slots = ctx.window_info(j)["slots"]
+            for m in range(ped.n_markers):
+                bi, bh = ctx.infprobs(j, m)
+                np.testing.assert_allclose(inf[m], bi, rtol=1e-8, atol=1e-12)
+                np.testing.assert_allclose(hz[m], bh, rtol=1e-8, atol=1e-12)
+            for m in (0, ped.n_markers - 1):
+                want, want_hz = o.infprobs_row(int(ind), m, gen)
+                got = np.zeros_like(want)
+                for k, r in enumerate(slots):
+                    if r >= 0:
+                        got[r] += inf[m, k]
+                np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12)
+                np.testing.assert_allclose(hz[m], want_hz, rtol=1e-8, atol=1e-12)
+                checked += 1
+        assert checked > 0
+        ctx.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd

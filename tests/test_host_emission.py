@@ -144,3 +144,53 @@ def test_fast_tile_producer_matches_general_producer(shim, seed):
                     got = sum(fc4[f * 2 + s0] * fa[lane_index(0, f, s1, g & 7)] * fb[lane_index(1, f, s2, g >> 3)]
                               for f in range(2))
                     np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
+
+
+def _mode_weights(o, ped, ind, m):
+    """wg[s][g] = exp(scales - factor) * alphaminus_s(g) * beta_s(g) from the oracle's store, 0 for the
+    modes HOT LOOP 2 skips (cnF2freq.cpp:5420-5421)."""
+    gen = int(ped.gen[ind])
+    r = o.sweep_ind(int(ind), gen, mode=2, keep_store=True)
+    if not r["ok"]:
+        return None
+    t = o.fixtrees(int(ind))
+    wg = np.zeros((8, 64))
+    for s in range(8 if gen >= 2 else 2):
+        if (s & t.shiftignore) or r["factor"] - r["factors"][s] > 40:
+            continue
+        wg[s] = (np.exp(r["fwbwfactors"][s, m, 0] + r["fwbwfactors"][s, m, 1] - r["factor"])
+                 * r["fwbw"][s, m, 0] * r["fwbw"][s, m, 1])
+    return wg
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.make_random_windows(30, 4, seed=21),
+    lambda: synth.make_outbred3(2, 2, 7, 1, seed=8, missing=0.25, random_hw=True, random_sure=True),
+    lambda: synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2),
+    lambda: synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+])
+def test_closed_form_infprobs_matches_fanout(shim, maker):
+    """cnf2_accum.h (closed form of the infprobs / homozyg accumulators of HOT LOOP 2) against the oracle's
+    brute-force fan-out over (state, shift mode, path), which is pinned on the reference."""
+    ped = maker()
+    o = oracle_ped(ped)
+    checked = 0
+    for ind in ped.dous:
+        slots = np.zeros(17, np.int32)
+        shim.shim_window(*_ped_args(ped), int(ind), _p(slots))
+        for m in (0, ped.n_markers - 1):
+            wg = _mode_weights(o, ped, ind, m)
+            if wg is None:
+                continue
+            inf, hz = np.zeros((7, 2, 2)), np.zeros(2)
+            shim.shim_accum_infprobs(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
+                                     int(ind), m, _p(np.ascontiguousarray(wg)), 0, _p(inf), _p(hz))
+            want, want_hz = o.infprobs_row(int(ind), m, int(ped.gen[ind]))
+            got = np.zeros_like(want)
+            for k in range(7):
+                if slots[3 + k] >= 0:
+                    got[slots[3 + k]] += inf[k]
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(hz, want_hz, rtol=1e-9, atol=1e-13)
+            checked += 1
+    assert checked > 0
