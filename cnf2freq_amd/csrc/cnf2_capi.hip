@@ -54,6 +54,8 @@ struct cnf2_ctx {
     // workspace
     Job*    d_jobs = nullptr;
     size_t  jobs_cap = 0;
+    PackedJob* d_pjobs = nullptr;
+    size_t  pjobs_cap = 0;
     double* d_spill = nullptr;
     size_t  spill_bytes = 0;
     double *d_factors = nullptr, *d_loglik = nullptr, *d_dosage = nullptr;
@@ -153,6 +155,7 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     hipFree(ctx->d_windows);
     hipFree(ctx->d_rowflags);
     hipFree(ctx->d_jobs);
+    hipFree(ctx->d_pjobs);
     hipFree(ctx->d_spill);
     hipFree(ctx->d_factors);
     hipFree(ctx->d_loglik);
@@ -451,12 +454,46 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     if (n_jobs > 0x7fffffff) return fail(ctx, CNF2_ERR_ARG, "too many jobs in one call");
     // job list: individuals x chromosomes (the loops at cnF2freq.cpp:5283 and 5294), windows
     // without an active tie group first (fast kernel), tied windows after (general kernel)
+    // CNF2_MERGE_MODES: windows whose two parents are homozygous with equal sure everywhere go four to a
+    // wavefront (fb_packed_kernel); groups are formed per chromosome, what does not fill a group of four
+    // stays with the ordinary kernel
+    const bool merge = (flags & CNF2_MERGE_MODES) && !(flags & CNF2_FULL_SPILL);
+    auto mergeable = [&](const Window& w) {
+        if (w.n_groups > 0 && !(flags & CNF2_NO_TIES)) return false;
+        if (w.shiftignore != 0 || w.shiftend != 8 || (w.flags[0] & SLOT_FOUNDER)) return false;
+        for (int k = 1; k <= 4; k += 3) {
+            if (!(w.flags[k] & SLOT_PRESENT) || w.row[k] < 0) return false;
+            if (!ctx->ped.row_hom[w.row[k]]) return false;
+        }
+        return true;
+    };
+    std::vector<uint8_t>   packed(merge ? n : 0, 0);
+    std::vector<PackedJob> pjobs;
+    if (merge) {
+        std::vector<int> el;
+        for (int j = 0; j < n; j++)
+            if (mergeable(ctx->windows[ind_begin + j])) el.push_back(j);
+        const size_t full = el.size() / 4 * 4;
+        for (size_t k = 0; k < full; k++) packed[el[k]] = 1;
+        for (int c = 0; c < ctx->n_chrom; c++)
+            for (size_t k = 0; k < full; k += 4) {
+                PackedJob pj;
+                for (int i = 0; i < 4; i++) pj.ind[i] = el[k + i];
+                pj.first = ctx->chromstarts[c];
+                pj.last  = ctx->chromstarts[c + 1] - 1;
+                pj.chrom = c;
+                pj.pad   = 0;
+                pjobs.push_back(pj);
+            }
+    }
+    const size_t n_packed = pjobs.size();
     std::vector<Job> jobs;
     jobs.reserve(n_jobs);
     size_t n_fast = 0;
     for (int pass = 0; pass < 2; pass++) {
         for (int c = 0; c < ctx->n_chrom; c++)
             for (int j = 0; j < n; j++) {
+                if (merge && packed[j]) continue;
                 const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
                 if (tied != (pass == 1)) continue;
                 Job jb;
@@ -468,11 +505,17 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
             }
         if (pass == 0) n_fast = jobs.size();
     }
-    const size_t n_general = n_jobs - n_fast;
-    rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, n_jobs);
+    const size_t n_general = jobs.size() - n_fast;
+    rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, jobs.size() + 1);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(Job) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // jobs vector goes out of scope
+    if (!jobs.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (n_packed > 0) {
+        rc = ensure(ctx, &ctx->d_pjobs, &ctx->pjobs_cap, n_packed);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pjobs, pjobs.data(), sizeof(PackedJob) * n_packed, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the job vectors go out of scope
 
     // grids: one wave per job in flight, capped at what is resident so that the spill stays small
     auto grid_for = [&](size_t nj, int per_cu) {
@@ -481,7 +524,8 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         if (cap < 1) cap = 1;
         return g > cap ? cap : g;
     };
-    int grid_fast = grid_for(n_fast, ctx->fast_blocks_per_cu);
+    // the packed kernel runs before the ordinary fast kernel on the same stream and in the same spill slots
+    int grid_fast = grid_for(n_fast > n_packed ? n_fast : n_packed, ctx->fast_blocks_per_cu);
     int grid_gen  = grid_for(n_general, ctx->blocks_per_cu);
     const size_t stride = (size_t)max_chrom_len(ctx) * 528;   // covers every layout: 520 or 528 doubles per (pair of) marker(s), 512 in the general kernel
     {
@@ -498,7 +542,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         if ((size_t)grid_fast > max_blks) grid_fast = (int)max_blks;
         if ((size_t)grid_gen > max_blks) grid_gen = (int)max_blks;
     }
-    if (n_fast > 0 && n_general > 0) {
+    if ((n_fast > 0 || n_packed > 0) && n_general > 0) {
         // both kernels run side by side on two streams with disjoint spill slots: share the budget
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -547,8 +591,16 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
               ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (n_packed > 0) {
+        p.pjobs   = ctx->d_pjobs;
+        p.n_pjobs = (int)n_packed;
+        int gp    = (int)((n_packed + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+        launch_fb_packed(p, gp < grid_fast ? gp : grid_fast, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (n_fast > 0) {
-        launch_fb_fast(p, grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
+        int gf = (int)((n_fast + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+        launch_fb_fast(p, gf < grid_fast ? gf : grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_general > 0) {
@@ -556,7 +608,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev0, 0));
         p.jobs   = ctx->d_jobs + n_fast;
         p.n_jobs = (int)n_general;
-        p.spill  = ctx->d_spill + (size_t)(n_fast > 0 ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
+        p.spill  = ctx->d_spill + (size_t)((n_fast > 0 || n_packed > 0) ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
         launch_fb(p, grid_gen, false, ctx->stream2);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));

@@ -26,6 +26,12 @@ struct Job {
     int32_t chrom;
 };
 
+// Four jobs of the same chromosome swept by one wavefront (fb_packed_kernel).
+struct PackedJob {
+    int32_t ind[4];
+    int32_t first, last, chrom, pad;
+};
+
 struct KernelParams {
     // inputs, resident in HBM
     const Window*  windows;    // [n_ind]
@@ -37,6 +43,8 @@ struct KernelParams {
                                //             genrec[0] (.x) and genrec[1] (.y); 0 when dist <= 0
     const double2* tq;         // [n_markers] r / (1 - r) of the same gaps (fast kernel's scaled butterflies)
     const double*  chrom_logk; // [n_chrom] sum over the chromosome's gaps of 4 log(1-r0) + 2 log(1-r1)
+    const PackedJob* pjobs;    // [n_pjobs] (fb_packed_kernel)
+    int            n_pjobs;
     int            n_jobs;
     int            n_markers;
     int            n_chrom;
@@ -70,6 +78,7 @@ void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* 
 void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream);
+void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream);
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
                       hipStream_t stream);
 int  fb_fast_blocks_per_cu();

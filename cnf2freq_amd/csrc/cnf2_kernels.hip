@@ -568,10 +568,9 @@ struct RawSlots {
 
 // TQ_SHIFT: the forward pass needs the gap after marker m in row m, the backward pass the gap before it
 template <int TQ_SHIFT>
-__device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c, int m0, int lo_m, int hi_m, RawSlots* r)
+__device__ __forceinline__ void load_raw_at(const KernelParams& p, const FastCtx& c, int m, int lo_m, int hi_m, RawSlots* r)
 {
-    int m = m0 + c.mi;
-    m     = m < lo_m ? lo_m : (m > hi_m ? hi_m : m);      // clamp: lanes beyond the chromosome load a valid marker
+    m = m < lo_m ? lo_m : (m > hi_m ? hi_m : m);          // clamp: lanes beyond the chromosome load a valid marker
     const int32_t rows[4] = {c.row_root, c.row_par, c.row_tr, c.row_ot};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -583,13 +582,17 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
     const int mt = m + TQ_SHIFT;
     r->tq        = p.tq[mt < 0 ? 0 : mt];
 }
-
-template <bool CLASSES>
-__device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
-                                             const RawSlots& raw)
+template <int TQ_SHIFT>
+__device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c, int m0, int lo_m, int hi_m, RawSlots* r)
 {
-    const int m = m0 + c.mi;
-    if (m <= last) {
+    load_raw_at<TQ_SHIFT>(p, c, m0 + c.mi, lo_m, hi_m, r);
+}
+
+// the table row c.mi of the tile from this lane's raw inputs (valid: the row's marker exists)
+template <bool CLASSES>
+__device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool valid, const RawSlots& raw)
+{
+    if (valid) {
         const Slot root = unpack_slot(raw.ap[0], raw.su[0].x, raw.su[0].y, raw.hw[0]);
         const Slot par  = unpack_slot(raw.ap[1], raw.su[1].x, raw.su[1].y, raw.hw[1]);
         const Slot tr   = unpack_slot(raw.ap[2], raw.su[2].x, raw.su[2].y, raw.hw[2]);
@@ -627,6 +630,12 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
         // (a vector load there would make every s_waitcnt drain the spill stores as well)
         if (c.part == 0) *(double2*)(row + TAB_T) = raw.tq;
     }
+}
+template <bool CLASSES>
+__device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
+                                             const RawSlots& raw)
+{
+    produce_row<CLASSES>(c, tab, m0 + c.mi <= last, raw);
 }
 
 __device__ __forceinline__ void emission_from_row(const double* row, const FastCtx& c, double (&e)[8], double k = 1.0)
@@ -955,6 +964,260 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                         d2 *= inv;
                     }
                     double* out = p.dosage + ((size_t)jb.ind * p.n_markers + (m0 + mi2)) * 3;
+                    out[0] = d0;
+                    out[1] = d1;
+                    out[2] = d2;
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// =====================================================================================
+// Packed kernel: four jobs per wavefront for windows whose BOTH parents are homozygous with equal sure
+// at every marker (e.g. the private empty F1 parents of an F2, cnF2freq.cpp:6515-6527).  For such a
+// parent the two allele indices are interchangeable, its phase weight is 0/1 (cnF2freq.cpp:1235-1239)
+// and the unrestricted table does not depend on its shift bit: shift modes that differ in shift bits
+// 1, 2 carry bit-identical alpha and beta.  Only the two modes s0 = 0, 1 are swept; the per-locus row
+// sums the restricted / class-2 tables over both values of each parent's shift bit, which is exactly the
+// sum of the four copies.  Lane layout: chain = lane >> 3 = (job in wave) << 1 | s0, the rest as in
+// fb_fast_kernel; a tile is 2 markers x 4 jobs (same 8 table rows of LDS, row = marker << 2 | job).
+// Always half-spill.  Outputs are written for all 8 shift modes.
+// =====================================================================================
+__global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p)
+{
+    constexpr int ROW = 528;
+    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
+
+    const int lane  = threadIdx.x & 63;
+    const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
+    const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
+    double*   tab   = lds[wib];
+    double*   spill = p.spill + (size_t)wave * p.spill_stride;
+
+    for (int job = wave; job < p.n_pjobs; job += nwave) {
+        const PackedJob pj = p.pjobs[job];
+        // producer role: part x (marker in tile, job)
+        FastCtx c;
+        c.part = lane >> 3;
+        c.mi   = lane & 7;                                   // table row = marker_in_tile << 2 | job
+        const int pmt = c.mi >> 2;
+        {
+            const Window wp = p.windows[pj.ind[c.mi & 3]];
+            make_part(wp, c.part, &c.pc, &c.row_par, &c.row_tr, &c.row_ot);
+            c.row_root = wp.row[0];
+        }
+        c.idx_base = part_entry_index(c.part, 0);
+        c.idx_k01  = part_entry_index(c.part, 1) - c.idx_base;
+        c.idx_k10  = part_entry_index(c.part, 2) - c.idx_base;
+        // consumer role: chain = job << 1 | s0; shift bits 1, 2 are represented by 0
+        const int s    = lane >> 3;
+        const int cjob = s >> 1;
+        const int ind  = pj.ind[cjob];
+        c.s0 = s & 1;
+        c.s1 = 0;
+        c.s2 = 0;
+        c.lo = state_lo(lane);
+        c.active = true;                                     // eligibility: shiftignore == 0, shiftend == 8
+        const int first = pj.first, last = pj.last;
+        const int ntile = (last - first + 2) >> 1;
+        double*   myrow0 = tab + cjob * TAB_STRIDE;          // this lane's job, marker 0 of the tile
+        double*   myrow1 = myrow0 + 4 * TAB_STRIDE;
+
+        using odd_t  = std::integral_constant<bool, true>;
+        using even_t = std::integral_constant<bool, false>;
+
+        // ---------------------------------------------------------------- forward
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = 1.0 / 64.0;
+        double mant = 1.0;
+        int    expo = 0;
+        bool   dead = false;
+        double pend = 1.0;
+        auto fwd_step = [&](auto odd_tag, const double* row, int m) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            double         e[8];
+            emission_from_row(row, c, e, pend);
+            const double2 r  = *(const double2*)(row + TAB_T);
+            const int     ml = m - first;
+            double*       sp = spill + (size_t)(ml >> 1) * ROW;
+            if (!ODD) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const d2v v = {a[2 * k], a[2 * k + 1]};
+                    __builtin_nontemporal_store(v, (d2v*)(sp + k * 128 + lane * 2));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] *= e[j];
+            pend = 1.0;
+            if (!ODD || m == last) {
+                const double inv = chain_normaliser(a, &mant, &expo, &dead);
+                pend             = inv;
+                if (c.lo == 0) sp[512 + 2 * s + (ODD ? 1 : 0)] = inv;
+            }
+            if (m < last) transition_scaled(a, r.x, r.y);
+        };
+        RawSlots raw;
+        load_raw_at<0>(p, c, first + pmt, first, last, &raw);
+        for (int t = 0; t < ntile; t++) {
+            const int m0 = first + t * 2;
+            produce_row<false>(c, tab, m0 + pmt <= last, raw);
+            if (t + 1 < ntile) load_raw_at<0>(p, c, m0 + 2 + pmt, first, last, &raw);
+            wave_lds_fence();
+            fwd_step(even_t(), myrow0, m0);
+            if (m0 < last) fwd_step(odd_t(), myrow1, m0 + 1);
+            wave_lds_fence();
+        }
+
+        // ---------------------------------------------------------------- likelihoods
+        // every mode s has the likelihood of mode s & 1; the log-sum-exp over 8 modes adds the same two
+        // terms four times (the pairwise tree of fb_fast_kernel doubles exactly, so the bits agree)
+        const double logk = p.chrom_logk[pj.chrom];
+        const double fs   = dead ? (double)CNF2_MINFACTOR_F : (log(mant) + (double)expo * 0.69314718055994530942);
+        double fmaxv = fmax(fs, lane_xor8(fs));
+        fmaxv        = fmax(fmaxv, -1e15);
+        const double term = exp(fs - fmaxv);
+        const double real = 4.0 * (term + lane_xor8(term));
+        const double factor = fmaxv + log(real);
+        if (c.lo == 0) {
+            double* fo = p.factors + ((size_t)ind * p.n_chrom + pj.chrom) * 8 + c.s0;
+            const double v = !dead ? fs + logk : fs;
+            fo[0] = v;
+            fo[2] = v;
+            fo[4] = v;
+            fo[6] = v;
+        }
+        if ((lane & 15) == 0) p.loglik[(size_t)ind * p.n_chrom + pj.chrom] = (fmaxv > -1e14) ? factor + logk : factor;
+        const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;     // cnF2freq.cpp:5403
+        if (p.flags & KP_NO_DOSAGE) continue;
+
+        // ---------------------------------------------------------------- backward + rows
+        BwdState S;
+#pragma unroll
+        for (int j = 0; j < 8; j++) S.b[j] = 1.0;
+        S.bmant = 1.0;
+        S.bexpo = 0;
+        S.bdead = false;
+        S.fmant = mant;
+        S.fexpo = expo;
+        const double nf  = -factor * 1.4426950408889634074;
+        const double nfk = floor(nf);
+        const double xm  = exp2(nf - nfk);
+        const int    xe  = (int)nfk;
+        const bool   chain_on = !skip && !dead && !(factor - fs > 40.0);          // cnF2freq.cpp:5420-5421
+        auto load_row = [&](int idx) {
+            const double* sp = spill + (size_t)idx * ROW;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const d2v v = __builtin_nontemporal_load((const d2v*)(sp + k * 128 + lane * 2));
+                S.am[2 * k]     = v.x;
+                S.am[2 * k + 1] = v.y;
+            }
+            const double2 iv = *(const double2*)(sp + 512 + 2 * s);
+            S.inv_even       = iv.x;
+            S.inv_odd        = iv.y;
+        };
+        S.inv_odd = 1.0;
+        load_row((last - first) >> 1);
+
+        auto marker = [&](auto odd_tag, double* row, int m) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            const int      ml  = m - first;
+            double         wj[8];
+            const double2 r_m = *(const double2*)(row + TAB_T);     // gap m-1 -> m
+            double        inv_m;
+            if (ODD) {
+                double ep[8];
+                emission_from_row(row - 4 * TAB_STRIDE, c, ep);     // the even marker of the pair: same job, marker 0
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] = S.am[j] * ep[j];
+                transition_scaled(wj, r_m.x, r_m.y);
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] *= S.b[j];
+                inv_m = S.inv_odd;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) wj[j] = S.am[j] * S.b[j];
+                inv_m = S.inv_even;
+                asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wj[4]), "+v"(wj[5]),
+                             "+v"(wj[6]), "+v"(wj[7]), "+v"(inv_m) : : "memory");
+                const int idx = (ml >> 1) - 1;
+                load_row(idx < 0 ? 0 : idx);
+            }
+            if (!ODD || m == last) {
+                int ex;
+                S.fmant = frexp(S.fmant * inv_m, &ex);
+                S.fexpo += ex;
+            }
+            // class sums over the four copies (s1, s2) of this mode: tables summed over the parents' shift bits
+            double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const int     ia = (0 << 5) | (f << 4) | c.lo;
+                const double* Br = row + TAB_R + ((1 << 5) | (f << 4));
+                const double* B1 = row + TAB_2 + ((1 << 5) | (f << 4));
+                const double  cf = row[TAB_C + f * 2 + c.s0];
+                const double  av = cf * (row[TAB_R + ia] + row[TAB_R + ia + 8]);
+                const double  a1 = cf * (row[TAB_2 + ia] + row[TAB_2 + ia + 8]);
+                double        sb = 0.0, sb1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    sb += wj[j] * (Br[j] + Br[8 + j]);
+                    sb1 += wj[j] * (B1[j] + B1[8 + j]);
+                }
+                n_tot += av * sb;
+                n_a1 += a1 * sb;
+                n_b1 += av * sb1;
+                n_2 += a1 * sb1;
+            }
+            const double sc0   = ODD ? xm * S.inv_even : xm;
+            const double scale = chain_on ? ldexp(sc0 * S.fmant * S.bmant, xe + S.fexpo + S.bexpo) : 0.0;
+            const double q2 = scale * n_2;
+            const double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
+            const double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+            double e[8];
+            emission_from_row(row, c, e);
+            // the 16 lanes of this job park their partials in the job's own row of this marker
+            wave_lds_fence();
+            row[lane & 15]         = q0;
+            row[64 + (lane & 15)]  = q1;
+            row[128 + (lane & 15)] = q2;
+#pragma unroll
+            for (int j = 0; j < 8; j++) S.b[j] *= e[j];
+            if (!ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
+            transition_scaled(S.b, r_m.x, r_m.y);
+        };
+        load_raw_at<-1>(p, c, first + (ntile - 1) * 2 + pmt, first, last, &raw);
+        for (int t = ntile - 1; t >= 0; t--) {
+            const int m0 = first + t * 2;
+            produce_row<true>(c, tab, m0 + pmt <= last, raw);
+            wave_lds_fence();
+            if (m0 < last) marker(odd_t(), myrow1, m0 + 1);
+            marker(even_t(), myrow0, m0);
+            wave_lds_fence();
+            if (t > 0) load_raw_at<-1>(p, c, m0 - 2 + pmt, first, last, &raw);
+            // tile epilogue: lane = table row (marker << 2 | job) x eighth: 3 x 16 partials per row
+            {
+                const int     r8 = lane >> 3, sub = lane & 7;
+                const double* red = tab + r8 * TAB_STRIDE + sub * 2;
+                double d0 = red[0] + red[1], d1 = red[64] + red[65], d2 = red[128] + red[129];
+                d0 = fmax(chain_sum(d0), 0.0);
+                d1 = fmax(chain_sum(d1), 0.0);
+                d2 = fmax(chain_sum(d2), 0.0);
+                const int mm = m0 + (r8 >> 2);
+                if (sub == 0 && mm <= last) {
+                    if (!(p.flags & KP_RAW_DOSAGE)) {
+                        const double tsum = d0 + d1 + d2;
+                        const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
+                        d0 *= inv;
+                        d1 *= inv;
+                        d2 *= inv;
+                    }
+                    double* out = p.dosage + ((size_t)pj.ind[r8 & 3] * p.n_markers + mm) * 3;
                     out[0] = d0;
                     out[1] = d1;
                     out[2] = d2;
@@ -1476,6 +1739,11 @@ void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipS
 void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(state_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
+}
+
+void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fb_packed_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream)

@@ -50,8 +50,14 @@ enum {
     CNF2_NO_DOSAGE    = 1u << 1, /* HOT LOOP 1 only: factors/loglik, skip the per-locus rows    */
     CNF2_RAW_DOSAGE   = 1u << 2, /* rows un-normalised (sum of val by class, cnF2freq.cpp:3523) */
     CNF2_NO_TIES      = 1u << 3, /* drop ignoreflag2's all-or-none rule (cnF2freq.cpp:3484-3486) */
-    CNF2_FULL_SPILL   = 1u << 4  /* store alpha-minus at every marker instead of every second one and
+    CNF2_FULL_SPILL   = 1u << 4, /* store alpha-minus at every marker instead of every second one and
                                     recomputing the others in the backward pass (same results) */
+    CNF2_MERGE_MODES  = 1u << 5  /* sweep bit-identical shift modes once: for a window whose two parents are
+                                    homozygous with equal sure at every marker (e.g. the private empty F1
+                                    parents of an F2, cnF2freq.cpp:6515-6527) the modes that differ in the
+                                    parents' shift bits carry the same alpha/beta; four such individuals
+                                    share a wavefront.  Same outputs for all 8 modes (rows to rounding).
+                                    Ignored together with CNF2_FULL_SPILL. */
 };
 
 typedef struct cnf2_ctx cnf2_ctx;

@@ -592,6 +592,32 @@ def test_infprobs_rows_closed_form_against_fanout_and_oracle(capi):
         ctx.close()
 
 
+def test_merge_modes_equals_plain_sweep(capi):
+    """CNF2_MERGE_MODES: F2 individuals with private empty F1 parents go four to a wavefront and only the
+    modes s0 = 0, 1 are swept; likelihoods must be bit-identical to the ordinary sweep for all 8 modes, rows
+    equal to rounding (normalised and raw).  10 individuals = 2 groups of four + 2 left to the ordinary
+    kernel; chromosomes of length 1, even and odd; missing genotypes."""
+    ped = synth.make_f2(10, 21, 1, seed=9, chrom_cm=30.0, missing=0.15)
+    ped.chromstarts = np.array([0, 1, 9, 22], np.int32)
+    ped.pos = np.concatenate([[0.0], np.arange(8) * 0.9, np.arange(13) * 1.7])
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for raw in (False, True):
+        a = ctx.sweep(raw=raw)
+        b = ctx.sweep(raw=raw, merge_modes=True)
+        assert np.array_equal(a["factors"], b["factors"])
+        assert np.array_equal(a["loglik"], b["loglik"])
+        np.testing.assert_allclose(b["dosage"], a["dosage"], rtol=1e-9, atol=1e-14 if not raw else 1e-300)
+    # a pedigree without such parents: the flag changes nothing
+    ped2 = synth.make_outbred3(3, 3, 11, 1, seed=12, missing=0.1)
+    ctx2 = capi.Context(0)
+    ctx2.upload(ped2)
+    a, b = ctx2.sweep(), ctx2.sweep(merge_modes=True)
+    assert np.array_equal(a["dosage"], b["dosage"]) and np.array_equal(a["factors"], b["factors"])
+    ctx.close()
+    ctx2.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd

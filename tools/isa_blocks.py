@@ -6,7 +6,7 @@ from collections import Counter
 
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith("E") )
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().endswith(":") or (l.startswith("_Z") and key in l and ":" in l and "@" in l))
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 
 
