@@ -116,9 +116,11 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // The 8 entries of one lane.  Output index e = sp*4 + bit_ot*2 + bit_tr (see part_entry_index).
 // tot: unrestricted (forward/backward recursion); rtot/two only if CLASSES.
 // cw[s0] = root weight c_f(s0) (written by every lane; identical across parts with equal f).
-template <bool CLASSES>
-CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
-                        double tot[8], double rtot[8], double two[8], double cw[2])
+// `out(kind, e, v)` receives entry e of table kind (0 tot, 1 restricted, 2 class-2) as soon as it is known
+// (the tile producer stores it straight into LDS: nothing is held in registers until the end).
+template <bool CLASSES, class Out>
+CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
+                           Out&& out, double cw[2])
 {
     // ---- root (cnF2freq.cpp:1191-1245 at genwidth 4, inmarkerval unknown)
     const int    mf = c.f ? root.a1 : root.a0, mo = c.f ? root.a0 : root.a1;
@@ -132,10 +134,10 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
         const double v = (c.P == 0) ? base_r + msv_r : 1.0;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            tot[e] = v;
+            out(0, e, v);
             if (CLASSES) {
-                rtot[e] = v;
-                two[e]  = (c.P == 0 && mf == 2) ? v : 0.0;
+                out(1, e, v);
+                out(2, e, (c.P == 0 && mf == 2) ? v : 0.0);
             }
         }
         return;
@@ -197,23 +199,50 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
             }
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                tot[sp * 4 + b] = v;
+                out(0, sp * 4 + b, v);
                 if (CLASSES) {
-                    rtot[sp * 4 + b] = vr;
-                    two[sp * 4 + b]  = v2;
+                    out(1, sp * 4 + b, vr);
+                    out(2, sp * 4 + b, v2);
                 }
             }
         }
         return;
     }
 
-    // ---- grandparents: traced (gets the matched allele and its odds) and other
-    Leaf Ltr[2], Lot[2];     // per parent allele fp
+    // ---- grandparents: traced (gets the matched allele and its odds) and other.  One at a time, and only
+    // their per-kind values are kept (12 + 8 doubles instead of four Leaf records): the producer runs with the
+    // whole backward state of the wave live around it, so its own footprint decides what spills.
+    const int KINDS = CLASSES ? 3 : 1;
+    double G[3][2][2];       // [kind][fp][bit_tr]   traced line: alpha * t0 + beta * t1
+    double OO[2][2][2];      // [kind 0/1][fp][bit_ot] other line (never carries the class: kind 2 uses kind 1)
 #pragma unroll
     for (int fp = 0; fp < 2; fp++) {
-        leaf_make(trs, c.tr, vtr[fp], pis2[fp], &Ltr[fp]);
-        leaf_make(ots, c.ot, vot[fp], false, &Lot[fp]);
+        Leaf L;
+        leaf_make(trs, c.tr, vtr[fp], pis2[fp], &L);
+#pragma unroll
+        for (int kind = 0; kind < KINDS; kind++)
+#pragma unroll
+            for (int bit = 0; bit < 2; bit++) {
+                double t0, t1;
+                leaf_value(L, bit, kind, &t0, &t1);
+                G[kind][fp][bit] = alpha[fp] * t0 + beta[fp] * t1;
+            }
     }
+    CNF2_SCHED_FENCE();
+#pragma unroll
+    for (int fp = 0; fp < 2; fp++) {
+        Leaf L;
+        leaf_make(ots, c.ot, vot[fp], false, &L);
+#pragma unroll
+        for (int kind = 0; kind < (CLASSES ? 2 : 1); kind++)
+#pragma unroll
+            for (int bit = 0; bit < 2; bit++) {
+                double o0, o1;
+                leaf_value(L, bit, kind, &o0, &o1);
+                OO[kind][fp][bit] = (1.0 - so_p[fp]) * o0 + so_p[fp] * o1;
+            }
+    }
+    CNF2_SCHED_FENCE();
     // parent phase weight of allele fp under shift bit sp: pw[fp ^ sp ^ firstpar], zeroed where !baseval
     // (cnF2freq.cpp:1271); wq folds firstpar so that the index below is static
     const double wq0 = c.firstpar ? pw[1] : pw[0], wq1 = c.firstpar ? pw[0] : pw[1];
@@ -223,41 +252,32 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
     wl[1][0] = (bzero[0] || wq1 == 0.0) ? 0.0 : wq1;
     wl[1][1] = (bzero[1] || wq0 == 0.0) ? 0.0 : wq0;
     const double pm1 = par_r0 ? 0.0 : 1.0;     // the parent's own restriction: kinds 1, 2 drop fp = 1
-    const int KINDS = CLASSES ? 3 : 1;
-    // one kind at a time (0 tot, 1 restricted, 2 class-2 part): keeps few values live
+    // Output order: e = sp*4 + bit_ot*2 + bit_tr (the caller maps it to the table index: the traced
+    // grandparent is pars[firstpar], so (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr) : (bit_tr, bit_ot))
 #pragma unroll
     for (int kind = 0; kind < KINDS; kind++) {
-        double H[2][2][2];   // [fp][bit_ot][bit_tr]
-#pragma unroll
-        for (int fp = 0; fp < 2; fp++) {
-            double G[2], OO[2];
-#pragma unroll
-            for (int bit = 0; bit < 2; bit++) {
-                double t0, t1, o0, o1;
-                leaf_value(Ltr[fp], bit, kind, &t0, &t1);
-                // the other line never carries the class: kinds 1 and 2 use its restricted total
-                leaf_value(Lot[fp], bit, kind == 2 ? 1 : kind, &o0, &o1);
-                G[bit]  = alpha[fp] * t0 + beta[fp] * t1;
-                OO[bit] = (1.0 - so_p[fp]) * o0 + so_p[fp] * o1;
-            }
-#pragma unroll
-            for (int bo = 0; bo < 2; bo++)
-#pragma unroll
-                for (int bt = 0; bt < 2; bt++) H[fp][bo][bt] = OO[bo] * G[bt];
-        }
-        double* out = kind == 0 ? tot : (kind == 1 ? rtot : two);
-        // Output order: e = sp*4 + bit_ot*2 + bit_tr (the caller maps it to the table index: the traced
-        // grandparent is pars[firstpar], so (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr) : (bit_tr, bit_ot))
+        const int ko = kind == 2 ? 1 : kind;
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
+            const double w0 = wl[sp][0];
             const double w1 = kind >= 1 ? pm1 * wl[sp][1] : wl[sp][1];
 #pragma unroll
             for (int bo = 0; bo < 2; bo++)
 #pragma unroll
                 for (int bt = 0; bt < 2; bt++)
-                    out[sp * 4 + bo * 2 + bt] = wl[sp][0] * H[0][bo][bt] + w1 * H[1][bo][bt];
+                    out(kind, sp * 4 + bo * 2 + bt,
+                        w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]));
         }
     }
+}
+
+// array form (host tests)
+template <bool CLASSES>
+CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
+                        double tot[8], double rtot[8], double two[8], double cw[2])
+{
+    emtab_part_to<CLASSES>(c, root, par, trs, ots,
+                           [&](int kind, int e, double v) { (kind == 0 ? tot : (kind == 1 ? rtot : two))[e] = v; }, cw);
 }
 
 // Static part of a lane of the tile producer.

@@ -597,31 +597,20 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         const Slot par  = unpack_slot(raw.ap[1], raw.su[1].x, raw.su[1].y, raw.hw[1]);
         const Slot tr   = unpack_slot(raw.ap[2], raw.su[2].x, raw.su[2].y, raw.hw[2]);
         const Slot ot   = unpack_slot(raw.ap[3], raw.su[3].x, raw.su[3].y, raw.hw[3]);
-        double tot[8], rtot[8], two[8], cw[2];
-        emtab_part<CLASSES>(c.pc, root, par, tr, ot, tot, rtot, two, cw);
+        double  cw[2];
         double* row = tab + c.mi * TAB_STRIDE;
-        // entry e = sp*4 + bit_ot*2 + bit_tr goes to table index base + sp*8 + k: k = firstpar | 6 bit for the
-        // two diagonal entries, and the two off-diagonal ones swap places with firstpar (part_entry_index);
-        // the two lane-dependent offsets are per-job constants, so no value is ever selected
+        // entry e = sp*4 + bit_ot*2 + bit_tr goes to table index base + sp*8 + k: k = 0 / 6 for the two
+        // diagonal entries, and the two off-diagonal ones swap places with firstpar (part_entry_index); the
+        // two lane-dependent offsets are per-job constants, so no value is ever selected.  Entries are stored
+        // as they are formed: the producer holds no output array in registers.
         double* rb = row + c.idx_base;
-#pragma unroll
-        for (int sp = 0; sp < 2; sp++) {
-            double* r8 = rb + sp * 8;
-            r8[0]         = tot[sp * 4 + 0];
-            r8[c.idx_k01] = tot[sp * 4 + 1];
-            r8[c.idx_k10] = tot[sp * 4 + 2];
-            r8[6]         = tot[sp * 4 + 3];
-            if (CLASSES) {
-                r8[TAB_R + 0]         = rtot[sp * 4 + 0];
-                r8[TAB_R + c.idx_k01] = rtot[sp * 4 + 1];
-                r8[TAB_R + c.idx_k10] = rtot[sp * 4 + 2];
-                r8[TAB_R + 6]         = rtot[sp * 4 + 3];
-                r8[TAB_2 + 0]         = two[sp * 4 + 0];
-                r8[TAB_2 + c.idx_k01] = two[sp * 4 + 1];
-                r8[TAB_2 + c.idx_k10] = two[sp * 4 + 2];
-                r8[TAB_2 + 6]         = two[sp * 4 + 3];
-            }
-        }
+        emtab_part_to<CLASSES>(c.pc, root, par, tr, ot,
+                               [&](int kind, int e, double v) {
+                                   const int b  = e & 3;
+                                   const int k  = b == 0 ? 0 : (b == 1 ? c.idx_k01 : (b == 2 ? c.idx_k10 : 6));
+                                   rb[(kind == 0 ? 0 : (kind == 1 ? TAB_R : TAB_2)) + (e >> 2) * 8 + k] = v;
+                               },
+                               cw);
         if ((c.part & 5) == 0) {                    // P == 0, firstpar == 0: one writer per f
             row[TAB_C + c.pc.f * 2 + 0] = cw[0];
             row[TAB_C + c.pc.f * 2 + 1] = cw[1];
