@@ -30,6 +30,7 @@ struct Options {
     int         limit = 1000000;    // INDCOUNT (settings.h:9)
     int         capmarker = 0;
     bool        quiet = false;
+    bool        merge_modes = true;   // CNF2_MERGE_MODES: exact, faster for F2-type pedigrees (include/cnf2hip.h)
     bool        parse_only = false;   // print the parsed tables and stop (no GPU needed; used by tests)
 };
 
@@ -61,6 +62,7 @@ static bool parse(int argc, char** argv, Options& o)
         else if (a == "--limit") o.limit = atoi(val().c_str());
         else if (a == "--capmarker") o.capmarker = atoi(val().c_str());
         else if (a == "--quiet") o.quiet = true;
+        else if (a == "--no-merge-modes") o.merge_modes = false;
         else if (a == "--parse-only") o.parse_only = true;
         else {
             fprintf(stderr, "unsupported option %s (this build covers the PlantImpute path only)\n", a.c_str());
@@ -147,7 +149,8 @@ int main(int argc, char** argv)
         const bool early = it < 1;                       // cnF2freq.cpp:8131
         FILE* dst = (it == opt.count - 1) ? out : stdout;
         if (!early && N > 0) {
-            CHECK(ctx, cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(), 0));
+            CHECK(ctx, cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(),
+                                  opt.merge_modes ? CNF2_MERGE_MODES : 0));
             for (int c = 0; c < C; c++) {
                 if (!opt.quiet)
                     for (int j = 0; j < N; j++) {
