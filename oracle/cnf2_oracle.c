@@ -30,9 +30,9 @@ static const int TYPEGENS[TYPEBITS]  = {1, 0, 0, 1, 0, 0}; /* set:23 */
 /* cpp:303-316 markermiss<zeropropagate>; *a may be bound to b. */
 static int markermiss(int zeropropagate, int *a, int b)
 {
-    if (zeropropagate) return 0;
+    if (zeropropagate == 1) return 0;                          /* ZERO_PROPAGATE only; NO_EQUIVALENCE (-1) matches */
     if (*a == UNKNOWN) {
-        *a = b;
+        if (!zeropropagate) *a = b;                            /* NO_EQUIVALENCE does not bind either */
         return 0;
     }
     if (b == UNKNOWN && *a != SEXMARKER) return 0;
@@ -947,6 +947,41 @@ void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int las
             }
         }
     cnf2o_fwbw_free(W);
+}
+
+/* individ::addvariance (cpp:1489-1558), the emission-driven statistic postmarkerdata computes for every
+ * individual and marker (cpp:3373-3389) to pick the marker whose phase gets locked: trackpossible with
+ * zeropropagate = NO_EQUIVALENCE (-1: alleles are matched as usual, every level weighs 0.5 instead of the
+ * phase weight, below the root only the traced line is followed), fed the individual's OWN two alleles
+ * (with their sure as error odds) in turn, over shift modes 0-1, all 128 flags i = 2 g + firstpar and all
+ * admissible paths; per (shift, i & 1, flag2 & 1) the signed sum over the two alleles is squared.
+ * Returns 0 and leaves *out alone when every term is zero (cpp:1550). */
+int cnf2o_addvariance(const cnf2o_ped *P, int rec, int marker, int flag2ignore, double *out)
+{
+    const int32_t *themarker = rec_allele(P, rec, marker);
+    const double  *thesure   = rec_sure(P, rec, marker);
+    double sum = 0, sqsum = 0;
+    for (int shift = 0; shift < 2; shift++)
+        for (int majori = 0; majori < 2; majori++)
+            for (int majorflag2 = 0; majorflag2 < 2; majorflag2++) {
+                double fullok = 0, ok = 0;
+                for (int i = majori; i < NUMTYPES * 2; i += 2)
+                    for (int flag2 = majorflag2; flag2 < NUMPATHS; flag2 += 2) {
+                        if (flag2 & flag2ignore) continue;
+                        for (int allele = 0; allele < 2; allele++) {
+                            double term = tp_core(P, rec, themarker[allele], thesure[allele], marker, (unsigned)i,
+                                                  flag2, shift, 1u << (CNF2O_NUMGEN - 1), -1, NULL, 0, NULL);
+                            ok += term * (allele ? 1 : -1);
+                            fullok += term;
+                        }
+                    }
+                ok = fabs(ok);
+                sum += fullok;
+                sqsum += ok * ok;
+            }
+    if (!sum) return 0;
+    *out = sqsum;
+    return 1;
 }
 
 int cnf2o_sweep_batch(const cnf2o_ped *P, const int *inds, const int *gens, int n_ind,

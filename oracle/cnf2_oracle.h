@@ -171,6 +171,9 @@ void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last,
 void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
                         double *inf_out, double *hz_out);
 
+/* individ::addvariance (cpp:1489-1558); returns 0 (and leaves *out) when all terms are zero */
+int cnf2o_addvariance(const cnf2o_ped *P, int rec, int marker, int flag2ignore, double *out);
+
 /* Batch driver used as the CPU baseline: OpenMP over individuals (cpp:5294),
  * per-thread private store.  inds[n_ind] record indices, gens[n_ind].
  * dosage_out [n_ind][last-first+1][3] normalised rows (or NULL).

@@ -101,6 +101,7 @@ def lib():
         L.cnf2o_val_table.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cnf2o_haplos_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cnf2o_infprobs_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.cnf2o_addvariance.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
@@ -231,6 +232,12 @@ class OraclePed:
         hz = np.zeros(2)
         lib().cnf2o_infprobs_row(C.byref(self.c), ind, gen, first, last, marker, _ptr(inf), _ptr(hz))
         return inf, hz
+
+    def addvariance(self, rec, marker, flag2ignore):
+        """variances[marker] as individ::addvariance sets it (cpp:1489-1558); None when it is left alone."""
+        v = C.c_double(0.0)
+        ok = lib().cnf2o_addvariance(C.byref(self.c), rec, marker, flag2ignore, C.byref(v))
+        return v.value if ok else None
 
     def sweep_batch(self, inds, gens=None, first=0, last=None, mode=2, dosage=True, n_threads=0):
         last = self.M - 1 if last is None else last

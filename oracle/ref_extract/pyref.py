@@ -44,6 +44,7 @@ def lib(ieee=True):
         L.ref_dosage_rows.argtypes = [C.c_void_p]
         L.ref_haplos_row.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.ref_infprobs_row.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_addvariance.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.ref_sweep_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _libs[key] = L
     return _libs[key]
@@ -125,6 +126,11 @@ class RefPed:
         hz = np.zeros(2)
         self.L.ref_infprobs_row(marker, self.ped.n_rec, inf.ctypes.data, hz.ctypes.data)
         return inf, hz
+
+    def addvariance(self, rec, marker, flag2ignore):
+        v = C.c_double(0.0)
+        ok = self.L.ref_addvariance(rec + 1, marker, flag2ignore, C.byref(v))
+        return v.value if ok else None
 
     def sweep_batch(self, recs, first=0, last=None, threads=0):
         last = self.M - 1 if last is None else last

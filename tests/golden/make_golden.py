@@ -17,6 +17,8 @@ seeds) and the reference's outputs for them -- data only, no reference text:
   G8 haplos[n][2] left by HOT LOOP 2 (updatehaplo, HAPLOS mode) at the turn_markers  (cpp:1561-1575,5556)
   G9 infprobs[n][allele index][markerval 1,2] and the homozyg[2] increments of HOT LOOP 2 (GENOSPROBE /
      HOMOZYGOUS / GENOS modes) at the turn_markers                                       (cpp:5513-5577)
+  G10 variances[record][marker] of individ::addvariance with the record's own flag2ignore (NaN where the
+     function leaves the entry alone)                                                    (cpp:1489-1558, 3373-3389)
 """
 import os
 import sys
@@ -110,6 +112,15 @@ def generate(name):
         for k in range(len(ig_idx) - M * 8 * 9, len(ig_idx)):
             _, m, g, f2, s = ig_idx[k]
             ig_val[k] = R.L.ref_ignoreflag2(f2, g, s, m)
+    variances = np.full((ped.n_rec, M), np.nan)
+    var_f2i = np.zeros(ped.n_rec, np.int32)
+    for rec in range(ped.n_rec):
+        var_f2i[rec] = R.fixtrees(rec)["flag2ignore"]
+        for m in range(M):
+            v = R.addvariance(rec, m, int(var_f2i[rec]))
+            if v is not None:
+                variances[rec, m] = v
+    out.update(variances=variances, variances_flag2ignore=var_f2i)
     out.update(fixtrees=fix, rel=rel, ordered=ordered, factors=factors, factor=factor, ok=ok,
                fwbw=fwbw, fwbwfactors=fwbwf, dosage=dosage, turn_markers=turn_markers, rawervals=rawer,
                haplos=haplos, infprobs=infprobs, homozyg=homozyg,

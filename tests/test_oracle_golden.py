@@ -118,3 +118,21 @@ def test_infprobs_homozyg_accumulators(golden):
             inf, hz = o.infprobs_row(int(ind), int(m), int(ped.gen[ind]))
             np.testing.assert_allclose(inf, z["infprobs"][j, ti], rtol=1e-12, atol=1e-15)
             np.testing.assert_allclose(hz, z["homozyg"][j, ti], rtol=1e-12, atol=1e-15)
+
+
+def test_addvariance(golden):
+    """individ::addvariance (cnF2freq.cpp:1489-1558; trackpossible with zeropropagate = NO_EQUIVALENCE) for
+    every record and marker, with the record's own flag2ignore as postmarkerdata passes it."""
+    ped, z = golden
+    o = oracle_ped(ped)
+    for rec in range(ped.n_rec):
+        f2i = int(z["variances_flag2ignore"][rec])
+        assert o.fixtrees(rec).flag2ignore == f2i
+        for m in range(ped.n_markers):
+            got = o.addvariance(rec, m, f2i)
+            want = z["variances"][rec, m]
+            if np.isnan(want):
+                assert got is None
+            else:
+                assert got is not None
+                np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
