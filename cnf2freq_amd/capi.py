@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_emission",
+    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_addvariance", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -68,6 +68,7 @@ def load():
         L.cnf2_haplos.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_infprobs.argtypes = [vp, i32, i32, i32, vp, vp, C.c_uint32]
         L.cnf2_infprobs_rows.argtypes = [vp, i32, i32, vp, C.c_uint32]
+        L.cnf2_addvariance.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
@@ -240,6 +241,12 @@ class Context:
         v = np.zeros((mc, 30))
         self._chk(self.L.cnf2_infprobs_rows(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_infprobs_rows")
         return v[:, :28].reshape(mc, 7, 2, 2).copy(), v[:, 28:].copy()
+
+    def addvariance(self, ind, chrom=0):
+        mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
+        v = np.zeros(mc)
+        self._chk(self.L.cnf2_addvariance(self.h, ind, chrom, _p(v)), "cnf2_addvariance")
+        return v
 
     def emission(self, ind, marker):
         e = np.zeros((8, 64))

@@ -824,6 +824,25 @@ int cnf2_infprobs_rows(cnf2_ctx* ctx, int ind, int chrom, double* rows_out, uint
     return CNF2_OK;
 }
 
+int cnf2_addvariance(cnf2_ctx* ctx, int ind, int chrom, double* var_out)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (!var_out || ind < 0 || ind >= (int)ctx->windows.size() || chrom < 0 || chrom >= ctx->n_chrom)
+        return fail(ctx, CNF2_ERR_ARG, "bad addvariance arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int first = ctx->chromstarts[chrom], len = ctx->chromstarts[chrom + 1] - first;
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)len))) return rc;
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows = ctx->d_windows + ind;
+    launch_addvariance(p, first, len, ctx->d_scratch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(var_out, ctx->d_scratch, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
 int cnf2_emission(cnf2_ctx* ctx, int ind, int marker, double* e_out)
 {
     int rc = ready(ctx);

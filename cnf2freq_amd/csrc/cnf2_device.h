@@ -76,6 +76,7 @@ void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipSt
 void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream);
 void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
+void launch_addvariance(const KernelParams& p, int first, int len, double* out, hipStream_t stream);
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream);
 void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream);

@@ -1538,7 +1538,10 @@ __device__ __forceinline__ int tp_upflagit(int flag, int parnum, int genwidth)  
     return flag & ((1 << (genwidth - 1)) - 1);
 }
 
-template <int GW>
+// NOEQ: zeropropagate = NO_EQUIVALENCE (cnF2freq.cpp:42): alleles are matched but an unknown incoming value is
+// not bound (cnF2freq.cpp:311), every level weighs 0.5 instead of its phase weight (cnF2freq.cpp:1229-1233) and
+// below the root only the traced line is followed (cnF2freq.cpp:1291); used by addvariance.
+template <int GW, bool NOEQ = false>
 __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slot, int inmv, double secondval,
                           unsigned flag, int flag99, int localshift, int update, double updateval, double* inf)
 {
@@ -1554,7 +1557,9 @@ __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slo
     const double sf = realf2n ? d.s1 : d.s0, so = realf2n ? d.s0 : d.s1;
     int    markerval;
     double baseval, mainsecondval = 0.0;
-    if (markermiss(inmv, mf, &markerval)) {                              // cpp:1198-1202
+    const bool miss = markermiss(inmv, mf, &markerval);
+    if (NOEQ && inmv == 0) markerval = 0;                                // cpp:311: no binding
+    if (miss) {                                                          // cpp:1198-1202
         baseval = sf;
         if (sf != 0.0 && secondval != 0.0) mainsecondval = (1.0 - sf) * secondval;
     } else {                                                             // cpp:1203-1210
@@ -1567,7 +1572,8 @@ __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slo
         mainsecondval = 0.0;
     } else if (mainsecondval != 0.0) mainsecondval /= baseval;
     f2n ^= (firstpar ^ localshift) & 1;                                  // cpp:1227
-    if (d.a0 == d.a1 && d.s0 == d.s1) baseval *= (f2n ? 1.0 : 0.0);      // cpp:1235-1239
+    if (NOEQ) baseval *= 0.5;                                            // cpp:1229-1233
+    else if (d.a0 == d.a1 && d.s0 == d.s1) baseval *= (f2n ? 1.0 : 0.0); // cpp:1235-1239
     else baseval *= fabs((f2n ? 1.0 : 0.0) - d.hw);                      // cpp:1245
     if constexpr (GW > 1) {
         if (baseval != 0.0 && !attopnow) {                               // cpp:1271
@@ -1575,11 +1581,11 @@ __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slo
             auto recurse = [&](int fp, int mv, double sv) -> double {    // recursetrackpossible, cpp:984-986, 1035-1057
                 const int child = slot == 0 ? (fp ? 4 : 1) : slot + 1 + fp;
                 if (!(w.flags[child] & SLOT_PRESENT)) return 1.0 + sv;   // cpp:1043-1046
-                return tp_path<GW / 2>(p, w, m, child, mv, sv, (unsigned)tp_upflagit(upflag, fp, GW),
+                return tp_path<GW / 2, NOEQ>(p, w, m, child, mv, sv, (unsigned)tp_upflagit(upflag, fp, GW),
                                        tp_upflagit(upflag2, fp, GW), tp_upflagit(upshift, fp, GW >> 1), down,
                                        updateval, inf);
             };
-            if (!(update & TP_GENOS)) {                                  // cpp:1291
+            if (!(update & TP_GENOS) && (!NOEQ || GW == 4)) {            // cpp:1291
                 double secsecondval = 0.0;
                 int    secmark      = mo;
                 if (!(update & TP_HOMOZYGOUS)) {
@@ -1700,6 +1706,57 @@ __global__ __launch_bounds__(64) void infprobs_rows_kernel(Stage2Params q, uint3
         v += lane_xor32(v);
         if (g == 0) out[(size_t)ml * 30 + k] = v;
     }
+}
+
+// individ::addvariance (cnF2freq.cpp:1489-1558) for the analysed individual of windows[0] and every marker in
+// [first, first + len): trackpossible<false, NO_EQUIVALENCE> fed the individual's own two alleles (their sure
+// as error odds) over shift modes 0-1, the 128 flags i = 2 g + firstpar and the admissible paths; per
+// (shift, i & 1, flag2 & 1) the signed sum over the two alleles is squared.  out[ml] = variance, NaN when every
+// term is zero (the reference leaves variances[marker] alone).  One block per marker, brute force.
+__global__ __launch_bounds__(256) void addvariance_kernel(KernelParams p, int first, double* out)
+{
+    __shared__ double red_ok[8][256], red_full[256];
+    const int    m  = first + blockIdx.x;
+    const Window w  = p.windows[0];
+    const Slot   me = load_slot(p, w.row[0], m);
+    double ok[8], full = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok[k] = 0.0;
+    // 2 shifts x 128 flags x 128 paths = 32768 (shift, i, flag2) triples, 128 per thread
+    for (int t = threadIdx.x; t < 2 * 128 * 128; t += 256) {
+        const int flag2 = t & 127, i = (t >> 7) & 127, shift = t >> 14;
+        if (flag2 & w.flag2ignore) continue;
+        double d = 0.0;
+        for (int allele = 0; allele < 2; allele++) {
+            const double term = tp_path<4, true>(p, w, m, 0, allele ? me.a1 : me.a0, allele ? me.s1 : me.s0, (unsigned)i,
+                                                 flag2, shift, 0, 0.0, nullptr);
+            d += allele ? term : -term;
+            full += term;
+        }
+        ok[(shift << 2) | ((i & 1) << 1) | (flag2 & 1)] += d;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) red_ok[k][threadIdx.x] = ok[k];
+    red_full[threadIdx.x] = full;
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const double* src = threadIdx.x < 8 ? red_ok[threadIdx.x] : red_full;
+        double acc = 0.0;
+        for (int k = 0; k < 256; k++) acc += src[k];
+        if (threadIdx.x < 8) red_ok[threadIdx.x][0] = acc;
+        else red_full[0] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sq = 0.0;
+        for (int k = 0; k < 8; k++) sq += red_ok[k][0] * red_ok[k][0];
+        out[blockIdx.x] = red_full[0] != 0.0 ? sq : nan("");
+    }
+}
+
+void launch_addvariance(const KernelParams& p, int first, int len, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(addvariance_kernel, dim3(len), dim3(256), 0, stream, p, first, out);
 }
 
 void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)

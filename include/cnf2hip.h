@@ -163,6 +163,12 @@ int cnf2_infprobs(cnf2_ctx *ctx, int ind, int chrom, int marker, double *inf_out
  *                       total) instead of the 128-path fan-out. */
 int cnf2_infprobs_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 
+/* Pre-processing user of the emission (parity level): individ::addvariance
+ * (cnF2freq.cpp:1489-1558, called by postmarkerdata for every marker, cnF2freq.cpp:3373-3389) for one analysed
+ * individual and chromosome: var_out[mc] = variances[marker], NaN where the reference leaves the entry alone
+ * (every term zero).  Brute force over (shift mode 0-1, flag, path) with trackpossible<false, NO_EQUIVALENCE>. */
+int cnf2_addvariance(cnf2_ctx *ctx, int ind, int chrom, double *var_out);
+
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
 int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);

@@ -618,6 +618,22 @@ def test_merge_modes_equals_plain_sweep(capi):
     ctx2.close()
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_addvariance_matches_reference(capi, case):
+    """cnf2_addvariance (pre-processing user of the emission, cnF2freq.cpp:1489-1558) for the analysed
+    individuals against the reference's variances[] (goldens G10)."""
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    for j, ind in enumerate(ped.dous):
+        got = ctx.addvariance(j, 0)
+        want = z["variances"][int(ind)]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-14)
+    ctx.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd
