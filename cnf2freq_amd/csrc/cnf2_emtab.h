@@ -55,6 +55,70 @@ CNF2_HD void match_affine(int inmv, int mf, double sf, double* Bv, double* K, do
     *C  = (!miss && bound) ? effms : 0.0;
 }
 
+// What the combination below needs from a window member at one marker, in two forms:
+//   SlotDirect  computes it from the raw data on the fly;
+//   SlotTable   reads it from a 20-double record prepared once per (slot, marker) by slot_table() -- the tile
+//               producer prepares the 7 records of a marker with 7 lanes and the 8 parts share them, instead of
+//               every part redoing the match logic of its three ancestors (11 matches per part).
+// A match outcome depends on the incoming value only through its class: 0 incoming unknown, 1 compatible
+// (equal, or the slot's allele is unknown and the value is not the sex-marker sentinel), 2 mismatch.
+struct SlotDirect {
+    const Slot& d;
+    CNF2_HD explicit SlotDirect(const Slot& s) : d(s) {}
+    CNF2_HD int    allele(int fa) const { return fa ? d.a1 : d.a0; }
+    CNF2_HD double sure(int fa) const { return fa ? d.s1 : d.s0; }
+    CNF2_HD double w(int phase) const { return phase_weight(d, phase); }
+    CNF2_HD void   match(int v, int fa, double* Bv, double* K, double* C, int* mv) const
+    {
+        match_affine(v, allele(fa), sure(fa), Bv, K, C, mv);
+    }
+};
+
+enum { SLOTTAB_DOUBLES = 20 };
+// record: [fa*7 + cls*2 + {0,1}] = (Bv, K) of class cls, [fa*7 + 6] = C of class 0; [14], [15] phase weights;
+// [16..19] = a0, a1, s0, s1
+CNF2_HD void slot_table(const Slot& d, double* t)
+{
+#pragma unroll
+    for (int fa = 0; fa < 2; fa++) {
+        const int    mf = fa ? d.a1 : d.a0;
+        const double sf = fa ? d.s1 : d.s0;
+        const double effms = (mf == 0) ? 1.0 : sf;
+        double* q = t + fa * 7;
+        q[0] = 1.0 - sf;                              // incoming unknown (cnF2freq.cpp:1203-1210, bound iff mf known)
+        q[1] = (mf != 0) ? 0.0 : effms;
+        q[6] = (mf != 0) ? effms : 0.0;
+        q[2] = 1.0 - sf;                              // compatible
+        q[3] = effms;
+        q[4] = sf;                                    // mismatch (cnF2freq.cpp:1198-1202)
+        q[5] = (sf != 0.0) ? 1.0 - sf : 0.0;
+    }
+    t[14] = phase_weight(d, 0);
+    t[15] = phase_weight(d, 1);
+    t[16] = (double)d.a0;
+    t[17] = (double)d.a1;
+    t[18] = d.s0;
+    t[19] = d.s1;
+}
+
+struct SlotTable {
+    const double* t;
+    CNF2_HD explicit SlotTable(const double* p) : t(p) {}
+    CNF2_HD int    allele(int fa) const { return (int)t[16 + fa]; }
+    CNF2_HD double sure(int fa) const { return t[18 + fa]; }
+    CNF2_HD double w(int phase) const { return t[14 + phase]; }
+    CNF2_HD void   match(int v, int fa, double* Bv, double* K, double* C, int* mv) const
+    {
+        const int mf  = allele(fa);
+        const int cls = (v == 0) ? 0 : (((mf == 0 && v != 9) || v == mf) ? 1 : 2);
+        const double* q = t + fa * 7;
+        *Bv = q[cls * 2];
+        *K  = q[cls * 2 + 1];
+        *C  = (cls == 0) ? q[6] : 0.0;
+        *mv = (v == 0) ? mf : v;
+    }
+};
+
 // Grandparent (top of a line) as seen with incoming allele v.  Per allele index fg the products
 //     p0[fg][bit] = w(fg ^ bit) * t0[fg],   p1[fg][bit] = w(fg ^ bit) * t1[fg]
 // so that the leaf's value for state bit `bit` and incoming odds sv is sum_fg (p0 + sv * p1), with the
@@ -69,18 +133,19 @@ struct Leaf {
     double m1, i2[2];
 };
 
-CNF2_HD void leaf_make(const Slot& d, uint32_t flags, int v, bool parent_is2, Leaf* L)
+template <class View>
+CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Leaf* L)
 {
     const bool present = (flags & SLOT_PRESENT) != 0;
     const bool r0      = (flags & SLOT_RESTRICT0) != 0;
-    const double w0 = present ? phase_weight(d, 0) : 1.0;
-    const double w1 = present ? phase_weight(d, 1) : 1.0;
+    const double w0 = present ? d.w(0) : 1.0;
+    const double w1 = present ? d.w(1) : 1.0;
     double t0[2], t1[2];
 #pragma unroll
     for (int fg = 0; fg < 2; fg++) {
         double Bv, K, C;
         int    mv;
-        match_affine(v, fg ? d.a1 : d.a0, fg ? d.s1 : d.s0, &Bv, &K, &C, &mv);
+        d.match(v, fg, &Bv, &K, &C, &mv);
         const double miss = fg ? 0.0 : 1.0;
         t0[fg] = present ? Bv + C : miss;
         t1[fg] = present ? K : miss;
@@ -94,8 +159,8 @@ CNF2_HD void leaf_make(const Slot& d, uint32_t flags, int v, bool parent_is2, Le
     L->p1[1][0] = w1 * t1[1];
     L->p1[1][1] = w0 * t1[1];
     L->m1    = (present && r0) ? 0.0 : 1.0;
-    L->i2[0] = (present ? d.a0 == 2 : parent_is2) ? 1.0 : 0.0;
-    L->i2[1] = (present && d.a1 == 2 && !r0) ? 1.0 : 0.0;
+    L->i2[0] = (present ? d.allele(0) == 2 : parent_is2) ? 1.0 : 0.0;
+    L->i2[1] = (present && d.allele(1) == 2 && !r0) ? 1.0 : 0.0;
 }
 
 // (V0, V1) of the leaf for state bit `bit`; kind 0 = all alleles, 1 = restricted, 2 = class-2 part of restricted
@@ -118,17 +183,17 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // cw[s0] = root weight c_f(s0) (written by every lane; identical across parts with equal f).
 // `out(kind, e, v)` receives entry e of table kind (0 tot, 1 restricted, 2 class-2) as soon as it is known
 // (the tile producer stores it straight into LDS: nothing is held in registers until the end).
-template <bool CLASSES, class Out>
-CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
-                           Out&& out, double cw[2])
+template <bool CLASSES, class VR, class VP, class VT, class VO, class Out>
+CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
+                              Out&& out, double cw[2])
 {
     // ---- root (cnF2freq.cpp:1191-1245 at genwidth 4, inmarkerval unknown)
-    const int    mf = c.f ? root.a1 : root.a0, mo = c.f ? root.a0 : root.a1;
-    const double sf = c.f ? root.s1 : root.s0, so_r = c.f ? root.s0 : root.s1;
+    const int    mf = root.allele(c.f), mo = root.allele(c.f ^ 1);
+    const double sf = root.sure(c.f), so_r = root.sure(c.f ^ 1);
     const double base_r = 1.0 - sf;
     const double msv_r  = (mf != 0) ? sf : 0.0;
-    cw[0] = phase_weight(root, c.f ^ 0);
-    cw[1] = phase_weight(root, c.f ^ 1);
+    cw[0] = root.w(c.f ^ 0);
+    cw[1] = root.w(c.f ^ 1);
     if (c.root_attop) {
         // the root is the top of its only line: e = sum_f (base + odds) * weight
         const double v = (c.P == 0) ? base_r + msv_r : 1.0;
@@ -158,22 +223,20 @@ CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, 
     bool   bzero[2], pis2[2];
     int    vtr[2], vot[2];
     double so_p[2];
-    pw[0] = phase_weight(par, 0);
-    pw[1] = phase_weight(par, 1);
+    pw[0] = par.w(0);
+    pw[1] = par.w(1);
 #pragma unroll
     for (int fp = 0; fp < 2; fp++) {
         double Bp, Kp, Cp;
         int    mv;
-        const int    mfp = fp ? par.a1 : par.a0;
-        const double sfp = fp ? par.s1 : par.s0;
-        match_affine(inmv, mfp, sfp, &Bp, &Kp, &Cp, &mv);
+        par.match(inmv, fp, &Bp, &Kp, &Cp, &mv);
         alpha[fp] = u0 * Bp;
         beta[fp]  = u0 * Cp + u1 * Kp;
         bzero[fp] = (Bp == 0.0);
-        pis2[fp]  = (mfp == 2);
+        pis2[fp]  = (par.allele(fp) == 2);
         vtr[fp]   = mv;
-        vot[fp]   = fp ? par.a0 : par.a1;
-        so_p[fp]  = fp ? par.s0 : par.s1;
+        vot[fp]   = par.allele(fp ^ 1);
+        so_p[fp]  = par.sure(fp ^ 1);
     }
 
     if (!par_present || par_founder) {
@@ -269,6 +332,24 @@ CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, 
                         w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]));
         }
     }
+}
+
+// from raw slot data (every part does its own match logic)
+template <bool CLASSES, class Out>
+CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
+                           Out&& out, double cw[2])
+{
+    emtab_part_views<CLASSES>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
+}
+
+// from the 7 slot records of the marker (`recs` = 7 x SLOTTAB_DOUBLES, slot order of the window)
+template <bool CLASSES, class Out>
+CNF2_HD void emtab_part_tables(const PartCfg& c, const double* recs, Out&& out, double cw[2])
+{
+    const int sp = 1 + 3 * c.P;
+    emtab_part_views<CLASSES>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
+                              SlotTable(recs + (sp + 1 + c.firstpar) * SLOTTAB_DOUBLES),
+                              SlotTable(recs + (sp + 1 + (c.firstpar ^ 1)) * SLOTTAB_DOUBLES), out, cw);
 }
 
 // array form (host tests)

@@ -553,6 +553,8 @@ struct FastCtx {
     int     part, mi;
     int     idx_base, idx_k01, idx_k10;   // where this lane's entries go in a table row (produce_tile)
     int32_t row_root, row_par, row_tr, row_ot;
+    int     slot_a;                       // two-phase producer: window slot this lane prepares (lane >> 3; 7 = none)
+    int32_t row_a;                        //                     and its genotype row
     int     s0, s1, s2, lo;
     bool    active;
 };
@@ -627,6 +629,77 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
     produce_row<CLASSES>(c, tab, m0 + c.mi <= last, raw);
 }
 
+// Raw inputs of one lane of the tile producer's first phase (ONE window member at one marker), requested a
+// whole tile ahead.
+struct RawOne {
+    uint8_t ap;
+    double2 su;
+    double  hw;
+    double2 tq;      // scaled recombination odds of the gap this marker's row carries (lanes of slot 0)
+};
+
+// TQ_SHIFT: the forward pass needs the gap after marker m in row m, the backward pass the gap before it
+template <int TQ_SHIFT>
+__device__ __forceinline__ void load_raw1_at(const KernelParams& p, const FastCtx& c, int m, int lo_m, int hi_m, RawOne* r)
+{
+    m = m < lo_m ? lo_m : (m > hi_m ? hi_m : m);          // clamp: lanes beyond the chromosome load a valid marker
+    const size_t i = (size_t)c.row_a * p.n_markers + m;
+    r->ap = p.allele8[i];
+    r->su = p.sure[i];
+    r->hw = p.hw[i];
+    const int mt = m + TQ_SHIFT;
+    r->tq        = p.tq[mt < 0 ? 0 : mt];
+}
+// Two-phase form of produce_row (used by the packed kernel, where the producer runs every second marker and
+// its register footprint decides what spills; for the ordinary kernel the extra LDS round trips cost more than
+// the shorter match logic saves: measured 657 against 629 ms).  The table row c.mi in two phases: lanes (slot, row) turn the raw
+// data of one window member into its match record (cnf2_emtab.h slot_table: 20 doubles in the row itself); then
+// lanes (part, row) combine the records of their line into their 8 entries per table kind and, once every
+// lane has read what it needs, store them over the records.
+template <bool CLASSES>
+__device__ __forceinline__ void produce_row2(const FastCtx& c, double* tab, bool valid, const RawOne& raw)
+{
+    double* row = tab + c.mi * TAB_STRIDE;
+    if (valid && c.slot_a < 7)
+        slot_table(unpack_slot(raw.ap, raw.su.x, raw.su.y, raw.hw), row + c.slot_a * SLOTTAB_DOUBLES);
+    wave_lds_fence();
+    double tot[8], rtot[8], two[8], cw[2];
+    if (valid)
+        emtab_part_tables<CLASSES>(c.pc, row,
+                                   [&](int kind, int e, double v) { (kind == 0 ? tot : (kind == 1 ? rtot : two))[e] = v; }, cw);
+    wave_lds_fence();
+    if (valid) {
+        // entry e = sp*4 + bit_ot*2 + bit_tr goes to table index base + sp*8 + k: k = 0 / 6 for the two
+        // diagonal entries, and the two off-diagonal ones swap places with firstpar (part_entry_index); the
+        // two lane-dependent offsets are per-job constants, so no value is ever selected
+        double* rb = row + c.idx_base;
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            double* r8 = rb + sp * 8;
+            r8[0]         = tot[sp * 4 + 0];
+            r8[c.idx_k01] = tot[sp * 4 + 1];
+            r8[c.idx_k10] = tot[sp * 4 + 2];
+            r8[6]         = tot[sp * 4 + 3];
+            if (CLASSES) {
+                r8[TAB_R + 0]         = rtot[sp * 4 + 0];
+                r8[TAB_R + c.idx_k01] = rtot[sp * 4 + 1];
+                r8[TAB_R + c.idx_k10] = rtot[sp * 4 + 2];
+                r8[TAB_R + 6]         = rtot[sp * 4 + 3];
+                r8[TAB_2 + 0]         = two[sp * 4 + 0];
+                r8[TAB_2 + c.idx_k01] = two[sp * 4 + 1];
+                r8[TAB_2 + c.idx_k10] = two[sp * 4 + 2];
+                r8[TAB_2 + 6]         = two[sp * 4 + 3];
+            }
+        }
+        if ((c.part & 5) == 0) {                    // P == 0, firstpar == 0: one writer per f
+            row[TAB_C + c.pc.f * 2 + 0] = cw[0];
+            row[TAB_C + c.pc.f * 2 + 1] = cw[1];
+        }
+        // the gap's butterfly factors ride in the row: the marker loop never touches vmcnt for them
+        // (a vector load there would make every s_waitcnt drain the spill stores as well)
+        if (c.part == 0) *(double2*)(row + TAB_T) = raw.tq;
+    }
+}
 __device__ __forceinline__ void emission_from_row(const double* row, const FastCtx& c, double (&e)[8], double k = 1.0)
 {
     const double cA0 = row[TAB_C + 0 + c.s0] * row[(0 << 5) | (0 << 4) | (c.s1 << 3) | c.lo] * k;
@@ -995,8 +1068,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
         const int pmt = c.mi >> 2;
         {
             const Window wp = p.windows[pj.ind[c.mi & 3]];
-            make_part(wp, c.part, &c.pc, &c.row_par, &c.row_tr, &c.row_ot);
-            c.row_root = wp.row[0];
+            int32_t      rp, rt, ro;
+            make_part(wp, c.part, &c.pc, &rp, &rt, &ro);
+            c.slot_a = lane >> 3;
+            c.row_a  = (c.slot_a < 7 && wp.row[c.slot_a] >= 0) ? wp.row[c.slot_a] : 0;
         }
         c.idx_base = part_entry_index(c.part, 0);
         c.idx_k01  = part_entry_index(c.part, 1) - c.idx_base;
@@ -1050,12 +1125,12 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
             }
             if (m < last) transition_scaled(a, r.x, r.y);
         };
-        RawSlots raw;
-        load_raw_at<0>(p, c, first + pmt, first, last, &raw);
+        RawOne raw;
+        load_raw1_at<0>(p, c, first + pmt, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 2;
-            produce_row<false>(c, tab, m0 + pmt <= last, raw);
-            if (t + 1 < ntile) load_raw_at<0>(p, c, m0 + 2 + pmt, first, last, &raw);
+            produce_row2<false>(c, tab, m0 + pmt <= last, raw);
+            if (t + 1 < ntile) load_raw1_at<0>(p, c, m0 + 2 + pmt, first, last, &raw);
             wave_lds_fence();
             fwd_step(even_t(), myrow0, m0);
             if (m0 < last) fwd_step(odd_t(), myrow1, m0 + 1);
@@ -1180,15 +1255,15 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
             if (!ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
             transition_scaled(S.b, r_m.x, r_m.y);
         };
-        load_raw_at<-1>(p, c, first + (ntile - 1) * 2 + pmt, first, last, &raw);
+        load_raw1_at<-1>(p, c, first + (ntile - 1) * 2 + pmt, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 2;
-            produce_row<true>(c, tab, m0 + pmt <= last, raw);
+            produce_row2<true>(c, tab, m0 + pmt <= last, raw);
             wave_lds_fence();
             if (m0 < last) marker(odd_t(), myrow1, m0 + 1);
             marker(even_t(), myrow0, m0);
             wave_lds_fence();
-            if (t > 0) load_raw_at<-1>(p, c, m0 - 2 + pmt, first, last, &raw);
+            if (t > 0) load_raw1_at<-1>(p, c, m0 - 2 + pmt, first, last, &raw);
             // tile epilogue: lane = table row (marker << 2 | job) x eighth: 3 x 16 partials per row
             {
                 const int     r8 = lane >> 3, sub = lane & 7;

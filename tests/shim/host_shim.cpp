@@ -124,6 +124,39 @@ int shim_emtab_fast(int n_rec, const int32_t* par, const uint8_t* empty, const i
     return w.n_groups;
 }
 
+// Same tables from the 7 per-slot records (slot_table / SlotTable, the tile producer's two-phase form)
+int shim_emtab_tables(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                      const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+                      int n_markers, int rec, int marker, double* tot, double* rtot, double* two, double* c4)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    double recs[7 * SLOTTAB_DOUBLES];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot_table(unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]),
+                   recs + k * SLOTTAB_DOUBLES);
+    }
+    for (int part = 0; part < 8; part++) {
+        PartCfg c;
+        int32_t rp, rt, ro;
+        make_part(w, part, &c, &rp, &rt, &ro);
+        double t[8], r[8], t2[8], cw[2];
+        emtab_part_tables<true>(c, recs, [&](int kind, int e, double v) { (kind == 0 ? t : (kind == 1 ? r : t2))[e] = v; }, cw);
+        for (int e = 0; e < 8; e++) {
+            int idx = part_entry_index(part, e);
+            tot[idx] = t[e];
+            rtot[idx] = r[e];
+            two[idx] = t2[e];
+        }
+        c4[c.f * 2 + 0] = cw[0];
+        c4[c.f * 2 + 1] = cw[1];
+    }
+    return w.n_groups;
+}
+
 // Closed form of the infprobs / homozyg accumulators (cnf2_accum.h) at one marker: wg[8][64] = weight of
 // (shift mode, state) or 0 where the reference skips the mode; inf_out[7][2][2], hz_out[2].
 int shim_accum_infprobs(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,

@@ -146,6 +146,23 @@ def test_fast_tile_producer_matches_general_producer(shim, seed):
                     np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
 
 
+@pytest.mark.parametrize("seed", [31, 32])
+def test_table_form_of_the_tile_producer_is_identical(shim, seed):
+    """The two-phase tile producer (7 per-slot match records shared by the 8 parts, SlotTable) must give
+    exactly the tables of the form that redoes the match logic in every part (SlotDirect)."""
+    for ped in (synth.make_random_windows(40, 4, seed=seed),
+                synth.make_outbred3(2, 3, 9, 1, seed=seed, missing=0.3, random_hw=True, random_sure=True)):
+        a = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
+        b = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
+        for ind in ped.dous:
+            for m in range(ped.n_markers):
+                args = _ped_args(ped) + [_p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, int(ind), m]
+                shim.shim_emtab_fast(*args, *[_p(x) for x in a])
+                shim.shim_emtab_tables(*args, *[_p(x) for x in b])
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y)
+
+
 def _mode_weights(o, ped, ind, m):
     """wg[s][g] = exp(scales - factor) * alphaminus_s(g) * beta_s(g) from the oracle's store, 0 for the
     modes HOT LOOP 2 skips (cnF2freq.cpp:5420-5421)."""
