@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--full-spill", action="store_true", help="A/B: store alpha-minus at every marker (CNF2_FULL_SPILL)")
     ap.add_argument("--extra-flags", type=int, default=0,
                     help="tuning aid: OR into the sweep flags (2 = CNF2_NO_DOSAGE, forward pass only); not the metric")
+    ap.add_argument("--no-merge-probe", action="store_true",
+                    help="skip the extra CNF2_MERGE_MODES sweeps reported next to the headline (N = 1 only)")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each step's gather before the next sweep (default: the gather of step k runs "
@@ -337,6 +339,27 @@ def main():
         }
         del rs, fmx, lse
         ll = loglik.cpu().numpy()
+        # outside the timed region and after the checks, rank 0 at N = 1: the same sweep with CNF2_MERGE_MODES
+        # (exact; the F2's empty F1 parents make the four shift modes that share s0 bit-identical, see DESIGN.md
+        # 5b) -- reported next to the headline, never as the headline
+        merge_info = None
+        if world == 1 and not args.extra_flags and not args.full_spill and not args.no_merge_probe:
+            ns = min(n, 512)
+            rows_h = dosage[:ns].clone()
+            ll_h = loglik.clone()
+            ms_m = []
+            for _ in range(2):
+                ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(), capi.MERGE_MODES)
+                ctx.sync()
+                ms_m.append(ctx.last_kernel_ms())
+            merge_info = {"value": float(n) * M / (ms_m[-1] * 1e-3), "unit": "individual*marker/s",
+                          "kernel_ms": ms_m[-1], "kernel": "cnf2::fb_packed_kernel",
+                          "loglik_bit_identical": bool(torch.equal(loglik, ll_h)),
+                          "rows_max_abs_diff": float((dosage[:ns] - rows_h).abs().max().item()),
+                          "note": "CNF2_MERGE_MODES: modes differing only in the shift bits of parents that are "
+                                  "homozygous everywhere are swept once; all 8 modes are output"}
+            del rows_h, ll_h
+
         out = {
             "metric": "individual*marker fwd-bwd steps/sec (all 8 shift modes, forward+backward, dosage rows)",
             "value": value, "unit": "individual*marker/s", "n_gpus": world, "steps": args.steps,
@@ -357,6 +380,8 @@ def main():
             "checks": checks,
             "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,
         }
+        if merge_info:
+            out["merge_modes"] = merge_info
         if args.cpu_seconds > 0 and world == 1:      # CPU baseline leg: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(sample, pos, starts, args)
