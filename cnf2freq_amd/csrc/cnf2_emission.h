@@ -53,7 +53,9 @@ struct LineCfg {
     int      sp;         // shift bit of this parent (localshift at genwidth 2)
 };
 
-enum { SLOT_PRESENT = 1, SLOT_FOUNDER = 2, SLOT_RESTRICT0 = 4 };
+// SLOT_HOM: the slot's genotype row is homozygous (or doubly unknown) with equal sure at EVERY marker
+// (derived from the data, not from the pedigree): its two allele indices are then interchangeable
+enum { SLOT_PRESENT = 1, SLOT_FOUNDER = 2, SLOT_RESTRICT0 = 4, SLOT_HOM = 8 };
 
 // Terms of one table entry.  For parent allele fp and grandparent allele fg:
 //   value = sum_fp base[fp] * (sum_fg ot[fp][fg]) * (sum_fg tr[fp][fg])

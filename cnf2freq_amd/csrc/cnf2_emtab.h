@@ -183,10 +183,14 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // cw[s0] = root weight c_f(s0) (written by every lane; identical across parts with equal f).
 // `out(kind, e, v)` receives entry e of table kind (0 tot, 1 restricted, 2 class-2) as soon as it is known
 // (the tile producer stores it straight into LDS: nothing is held in registers until the end).
-template <bool CLASSES, class VR, class VP, class VT, class VO, class Out>
+// HOMPAR: the caller guarantees that the parent is homozygous with equal sure at this marker (SLOT_HOM): the
+// terms of its two allele indices are then the same numbers and only fp = 0 is evaluated (the parent's phase
+// weights are 0/1, so  wl0 * h + w1 * h  ==  (wl0 + w1) * h  bit for bit).
+template <bool CLASSES, bool HOMPAR, class VR, class VP, class VT, class VO, class Out>
 CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
                               Out&& out, double cw[2])
 {
+    constexpr int NFP = HOMPAR ? 1 : 2;
     // ---- root (cnF2freq.cpp:1191-1245 at genwidth 4, inmarkerval unknown)
     const int    mf = root.allele(c.f), mo = root.allele(c.f ^ 1);
     const double sf = root.sure(c.f), so_r = root.sure(c.f ^ 1);
@@ -227,6 +231,16 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     pw[1] = par.w(1);
 #pragma unroll
     for (int fp = 0; fp < 2; fp++) {
+        if (HOMPAR && fp == 1) {
+            alpha[1] = alpha[0];
+            beta[1]  = beta[0];
+            bzero[1] = bzero[0];
+            pis2[1]  = pis2[0];
+            vtr[1]   = vtr[0];
+            vot[1]   = vot[0];
+            so_p[1]  = so_p[0];
+            continue;
+        }
         double Bp, Kp, Cp;
         int    mv;
         par.match(inmv, fp, &Bp, &Kp, &Cp, &mv);
@@ -279,7 +293,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     double G[3][2][2];       // [kind][fp][bit_tr]   traced line: alpha * t0 + beta * t1
     double OO[2][2][2];      // [kind 0/1][fp][bit_ot] other line (never carries the class: kind 2 uses kind 1)
 #pragma unroll
-    for (int fp = 0; fp < 2; fp++) {
+    for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
         leaf_make(trs, c.tr, vtr[fp], pis2[fp], &L);
 #pragma unroll
@@ -293,7 +307,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     }
     CNF2_SCHED_FENCE();
 #pragma unroll
-    for (int fp = 0; fp < 2; fp++) {
+    for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
         leaf_make(ots, c.ot, vot[fp], false, &L);
 #pragma unroll
@@ -329,25 +343,26 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
                 for (int bt = 0; bt < 2; bt++)
                     out(kind, sp * 4 + bo * 2 + bt,
-                        w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]));
+                        HOMPAR ? (w0 + w1) * (OO[ko][0][bo] * G[kind][0][bt])
+                               : w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]));
         }
     }
 }
 
 // from raw slot data (every part does its own match logic)
-template <bool CLASSES, class Out>
+template <bool CLASSES, bool HOMPAR = false, class Out>
 CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
                            Out&& out, double cw[2])
 {
-    emtab_part_views<CLASSES>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
+    emtab_part_views<CLASSES, HOMPAR>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
 }
 
 // from the 7 slot records of the marker (`recs` = 7 x SLOTTAB_DOUBLES, slot order of the window)
-template <bool CLASSES, class Out>
+template <bool CLASSES, bool HOMPAR = false, class Out>
 CNF2_HD void emtab_part_tables(const PartCfg& c, const double* recs, Out&& out, double cw[2])
 {
     const int sp = 1 + 3 * c.P;
-    emtab_part_views<CLASSES>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
+    emtab_part_views<CLASSES, HOMPAR>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + c.firstpar) * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + (c.firstpar ^ 1)) * SLOTTAB_DOUBLES), out, cw);
 }

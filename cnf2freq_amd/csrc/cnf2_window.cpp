@@ -80,6 +80,7 @@ void derive_window(const HostPedigree& P, int rec, Window* w, int32_t* slot_rec_
         uint8_t f   = SLOT_PRESENT;
         if (P.founder[r]) f |= SLOT_FOUNDER;
         if ((flag2ignore >> i) & 1) f |= SLOT_RESTRICT0;
+        if (!P.row_hom.empty() && P.row_hom[P.row_of[r]]) f |= SLOT_HOM;
         w->flags[i] = f;
     }
     // relmap groups: one ancestor in several (non-ignored) slots (cnF2freq.cpp:3130,3147)

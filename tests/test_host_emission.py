@@ -163,6 +163,23 @@ def test_table_form_of_the_tile_producer_is_identical(shim, seed):
                     assert np.array_equal(x, y)
 
 
+def test_single_parent_allele_shortcut_is_identical(shim):
+    """HOMPAR: where the parent is homozygous with equal sure, evaluating one of its allele indices gives
+    exactly the same tables (F2 with empty F1 parents; random windows with missing data)."""
+    used = 0
+    for ped in (synth.make_f2(4, 9, 1, seed=3, chrom_cm=30.0, missing=0.2), synth.make_random_windows(40, 4, seed=77)):
+        a = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
+        b = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
+        for ind in ped.dous:
+            for m in range(ped.n_markers):
+                args = _ped_args(ped) + [_p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, int(ind), m]
+                shim.shim_emtab_fast(*args, *[_p(x) for x in a])
+                used += shim.shim_emtab_hompar(*args, *[_p(x) for x in b])
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y)
+    assert used > 100
+
+
 def _mode_weights(o, ped, ind, m):
     """wg[s][g] = exp(scales - factor) * alphaminus_s(g) * beta_s(g) from the oracle's store, 0 for the
     modes HOT LOOP 2 skips (cnF2freq.cpp:5420-5421)."""
