@@ -470,21 +470,31 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     std::vector<uint8_t>   packed(merge ? n : 0, 0);
     std::vector<PackedJob> pjobs;
     if (merge) {
-        std::vector<int> el;
-        for (int j = 0; j < n; j++)
-            if (mergeable(ctx->windows[ind_begin + j])) el.push_back(j);
-        const size_t full = el.size() / 4 * 4;
-        for (size_t k = 0; k < full; k++) packed[el[k]] = 1;
-        for (int c = 0; c < ctx->n_chrom; c++)
-            for (size_t k = 0; k < full; k += 4) {
-                PackedJob pj;
-                for (int i = 0; i < 4; i++) pj.ind[i] = el[k + i];
-                pj.first = ctx->chromstarts[c];
-                pj.last  = ctx->chromstarts[c + 1] - 1;
-                pj.chrom = c;
-                pj.pad   = 0;
-                pjobs.push_back(pj);
+        // a group shares the producer's instantiation: windows whose grandparents are all present and
+        // homozygous everywhere (SLOT_HOM) are grouped apart from the others
+        auto homleaf = [&](const Window& w) {
+            const int gp = w.flags[2] & w.flags[3] & w.flags[5] & w.flags[6];
+            return (gp & SLOT_HOM) && (gp & SLOT_PRESENT);
+        };
+        for (int cls = 0; cls < 2; cls++) {
+            std::vector<int> el;
+            for (int j = 0; j < n; j++) {
+                const Window& w = ctx->windows[ind_begin + j];
+                if (mergeable(w) && (homleaf(w) ? 1 : 0) == cls) el.push_back(j);
             }
+            const size_t full = el.size() / 4 * 4;
+            for (size_t k = 0; k < full; k++) packed[el[k]] = 1;
+            for (int c = 0; c < ctx->n_chrom; c++)
+                for (size_t k = 0; k < full; k += 4) {
+                    PackedJob pj;
+                    for (int i = 0; i < 4; i++) pj.ind[i] = el[k + i];
+                    pj.first   = ctx->chromstarts[c];
+                    pj.last    = ctx->chromstarts[c + 1] - 1;
+                    pj.chrom   = c;
+                    pj.homleaf = cls;
+                    pjobs.push_back(pj);
+                }
+        }
     }
     const size_t n_packed = pjobs.size();
     std::vector<Job> jobs;

@@ -29,7 +29,8 @@ struct Job {
 // Four jobs of the same chromosome swept by one wavefront (fb_packed_kernel).
 struct PackedJob {
     int32_t ind[4];
-    int32_t first, last, chrom, pad;
+    int32_t first, last, chrom;
+    int32_t homleaf;   // all four jobs: the grandparents are present and homozygous everywhere too (HOMLEAF)
 };
 
 struct KernelParams {

@@ -133,7 +133,10 @@ struct Leaf {
     double m1, i2[2];
 };
 
-template <class View>
+// HOMLEAF: the caller guarantees that the slot is present and homozygous with equal sure at this marker: both
+// allele indices match the incoming value alike, so one match is evaluated (its weights are 0/1, the sums over
+// fg keep their bits).
+template <bool HOMLEAF = false, class View>
 CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Leaf* L)
 {
     const bool present = (flags & SLOT_PRESENT) != 0;
@@ -143,6 +146,11 @@ CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Le
     double t0[2], t1[2];
 #pragma unroll
     for (int fg = 0; fg < 2; fg++) {
+        if (HOMLEAF && fg == 1) {
+            t0[1] = t0[0];
+            t1[1] = t1[0];
+            continue;
+        }
         double Bv, K, C;
         int    mv;
         d.match(v, fg, &Bv, &K, &C, &mv);
@@ -186,7 +194,7 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // HOMPAR: the caller guarantees that the parent is homozygous with equal sure at this marker (SLOT_HOM): the
 // terms of its two allele indices are then the same numbers and only fp = 0 is evaluated (the parent's phase
 // weights are 0/1, so  wl0 * h + w1 * h  ==  (wl0 + w1) * h  bit for bit).
-template <bool CLASSES, bool HOMPAR, class VR, class VP, class VT, class VO, class Out>
+template <bool CLASSES, bool HOMPAR, bool HOMLEAF, class VR, class VP, class VT, class VO, class Out>
 CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
                               Out&& out, double cw[2])
 {
@@ -295,7 +303,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make(trs, c.tr, vtr[fp], pis2[fp], &L);
+        leaf_make<HOMLEAF>(trs, c.tr, vtr[fp], pis2[fp], &L);
 #pragma unroll
         for (int kind = 0; kind < KINDS; kind++)
 #pragma unroll
@@ -309,7 +317,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make(ots, c.ot, vot[fp], false, &L);
+        leaf_make<HOMLEAF>(ots, c.ot, vot[fp], false, &L);
 #pragma unroll
         for (int kind = 0; kind < (CLASSES ? 2 : 1); kind++)
 #pragma unroll
@@ -350,19 +358,19 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 }
 
 // from raw slot data (every part does its own match logic)
-template <bool CLASSES, bool HOMPAR = false, class Out>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, class Out>
 CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
                            Out&& out, double cw[2])
 {
-    emtab_part_views<CLASSES, HOMPAR>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
 }
 
 // from the 7 slot records of the marker (`recs` = 7 x SLOTTAB_DOUBLES, slot order of the window)
-template <bool CLASSES, bool HOMPAR = false, class Out>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, class Out>
 CNF2_HD void emtab_part_tables(const PartCfg& c, const double* recs, Out&& out, double cw[2])
 {
     const int sp = 1 + 3 * c.P;
-    emtab_part_views<CLASSES, HOMPAR>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + c.firstpar) * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + (c.firstpar ^ 1)) * SLOTTAB_DOUBLES), out, cw);
 }

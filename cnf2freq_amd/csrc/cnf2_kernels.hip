@@ -591,7 +591,7 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
 }
 
 // the table row c.mi of the tile from this lane's raw inputs (valid: the row's marker exists)
-template <bool CLASSES, bool HOMPAR = false>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false>
 __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool valid, const RawSlots& raw)
 {
     if (valid) {
@@ -606,7 +606,7 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         // two lane-dependent offsets are per-job constants, so no value is ever selected.  Entries are stored
         // as they are formed: the producer holds no output array in registers.
         double* rb = row + c.idx_base;
-        emtab_part_to<CLASSES, HOMPAR>(c.pc, root, par, tr, ot,
+        emtab_part_to<CLASSES, HOMPAR, HOMLEAF>(c.pc, root, par, tr, ot,
                                [&](int kind, int e, double v) {
                                    const int b  = e & 3;
                                    const int k  = b == 0 ? 0 : (b == 1 ? c.idx_k01 : (b == 2 ? c.idx_k10 : 6));
@@ -622,14 +622,16 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         if (c.part == 0) *(double2*)(row + TAB_T) = raw.tq;
     }
 }
-// hompar (wave-uniform): both parents of the window are homozygous with equal sure at every marker
-// (SLOT_HOM), so each part evaluates one allele index of its parent (cnf2_emtab.h HOMPAR)
+// hom (wave-uniform): 1 = both parents of the window are homozygous with equal sure at every marker (SLOT_HOM),
+// so each part evaluates one allele index of its parent (cnf2_emtab.h HOMPAR); 2 = the four grandparents are
+// present and homozygous everywhere as well (HOMLEAF) -- the F2 with empty F1 parents and inbred founders
 template <bool CLASSES>
 __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
-                                             const RawSlots& raw, bool hompar)
+                                             const RawSlots& raw, int hom)
 {
-    if (hompar) produce_row<CLASSES, true>(c, tab, m0 + c.mi <= last, raw);
-    else produce_row<CLASSES, false>(c, tab, m0 + c.mi <= last, raw);
+    if (hom == 2) produce_row<CLASSES, true, true>(c, tab, m0 + c.mi <= last, raw);
+    else if (hom == 1) produce_row<CLASSES, true, false>(c, tab, m0 + c.mi <= last, raw);
+    else produce_row<CLASSES, false, false>(c, tab, m0 + c.mi <= last, raw);
 }
 
 // Raw inputs of one lane of the tile producer's first phase (ONE window member at one marker), requested a
@@ -659,7 +661,7 @@ __device__ __forceinline__ void load_raw1_at(const KernelParams& p, const FastCt
 // data of one window member into its match record (cnf2_emtab.h slot_table: 20 doubles in the row itself); then
 // lanes (part, row) combine the records of their line into their 8 entries per table kind and, once every
 // lane has read what it needs, store them over the records.
-template <bool CLASSES, bool HOMPAR = false>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false>
 __device__ __forceinline__ void produce_row2(const FastCtx& c, double* tab, bool valid, const RawOne& raw)
 {
     double* row = tab + c.mi * TAB_STRIDE;
@@ -668,7 +670,7 @@ __device__ __forceinline__ void produce_row2(const FastCtx& c, double* tab, bool
     wave_lds_fence();
     double tot[8], rtot[8], two[8], cw[2];
     if (valid)
-        emtab_part_tables<CLASSES, HOMPAR>(c.pc, row,
+        emtab_part_tables<CLASSES, HOMPAR, HOMLEAF>(c.pc, row,
                                    [&](int kind, int e, double v) { (kind == 0 ? tot : (kind == 1 ? rtot : two))[e] = v; }, cw);
     wave_lds_fence();
     if (valid) {
@@ -755,7 +757,13 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         c.idx_k01   = part_entry_index(c.part, 1) - c.idx_base;
         c.idx_k10   = part_entry_index(c.part, 2) - c.idx_base;
         c.row_root  = w.row[0];
-        const bool hompar = __builtin_amdgcn_readfirstlane((int)(w.flags[1] & w.flags[4] & SLOT_HOM)) != 0;
+        int hom = 0;
+        if (w.flags[1] & w.flags[4] & SLOT_HOM) {
+            hom = 1;
+            const int gp = w.flags[2] & w.flags[3] & w.flags[5] & w.flags[6];
+            if ((gp & SLOT_HOM) && (gp & SLOT_PRESENT)) hom = 2;
+        }
+        hom = __builtin_amdgcn_readfirstlane(hom);
         const int s = lane >> 3;
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (t == 0)
 #endif
             {
-                produce_tile<false>(p, c, tab, m0, last, raw, hompar);
+                produce_tile<false>(p, c, tab, m0, last, raw, hom);
                 if (t + 1 < ntile) load_raw<0>(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
             }
             wave_lds_fence();
@@ -982,7 +990,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
             if (t == ntile - 1)
 #endif
-            produce_tile<true>(p, c, tab, m0, last, raw, hompar);
+            produce_tile<true>(p, c, tab, m0, last, raw, hom);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             int       i    = mend - m0;                 // local index; its parity is the parity of m - first
@@ -1133,7 +1141,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
         load_raw1_at<0>(p, c, first + pmt, first, last, &raw);
         for (int t = 0; t < ntile; t++) {
             const int m0 = first + t * 2;
-            produce_row2<false, true>(c, tab, m0 + pmt <= last, raw);
+            if (pj.homleaf) produce_row2<false, true, true>(c, tab, m0 + pmt <= last, raw);
+            else produce_row2<false, true, false>(c, tab, m0 + pmt <= last, raw);
             if (t + 1 < ntile) load_raw1_at<0>(p, c, m0 + 2 + pmt, first, last, &raw);
             wave_lds_fence();
             fwd_step(even_t(), myrow0, m0);
@@ -1262,7 +1271,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
         load_raw1_at<-1>(p, c, first + (ntile - 1) * 2 + pmt, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 2;
-            produce_row2<true, true>(c, tab, m0 + pmt <= last, raw);
+            if (pj.homleaf) produce_row2<true, true, true>(c, tab, m0 + pmt <= last, raw);
+            else produce_row2<true, true, false>(c, tab, m0 + pmt <= last, raw);
             wave_lds_fence();
             if (m0 < last) marker(odd_t(), myrow1, m0 + 1);
             marker(even_t(), myrow0, m0);

@@ -145,11 +145,15 @@ int shim_emtab_hompar(int n_rec, const int32_t* par, const uint8_t* empty, const
         make_part(w, part, &c, &rp, &rt, &ro);
         double t[8], r[8], t2[8], cw[2];
         auto sink = [&](int kind, int e, double v) { (kind == 0 ? t : (kind == 1 ? r : t2))[e] = v; };
-        const Slot ps = slot_at(rp);
-        if (ps.a0 == ps.a1 && ps.s0 == ps.s1) {
-            emtab_part_to<true, true>(c, root, ps, slot_at(rt), slot_at(ro), sink, cw);
+        const Slot ps = slot_at(rp), ts = slot_at(rt), os = slot_at(ro);
+        auto hom = [](const Slot& d) { return d.a0 == d.a1 && d.s0 == d.s1; };
+        if (hom(ps) && (c.tr & SLOT_PRESENT) && (c.ot & SLOT_PRESENT) && hom(ts) && hom(os)) {
+            emtab_part_to<true, true, true>(c, root, ps, ts, os, sink, cw);
+            used += 1000;
+        } else if (hom(ps)) {
+            emtab_part_to<true, true, false>(c, root, ps, ts, os, sink, cw);
             used++;
-        } else emtab_part_to<true, false>(c, root, ps, slot_at(rt), slot_at(ro), sink, cw);
+        } else emtab_part_to<true, false, false>(c, root, ps, ts, os, sink, cw);
         for (int e = 0; e < 8; e++) {
             int idx = part_entry_index(part, e);
             tot[idx] = t[e];
