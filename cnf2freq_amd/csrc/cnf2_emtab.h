@@ -194,7 +194,9 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // HOMPAR: the caller guarantees that the parent is homozygous with equal sure at this marker (SLOT_HOM): the
 // terms of its two allele indices are then the same numbers and only fp = 0 is evaluated (the parent's phase
 // weights are 0/1, so  wl0 * h + w1 * h  ==  (wl0 + w1) * h  bit for bit).
-template <bool CLASSES, bool HOMPAR, bool HOMLEAF, class VR, class VP, class VT, class VO, class Out>
+// NORESTR: the caller guarantees that no slot of the window is restricted (flag2ignore == 0, a complete
+// window): the restricted table is the unrestricted one, bit for bit, and is copied instead of recomputed.
+template <bool CLASSES, bool HOMPAR, bool HOMLEAF, bool NORESTR, class VR, class VP, class VT, class VO, class Out>
 CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
                               Out&& out, double cw[2])
 {
@@ -305,13 +307,15 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
         Leaf L;
         leaf_make<HOMLEAF>(trs, c.tr, vtr[fp], pis2[fp], &L);
 #pragma unroll
-        for (int kind = 0; kind < KINDS; kind++)
+        for (int kind = 0; kind < KINDS; kind++) {
+            if (NORESTR && kind == 1) continue;
 #pragma unroll
             for (int bit = 0; bit < 2; bit++) {
                 double t0, t1;
                 leaf_value(L, bit, kind, &t0, &t1);
                 G[kind][fp][bit] = alpha[fp] * t0 + beta[fp] * t1;
             }
+        }
     }
     CNF2_SCHED_FENCE();
 #pragma unroll
@@ -319,7 +323,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
         Leaf L;
         leaf_make<HOMLEAF>(ots, c.ot, vot[fp], false, &L);
 #pragma unroll
-        for (int kind = 0; kind < (CLASSES ? 2 : 1); kind++)
+        for (int kind = 0; kind < ((CLASSES && !NORESTR) ? 2 : 1); kind++)
 #pragma unroll
             for (int bit = 0; bit < 2; bit++) {
                 double o0, o1;
@@ -341,28 +345,31 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     // grandparent is pars[firstpar], so (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr) : (bit_tr, bit_ot))
 #pragma unroll
     for (int kind = 0; kind < KINDS; kind++) {
-        const int ko = kind == 2 ? 1 : kind;
+        if (NORESTR && kind == 1) continue;
+        const int ko = NORESTR ? 0 : (kind == 2 ? 1 : kind);
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
             const double w0 = wl[sp][0];
-            const double w1 = kind >= 1 ? pm1 * wl[sp][1] : wl[sp][1];
+            const double w1 = (kind >= 1 && !NORESTR) ? pm1 * wl[sp][1] : wl[sp][1];
 #pragma unroll
             for (int bo = 0; bo < 2; bo++)
 #pragma unroll
-                for (int bt = 0; bt < 2; bt++)
-                    out(kind, sp * 4 + bo * 2 + bt,
-                        HOMPAR ? (w0 + w1) * (OO[ko][0][bo] * G[kind][0][bt])
-                               : w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]));
+                for (int bt = 0; bt < 2; bt++) {
+                    const double v = HOMPAR ? (w0 + w1) * (OO[ko][0][bo] * G[kind][0][bt])
+                                            : w0 * (OO[ko][0][bo] * G[kind][0][bt]) + w1 * (OO[ko][1][bo] * G[kind][1][bt]);
+                    out(kind, sp * 4 + bo * 2 + bt, v);
+                    if (NORESTR && CLASSES && kind == 0) out(1, sp * 4 + bo * 2 + bt, v);
+                }
         }
     }
 }
 
 // from raw slot data (every part does its own match logic)
-template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, class Out>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, class Out>
 CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
                            Out&& out, double cw[2])
 {
-    emtab_part_views<CLASSES, HOMPAR, HOMLEAF>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, NORESTR>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
 }
 
 // from the 7 slot records of the marker (`recs` = 7 x SLOTTAB_DOUBLES, slot order of the window)
@@ -370,7 +377,7 @@ template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, class Out>
 CNF2_HD void emtab_part_tables(const PartCfg& c, const double* recs, Out&& out, double cw[2])
 {
     const int sp = 1 + 3 * c.P;
-    emtab_part_views<CLASSES, HOMPAR, HOMLEAF>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, false>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + c.firstpar) * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + (c.firstpar ^ 1)) * SLOTTAB_DOUBLES), out, cw);
 }

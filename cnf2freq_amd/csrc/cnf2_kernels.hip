@@ -591,7 +591,7 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
 }
 
 // the table row c.mi of the tile from this lane's raw inputs (valid: the row's marker exists)
-template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false>
 __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool valid, const RawSlots& raw)
 {
     if (valid) {
@@ -606,7 +606,7 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         // two lane-dependent offsets are per-job constants, so no value is ever selected.  Entries are stored
         // as they are formed: the producer holds no output array in registers.
         double* rb = row + c.idx_base;
-        emtab_part_to<CLASSES, HOMPAR, HOMLEAF>(c.pc, root, par, tr, ot,
+        emtab_part_to<CLASSES, HOMPAR, HOMLEAF, NORESTR>(c.pc, root, par, tr, ot,
                                [&](int kind, int e, double v) {
                                    const int b  = e & 3;
                                    const int k  = b == 0 ? 0 : (b == 1 ? c.idx_k01 : (b == 2 ? c.idx_k10 : 6));
@@ -624,13 +624,16 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
 }
 // hom (wave-uniform): 1 = both parents of the window are homozygous with equal sure at every marker (SLOT_HOM),
 // so each part evaluates one allele index of its parent (cnf2_emtab.h HOMPAR); 2 = the four grandparents are
-// present and homozygous everywhere as well (HOMLEAF) -- the F2 with empty F1 parents and inbred founders
+// present and homozygous everywhere as well (HOMLEAF) -- the F2 with empty F1 parents and inbred founders;
+// 3 = no slot of the window is restricted (flag2ignore == 0: a complete window): the restricted table is a
+// copy of the unrestricted one (NORESTR)
 template <bool CLASSES>
 __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
                                              const RawSlots& raw, int hom)
 {
     if (hom == 2) produce_row<CLASSES, true, true>(c, tab, m0 + c.mi <= last, raw);
     else if (hom == 1) produce_row<CLASSES, true, false>(c, tab, m0 + c.mi <= last, raw);
+    else if (hom == 3 && CLASSES) produce_row<CLASSES, false, false, true>(c, tab, m0 + c.mi <= last, raw);
     else produce_row<CLASSES, false, false>(c, tab, m0 + c.mi <= last, raw);
 }
 
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             const int gp = w.flags[2] & w.flags[3] & w.flags[5] & w.flags[6];
             if ((gp & SLOT_HOM) && (gp & SLOT_PRESENT)) hom = 2;
         }
+        if (hom == 0 && w.flag2ignore == 0) hom = 3;
         hom = __builtin_amdgcn_readfirstlane(hom);
         const int s = lane >> 3;
         c.s0 = s & 1;

@@ -153,6 +153,9 @@ int shim_emtab_hompar(int n_rec, const int32_t* par, const uint8_t* empty, const
         } else if (hom(ps)) {
             emtab_part_to<true, true, false>(c, root, ps, ts, os, sink, cw);
             used++;
+        } else if (w.flag2ignore == 0) {
+            emtab_part_to<true, false, false, true>(c, root, ps, ts, os, sink, cw);
+            used += 1000000;
         } else emtab_part_to<true, false, false>(c, root, ps, ts, os, sink, cw);
         for (int e = 0; e < 8; e++) {
             int idx = part_entry_index(part, e);

@@ -168,7 +168,8 @@ def test_single_parent_allele_shortcut_is_identical(shim):
     of the allele indices gives exactly the same tables (F2 with empty F1 parents and inbred founders; random
     windows with missing data)."""
     used = 0
-    for ped in (synth.make_f2(4, 9, 1, seed=3, chrom_cm=30.0, missing=0.2), synth.make_random_windows(40, 4, seed=77)):
+    for ped in (synth.make_f2(4, 9, 1, seed=3, chrom_cm=30.0, missing=0.2), synth.make_random_windows(40, 4, seed=77),
+                synth.make_outbred3(3, 3, 9, 1, seed=5, missing=0.2, random_hw=True, random_sure=True)):
         a = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
         b = [np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)]
         for ind in ped.dous:
@@ -178,7 +179,8 @@ def test_single_parent_allele_shortcut_is_identical(shim):
                 used += shim.shim_emtab_hompar(*args, *[_p(x) for x in b])
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y)
-    assert used % 1000 > 100 and used // 1000 > 100      # both shortcuts were exercised
+    # all three shortcuts were exercised (NORESTR: complete windows, flag2ignore == 0)
+    assert used % 1000 > 100 and (used // 1000) % 1000 > 100 and used // 1000000 > 100
 
 
 def _mode_weights(o, ped, ind, m):
