@@ -949,6 +949,107 @@ void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int las
     cnf2o_fwbw_free(W);
 }
 
+/* individ::descendants as postmarkerdata leaves it (cpp:3224-3255): every individual sends max(1, own count) to
+ * both parents until nothing changes; zeros become 1.  (Restated without a pin: that loop is outside the
+ * reference extract.  cnf2o_accumulate takes the counts as an input.) */
+void cnf2o_descendants(const cnf2o_ped *P, int32_t *desc)
+{
+    int32_t *upsent = (int32_t *)calloc((size_t)P->n_rec, sizeof(int32_t));
+    memset(desc, 0, sizeof(int32_t) * (size_t)P->n_rec);
+    int any;
+    do {
+        any = 0;
+        for (int r = 0; r < P->n_rec; r++) {
+            int now = desc[r] ? desc[r] : 1;
+            now -= upsent[r];
+            if (now > 0) {
+                for (int k = 0; k < 2; k++)
+                    if (P->par[r * 2 + k] >= 0) desc[P->par[r * 2 + k]] += now;
+                upsent[r] += now;
+                any = 1;
+            }
+        }
+    } while (any);
+    for (int r = 0; r < P->n_rec; r++)
+        if (!desc[r]) desc[r] = 1;
+    free(upsent);
+}
+
+/* HOT LOOP 2 with its reductions (cpp:5416-5577, 5876-5902) for a list of individuals, in list order:
+ * per marker the thread-private accumulators (cnf2o_haplos_row / cnf2o_infprobs_row), then
+ *   sum = 1 / sum of infprobs[self][allele index 0][.];  homozyg[marker][.] *= sum           cpp:5880-5890
+ *   moveinfprobs (cpp:3577-3597): target.infprobs[marker][side][val] += value * sum * 2 / 2^(slots the member
+ *       occupies in reltreeordered) * descendants
+ *   movehaplos (cpp:3599-3616): if the pair is non-zero and |haploweight - 0.5| < 0.5 - 1e-12:
+ *       haplobase += b1 / (b1 + b2) * descendants, haplocount += descendants, b = haplos + e^-400 maxdiff^2 / 2
+ * for every member of reltree (all existing window members; reltreeordered holds the non-empty ones only).
+ * inf_out[n_rec][nm][2][2], hb_out / hc_out[n_rec][nm], hz_out[n_ind][nm][2]; nm = last - first + 1. */
+void cnf2o_accumulate(const cnf2o_ped *P, const int *inds, const int *gens, int n_ind, int first, int last,
+                      const int32_t *desc, double *inf_out, double *hb_out, double *hc_out, double *hz_out)
+{
+    const int   nm      = last - first + 1;
+    const float maxdiff = 0.000005f;                                           /* cpp:228 */
+    memset(inf_out, 0, sizeof(double) * 4 * (size_t)P->n_rec * nm);
+    memset(hb_out, 0, sizeof(double) * (size_t)P->n_rec * nm);
+    memset(hc_out, 0, sizeof(double) * (size_t)P->n_rec * nm);
+    memset(hz_out, 0, sizeof(double) * 2 * (size_t)n_ind * nm);
+    double *inf = (double *)malloc(sizeof(double) * 4 * (size_t)P->n_rec);
+    double *hap = (double *)malloc(sizeof(double) * 2 * (size_t)P->n_rec);
+    for (int j = 0; j < n_ind; j++) {
+        const int ind = inds[j], gen = gens[j];
+        double factors[NUMSHIFTS], factor;
+        if (!cnf2o_sweep_ind(P, ind, gen, first, last, factors, &factor, NULL, 0, NULL)) continue;
+        cnf2o_tree T;
+        cnf2o_fixtrees(P, ind, &T);
+        const double descf = desc[ind];
+        for (int m = first; m <= last; m++) {
+            double hz[2];
+            cnf2o_infprobs_row(P, ind, gen, first, last, m, inf, hz);
+            cnf2o_haplos_row(P, ind, gen, first, last, m, hap);
+            double sum = 0;
+            for (int v = 0; v < 2; v++) sum += inf[(ind * 2 + 0) * 2 + v];
+            sum = 1 / sum;
+            for (int v = 0; v < 2; v++) hz_out[((size_t)j * nm + (m - first)) * 2 + v] = hz[v] * sum;
+            /* reltree: every existing window member, empty or not, once (cpp:3109,3136,3152,3183-3184) */
+            int members[7], n_members = 0;
+            members[n_members++] = ind;
+            for (int l1 = 0; l1 < 2; l1++) {
+                const int p1 = P->par[ind * 2 + l1];
+                if (p1 < 0) continue;
+                members[n_members++] = p1;
+                for (int l2 = 0; l2 < 2; l2++)
+                    if (P->par[p1 * 2 + l2] >= 0) members[n_members++] = P->par[p1 * 2 + l2];
+            }
+            for (int k = 0; k < n_members; k++) {
+                const int r = members[k];
+                int dup = 0;
+                for (int k2 = 0; k2 < k; k2++) dup |= (members[k2] == r);
+                if (dup) continue;
+                double norm = sum;
+                norm *= 2;
+                for (int s7 = 0; s7 < 7; s7++)
+                    if (T.ordered[s7] == r) norm /= 2;
+                norm *= descf;
+                const size_t o = (size_t)r * nm + (m - first);
+                for (int side = 0; side < 2; side++)
+                    for (int v = 0; v < 2; v++)
+                        inf_out[(o * 2 + side) * 2 + v] += inf[(r * 2 + side) * 2 + v] * norm;
+                if (hap[r * 2] || hap[r * 2 + 1]) {
+                    const double hw = P->hw[(size_t)r * P->n_markers + m];
+                    if (fabs(hw - 0.5) < 0.5 - 1e-12) {
+                        double b1 = hap[r * 2] + exp(-400) * maxdiff * maxdiff * 0.5;
+                        double b2 = hap[r * 2 + 1] + exp(-400) * maxdiff * maxdiff * 0.5;
+                        hb_out[o] += b1 / (b1 + b2) * descf;
+                        hc_out[o] += descf;
+                    }
+                }
+            }
+        }
+    }
+    free(inf);
+    free(hap);
+}
+
 /* individ::addvariance (cpp:1489-1558), the emission-driven statistic postmarkerdata computes for every
  * individual and marker (cpp:3373-3389) to pick the marker whose phase gets locked: trackpossible with
  * zeropropagate = NO_EQUIVALENCE (-1: alleles are matched as usual, every level weighs 0.5 instead of the

@@ -171,6 +171,13 @@ void cnf2o_haplos_row(const cnf2o_ped *P, int ind, int gen, int first, int last,
 void cnf2o_infprobs_row(const cnf2o_ped *P, int ind, int gen, int first, int last, int marker,
                         double *inf_out, double *hz_out);
 
+/* individ::descendants (cpp:3224-3255), desc[n_rec] */
+void cnf2o_descendants(const cnf2o_ped *P, int32_t *desc);
+
+/* HOT LOOP 2 + moveinfprobs / movehaplos (cpp:5416-5577, 5876-5902, 3577-3616) for a list of individuals; see .c */
+void cnf2o_accumulate(const cnf2o_ped *P, const int *inds, const int *gens, int n_ind, int first, int last,
+                      const int32_t *desc, double *inf_out, double *hb_out, double *hc_out, double *hz_out);
+
 /* individ::addvariance (cpp:1489-1558); returns 0 (and leaves *out) when all terms are zero */
 int cnf2o_addvariance(const cnf2o_ped *P, int rec, int marker, int flag2ignore, double *out);
 

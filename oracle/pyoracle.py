@@ -102,6 +102,9 @@ def lib():
         L.cnf2o_haplos_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cnf2o_infprobs_row.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cnf2o_addvariance.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.cnf2o_descendants.argtypes = [PP, C.c_void_p]
+        L.cnf2o_accumulate.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
@@ -232,6 +235,25 @@ class OraclePed:
         hz = np.zeros(2)
         lib().cnf2o_infprobs_row(C.byref(self.c), ind, gen, first, last, marker, _ptr(inf), _ptr(hz))
         return inf, hz
+
+    def descendants(self):
+        d = np.zeros(self.R, np.int32)
+        lib().cnf2o_descendants(C.byref(self.c), _ptr(d))
+        return d
+
+    def accumulate(self, inds, gens, desc, first=0, last=None):
+        """HOT LOOP 2 + moveinfprobs/movehaplos for a list of individuals: dict(infprobs[R][nm][2][2],
+        haplobase[R][nm], haplocount[R][nm], homozyg[n][nm][2])."""
+        last = self.M - 1 if last is None else last
+        nm = last - first + 1
+        inds = np.ascontiguousarray(inds, np.int32)
+        gens = np.ascontiguousarray(gens, np.int32)
+        desc = np.ascontiguousarray(desc, np.int32)
+        inf = np.zeros((self.R, nm, 2, 2)); hb = np.zeros((self.R, nm)); hc = np.zeros((self.R, nm))
+        hz = np.zeros((len(inds), nm, 2))
+        lib().cnf2o_accumulate(C.byref(self.c), _ptr(inds), _ptr(gens), len(inds), first, last, _ptr(desc),
+                               _ptr(inf), _ptr(hb), _ptr(hc), _ptr(hz))
+        return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def addvariance(self, rec, marker, flag2ignore):
         """variances[marker] as individ::addvariance sets it (cpp:1489-1558); None when it is left alone."""

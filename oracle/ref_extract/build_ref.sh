@@ -80,6 +80,7 @@ r 2448 2514
 r 3099 3187
 r 3462 3496
 r 3553 3570
+r 3577 3616
 echo "#include \"$HERE/ref_driver.inc\"" >> "$TU"
 
 mkdir -p "$OUT"

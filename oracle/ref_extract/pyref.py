@@ -45,6 +45,8 @@ def lib(ieee=True):
         L.ref_haplos_row.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.ref_infprobs_row.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_addvariance.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.ref_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_sweep_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _libs[key] = L
     return _libs[key]
@@ -126,6 +128,18 @@ class RefPed:
         hz = np.zeros(2)
         self.L.ref_infprobs_row(marker, self.ped.n_rec, inf.ctypes.data, hz.ctypes.data)
         return inf, hz
+
+    def accumulate(self, recs, gens, desc, first=0, last=None):
+        last = self.M - 1 if last is None else last
+        nm = last - first + 1
+        ns = np.ascontiguousarray(np.asarray(recs) + 1, np.int32)
+        gens = np.ascontiguousarray(gens, np.int32)
+        desc = np.ascontiguousarray(desc, np.int32)
+        R = self.ped.n_rec
+        inf = np.zeros((R, nm, 2, 2)); hb = np.zeros((R, nm)); hc = np.zeros((R, nm)); hz = np.zeros((len(ns), nm, 2))
+        self.L.ref_accumulate(ns.ctypes.data, gens.ctypes.data, len(ns), first, last, desc.ctypes.data, R,
+                              inf.ctypes.data, hb.ctypes.data, hc.ctypes.data, hz.ctypes.data)
+        return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def addvariance(self, rec, marker, flag2ignore):
         v = C.c_double(0.0)

@@ -17,6 +17,9 @@ seeds) and the reference's outputs for them -- data only, no reference text:
   G8 haplos[n][2] left by HOT LOOP 2 (updatehaplo, HAPLOS mode) at the turn_markers  (cpp:1561-1575,5556)
   G9 infprobs[n][allele index][markerval 1,2] and the homozyg[2] increments of HOT LOOP 2 (GENOSPROBE /
      HOMOZYGOUS / GENOS modes) at the turn_markers                                       (cpp:5513-5577)
+  G11 HOT LOOP 2 with its reductions over all analysed individuals in order (moveinfprobs / movehaplos,
+     cpp:5876-5902, 3577-3616): per-record infprobs, haplobase, haplocount and per-individual homozyg, for the
+     descendant counts stored next to them (acc_desc)
   G10 variances[record][marker] of individ::addvariance with the record's own flag2ignore (NaN where the
      function leaves the entry alone)                                                    (cpp:1489-1558, 3373-3389)
 """
@@ -121,6 +124,12 @@ def generate(name):
             if v is not None:
                 variances[rec, m] = v
     out.update(variances=variances, variances_flag2ignore=var_f2i)
+    from oracle.pyoracle import OraclePed  # only for the descendant counts (an input of the reference call)
+    a_, s_, h_ = ped.dense()
+    desc = OraclePed(a_, s_, h_, ped.par, ped.empty, ped.pos).descendants()
+    acc = R.accumulate(ped.dous, ped.gen[ped.dous], desc)
+    out.update(acc_desc=desc, acc_infprobs=acc["infprobs"], acc_haplobase=acc["haplobase"],
+               acc_haplocount=acc["haplocount"], acc_homozyg=acc["homozyg"])
     out.update(fixtrees=fix, rel=rel, ordered=ordered, factors=factors, factor=factor, ok=ok,
                fwbw=fwbw, fwbwfactors=fwbwf, dosage=dosage, turn_markers=turn_markers, rawervals=rawer,
                haplos=haplos, infprobs=infprobs, homozyg=homozyg,

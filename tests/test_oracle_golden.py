@@ -136,3 +136,13 @@ def test_addvariance(golden):
             else:
                 assert got is not None
                 np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+
+
+def test_hot_loop_2_reductions(golden):
+    """HOT LOOP 2 with moveinfprobs / movehaplos (cnF2freq.cpp:5876-5902, 3577-3616) over all analysed
+    individuals in order: per-record infprobs, haplobase, haplocount, per-individual homozyg."""
+    ped, z = golden
+    o = oracle_ped(ped)
+    got = o.accumulate(ped.dous, ped.gen[ped.dous], z["acc_desc"])
+    for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+        np.testing.assert_allclose(got[k], z["acc_" + k], rtol=1e-12, atol=1e-15, equal_nan=True)
