@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_addvariance", "cnf2_emission",
+    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -69,6 +69,8 @@ def load():
         L.cnf2_infprobs.argtypes = [vp, i32, i32, i32, vp, vp, C.c_uint32]
         L.cnf2_infprobs_rows.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_addvariance.argtypes = [vp, i32, i32, vp]
+        L.cnf2_descendants.argtypes = [vp, vp]
+        L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
@@ -95,7 +97,7 @@ class Context:
         if rc != 0:
             raise Cnf2Error("cnf2_ctx_create: %s" % self.L.cnf2_last_error(None).decode())
         self.h = h
-        self.n_markers = self.n_chrom = self.n_ind = 0
+        self.n_markers = self.n_chrom = self.n_ind = self.n_rec = 0
         self.chromstarts = None
 
     def close(self):
@@ -152,6 +154,7 @@ class Context:
         self._chk(self.L.cnf2_upload_pedigree(self.h, len(par), _p(par), _p(empty), _p(gen), _p(row_of), _p(dous),
                                               len(dous)), "cnf2_upload_pedigree")
         self.n_ind = len(dous)
+        self.n_rec = len(par)
 
     def upload(self, ped, dous=None):
         """Convenience: everything from a cnf2freq_amd.synth.Pedigree."""
@@ -241,6 +244,22 @@ class Context:
         v = np.zeros((mc, 30))
         self._chk(self.L.cnf2_infprobs_rows(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_infprobs_rows")
         return v[:, :28].reshape(mc, 7, 2, 2).copy(), v[:, 28:].copy()
+
+    def descendants(self):
+        d = np.zeros(self.n_rec, np.int32)
+        self._chk(self.L.cnf2_descendants(self.h, _p(d)), "cnf2_descendants")
+        return d
+
+    def accumulate(self, desc, ind_begin=0, ind_end=None, ties=True):
+        ind_end = self.n_ind if ind_end is None else ind_end
+        desc = np.ascontiguousarray(desc, np.int32)
+        inf = np.zeros((self.n_rec, self.n_markers, 2, 2))
+        hb = np.zeros((self.n_rec, self.n_markers))
+        hc = np.zeros((self.n_rec, self.n_markers))
+        hz = np.zeros((ind_end - ind_begin, self.n_markers, 2))
+        self._chk(self.L.cnf2_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(inf), _p(hb), _p(hc), _p(hz),
+                                         0 if ties else NO_TIES), "cnf2_accumulate")
+        return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def addvariance(self, ind, chrom=0):
         mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])

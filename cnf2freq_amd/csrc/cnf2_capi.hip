@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "cnf2_device.h"
@@ -831,6 +832,114 @@ int cnf2_infprobs_rows(cnf2_ctx* ctx, int ind, int chrom, double* rows_out, uint
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(rows_out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_descendants(cnf2_ctx* ctx, int32_t* desc_out)
+{
+    if (!ctx || !desc_out) return fail(ctx, CNF2_ERR_ARG, "bad descendants arguments");
+    if (ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "no pedigree uploaded");
+    derive_descendants(ctx->ped, desc_out);
+    return CNF2_OK;
+}
+
+// HOT LOOP 2 with its reductions (cnF2freq.cpp:5416-5577, 5876-5902 with moveinfprobs / movehaplos 3577-3616)
+// for the analysed individuals [ind_begin, ind_end), in that order: the per-slot accumulator rows of every
+// chromosome (haplos_rows_kernel, infprobs_rows_kernel) are reduced per individual on the host exactly as the
+// reference does after each locus.  Parity level: one store run per individual and chromosome.
+int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* descendants, double* infprobs_out,
+                    double* haplobase_out, double* haplocount_out, double* homozyg_out, uint32_t flags)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    const int n_all = (int)ctx->windows.size();
+    if (!descendants || !infprobs_out || !haplobase_out || !haplocount_out || !homozyg_out || ind_begin < 0 ||
+        ind_end > n_all || ind_begin > ind_end)
+        return fail(ctx, CNF2_ERR_ARG, "bad accumulate arguments");
+    const HostPedigree& P = ctx->ped;
+    const size_t M = (size_t)ctx->n_markers;
+    std::fill(infprobs_out, infprobs_out + (size_t)P.n_rec * M * 4, 0.0);
+    std::fill(haplobase_out, haplobase_out + (size_t)P.n_rec * M, 0.0);
+    std::fill(haplocount_out, haplocount_out + (size_t)P.n_rec * M, 0.0);
+    std::fill(homozyg_out, homozyg_out + (size_t)(ind_end - ind_begin) * M * 2, 0.0);
+    const float  maxdiff = 0.000005f;                                        // cnF2freq.cpp:228
+    const uint32_t kf = (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0;
+    std::vector<double> hrows, irows, hwrow[7];
+    for (int j = ind_begin; j < ind_end; j++) {
+        Window  w;
+        int32_t slot_rec[7];
+        derive_window(P, P.dous[j], &w, slot_rec);
+        // haploweight of the window members (movehaplos tests it): one row each, read back
+        for (int k = 0; k < 7; k++) {
+            hwrow[k].clear();
+            if (slot_rec[k] < 0) continue;
+            hwrow[k].resize(M);
+            HIP_TRY(ctx, hipMemcpy(hwrow[k].data(), ctx->d_hw + (size_t)ctx->windows[j].row[k] * M, M * sizeof(double),
+                                   hipMemcpyDeviceToHost));
+        }
+        const double descf = descendants[P.dous[j]];
+        for (int c = 0; c < ctx->n_chrom; c++) {
+            const int first = ctx->chromstarts[c], mc = ctx->chromstarts[c + 1] - first;
+            Stage2Params q;
+            double*      d_out = nullptr;
+            rc = run_store(ctx, j, c, &q, (size_t)mc * 44, &d_out);
+            if (rc) return rc;
+            launch_haplos_rows(q, kf, d_out, ctx->stream);
+            launch_infprobs_rows(q, kf, d_out + (size_t)mc * 14, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+            hrows.resize((size_t)mc * 14);
+            irows.resize((size_t)mc * 30);
+            double loglik = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(hrows.data(), d_out, hrows.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(irows.data(), d_out + (size_t)mc * 14, irows.size() * sizeof(double),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&loglik, q.loglik, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (std::isnan(loglik) || loglik < (double)CNF2_MINFACTOR_F) continue;       // cnF2freq.cpp:5403
+            for (int ml = 0; ml < mc; ml++) {
+                const size_t  m  = (size_t)first + ml;
+                const double* I  = irows.data() + (size_t)ml * 30;
+                const double* H  = hrows.data() + (size_t)ml * 14;
+                // the analysed individual's own allele-index-0 entries (its slots: slot 0 and any tie with it)
+                double self0 = 0.0;
+                for (int k = 0; k < 7; k++)
+                    if (slot_rec[k] == slot_rec[0]) self0 += I[(k * 2 + 0) * 2 + 0] + I[(k * 2 + 0) * 2 + 1];
+                const double sum = 1.0 / self0;                                           // cnF2freq.cpp:5880-5885
+                double* hz = homozyg_out + ((size_t)(j - ind_begin) * M + m) * 2;
+                hz[0] = I[28] * sum;
+                hz[1] = I[29] * sum;
+                for (int k = 0; k < 7; k++) {                                             // reltree: unique members
+                    const int r = slot_rec[k];
+                    if (r < 0) continue;
+                    bool dup = false;
+                    for (int k2 = 0; k2 < k; k2++) dup |= (slot_rec[k2] == r);
+                    if (dup) continue;
+                    double inf[4] = {0, 0, 0, 0}, hap[2] = {0, 0};
+                    int    occ = 0;
+                    for (int k2 = k; k2 < 7; k2++) {
+                        if (slot_rec[k2] != r) continue;
+                        for (int x = 0; x < 4; x++) inf[x] += I[k2 * 4 + x];
+                        hap[0] += H[k2 * 2];
+                        hap[1] += H[k2 * 2 + 1];
+                        if (!P.empty[r]) occ++;                                           // reltreeordered: non-empty only
+                    }
+                    double norm = sum * 2;                                                // cnF2freq.cpp:3582-3587
+                    for (int x = 0; x < occ; x++) norm /= 2;
+                    norm *= descf;
+                    double* dst = infprobs_out + ((size_t)r * M + m) * 4;
+                    for (int x = 0; x < 4; x++) dst[x] += inf[x] * norm;
+                    if (hap[0] != 0.0 || hap[1] != 0.0) {                                 // cnF2freq.cpp:3601-3616
+                        if (fabs(hwrow[k][m] - 0.5) < 0.5 - 1e-12) {
+                            const double b1 = hap[0] + exp(-400.0) * maxdiff * maxdiff * 0.5;
+                            const double b2 = hap[1] + exp(-400.0) * maxdiff * maxdiff * 0.5;
+                            haplobase_out[(size_t)r * M + m] += b1 / (b1 + b2) * descf;
+                            haplocount_out[(size_t)r * M + m] += descf;
+                        }
+                    }
+                }
+            }
+        }
+    }
     return CNF2_OK;
 }
 

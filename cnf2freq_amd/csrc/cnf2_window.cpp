@@ -28,6 +28,28 @@ void derive_founders(HostPedigree& P)
     }
 }
 
+void derive_descendants(const HostPedigree& P, int32_t* desc)
+{
+    std::vector<int32_t> upsent(P.n_rec, 0);
+    for (int r = 0; r < P.n_rec; r++) desc[r] = 0;
+    bool any;
+    do {
+        any = false;
+        for (int r = 0; r < P.n_rec; r++) {
+            int now = desc[r] ? desc[r] : 1;
+            now -= upsent[r];
+            if (now > 0) {
+                for (int k = 0; k < 2; k++)
+                    if (P.par[r * 2 + k] >= 0) desc[P.par[r * 2 + k]] += now;
+                upsent[r] += now;
+                any = true;
+            }
+        }
+    } while (any);
+    for (int r = 0; r < P.n_rec; r++)
+        if (!desc[r]) desc[r] = 1;
+}
+
 void derive_window(const HostPedigree& P, int rec, Window* w, int32_t* slot_rec_out)
 {
     memset(w, 0, sizeof(*w));

@@ -41,6 +41,10 @@ struct HostPedigree {
 // (cnF2freq.cpp:3373-3389) before the first sweep.
 void derive_founders(HostPedigree& P);
 
+// individ::descendants as postmarkerdata leaves it (cnF2freq.cpp:3224-3255): every individual sends
+// max(1, own count) to both parents until nothing changes; zeros become 1.  desc_out[n_rec].
+void derive_descendants(const HostPedigree& P, int32_t* desc_out);
+
 // Window of one analysed record.  slot_rec_out (optional, 7 ints) receives the record per slot.
 void derive_window(const HostPedigree& P, int rec, Window* w, int32_t* slot_rec_out);
 

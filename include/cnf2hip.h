@@ -163,6 +163,18 @@ int cnf2_infprobs(cnf2_ctx *ctx, int ind, int chrom, int marker, double *inf_out
  *                       total) instead of the 128-path fan-out. */
 int cnf2_infprobs_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 
+/* HOT LOOP 2 with its reductions (parity level): for the analysed individuals
+ * [ind_begin, ind_end), in that order, the per-locus accumulators of cnF2freq.cpp:5416-5577 are formed on the GPU
+ * (closed forms: cnf2_haplos, cnf2_infprobs_rows) and reduced per individual as the reference does after every
+ * locus (cnF2freq.cpp:5876-5902): homozyg scaled by 1 / sum of the individual's own allele-index-0 infprobs;
+ * moveinfprobs (cnF2freq.cpp:3577-3597) and movehaplos (cnF2freq.cpp:3599-3616) for every window member, with the
+ * individual's `descendants` count as weight.  Outputs are zeroed first: infprobs_out[n_rec][M][2][2] (side,
+ * markerval 1/2), haplobase_out / haplocount_out[n_rec][M], homozyg_out[ind_end - ind_begin][M][2].
+ * cnf2_descendants fills descendants[n_rec] as postmarkerdata computes them (cnF2freq.cpp:3224-3255). */
+int cnf2_descendants(cnf2_ctx *ctx, int32_t *desc_out);
+int cnf2_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *descendants, double *infprobs_out,
+                    double *haplobase_out, double *haplocount_out, double *homozyg_out, uint32_t flags);
+
 /* Pre-processing user of the emission (parity level): individ::addvariance
  * (cnF2freq.cpp:1489-1558, called by postmarkerdata for every marker, cnF2freq.cpp:3373-3389) for one analysed
  * individual and chromosome: var_out[mc] = variances[marker], NaN where the reference leaves the entry alone

@@ -634,6 +634,22 @@ def test_addvariance_matches_reference(capi, case):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_hot_loop_2_reductions_match_reference(capi, case):
+    """cnf2_accumulate (accumulator rows on the GPU, moveinfprobs / movehaplos reductions on the host) against
+    the reference's per-individual infprobs, haplobase, haplocount and homozyg (goldens G11); descendant
+    counts from cnf2_descendants."""
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = ctx.descendants()
+    assert np.array_equal(desc, z["acc_desc"])
+    got = ctx.accumulate(desc)
+    for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+        np.testing.assert_allclose(got[k], z["acc_" + k], rtol=1e-8, atol=1e-12, equal_nan=True)
+    ctx.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd
