@@ -145,28 +145,28 @@ int cnf2_ctx_create(int device, cnf2_ctx** out)
 void cnf2_ctx_destroy(cnf2_ctx* ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipFree(ctx->d_rho);
-    hipFree(ctx->d_tq);
-    hipFree(ctx->d_logk);
-    hipFree(ctx->d_allele8);
-    hipFree(ctx->d_sure);
-    hipFree(ctx->d_hw);
-    hipFree(ctx->d_windows);
-    hipFree(ctx->d_rowflags);
-    hipFree(ctx->d_jobs);
-    hipFree(ctx->d_pjobs);
-    hipFree(ctx->d_spill);
-    hipFree(ctx->d_factors);
-    hipFree(ctx->d_loglik);
-    hipFree(ctx->d_dosage);
-    hipFree(ctx->d_scratch);
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
-    hipEventDestroy(ctx->ev2);
-    hipStreamDestroy(ctx->stream2);
-    hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_rho);
+    (void)hipFree(ctx->d_tq);
+    (void)hipFree(ctx->d_logk);
+    (void)hipFree(ctx->d_allele8);
+    (void)hipFree(ctx->d_sure);
+    (void)hipFree(ctx->d_hw);
+    (void)hipFree(ctx->d_windows);
+    (void)hipFree(ctx->d_rowflags);
+    (void)hipFree(ctx->d_jobs);
+    (void)hipFree(ctx->d_pjobs);
+    (void)hipFree(ctx->d_spill);
+    (void)hipFree(ctx->d_factors);
+    (void)hipFree(ctx->d_loglik);
+    (void)hipFree(ctx->d_dosage);
+    (void)hipFree(ctx->d_scratch);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev2);
+    (void)hipStreamDestroy(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 

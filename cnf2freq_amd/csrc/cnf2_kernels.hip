@@ -1859,7 +1859,7 @@ void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hi
 
 void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream)
 {
-    hipMemsetAsync(out, 0, 30 * sizeof(double), stream);
+    (void)hipMemsetAsync(out, 0, 30 * sizeof(double), stream);
     hipLaunchKernelGGL(infprobs_kernel, dim3(8 * 64), dim3(128), 0, stream, q, marker, flags, out);
 }
 
