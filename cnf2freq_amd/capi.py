@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -64,6 +64,7 @@ def load():
         L.cnf2_fwbw_store.argtypes = [vp, i32, i32, vp, vp]
         L.cnf2_locked_query.argtypes = [vp, i32, i32, i32, vp]
         L.cnf2_turn_scan.argtypes = [vp, i32, i32, i32, vp]
+        L.cnf2_turn_scan_rows.argtypes = [vp, i32, i32, vp]
         L.cnf2_state_posterior.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_haplos.argtypes = [vp, i32, i32, vp, C.c_uint32]
         L.cnf2_infprobs.argtypes = [vp, i32, i32, i32, vp, vp, C.c_uint32]
@@ -223,6 +224,12 @@ class Context:
         mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
         v = np.zeros((mc, 64))
         self._chk(self.L.cnf2_state_posterior(self.h, ind, chrom, _p(v), 0 if ties else NO_TIES), "cnf2_state_posterior")
+        return v
+
+    def turn_scan_rows(self, ind, chrom=0):
+        mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])
+        v = np.zeros((mc, 128, 8))
+        self._chk(self.L.cnf2_turn_scan_rows(self.h, ind, chrom, _p(v)), "cnf2_turn_scan_rows")
         return v
 
     def haplos(self, ind, chrom=0, ties=True):

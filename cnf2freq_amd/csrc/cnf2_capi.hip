@@ -758,6 +758,24 @@ int cnf2_turn_scan(cnf2_ctx* ctx, int ind, int chrom, int marker, double* rawerv
     return CNF2_OK;
 }
 
+int cnf2_turn_scan_rows(cnf2_ctx* ctx, int ind, int chrom, double* rows_out)
+{
+    if (!ctx || !rows_out) return fail(ctx, CNF2_ERR_ARG, "bad turn_scan_rows arguments");
+    Stage2Params q;
+    double*      d_out = nullptr;
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (chrom < 0 || chrom >= ctx->n_chrom) return fail(ctx, CNF2_ERR_ARG, "chromosome out of range");
+    const size_t n = (size_t)(ctx->chromstarts[chrom + 1] - ctx->chromstarts[chrom]) * 1024;
+    rc = run_store(ctx, ind, chrom, &q, n, &d_out);
+    if (rc) return rc;
+    launch_turn_scan_rows(q, d_out, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(rows_out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
 int cnf2_state_posterior(cnf2_ctx* ctx, int ind, int chrom, double* rows_out, uint32_t flags)
 {
     if (!ctx || !rows_out) return fail(ctx, CNF2_ERR_ARG, "bad state_posterior arguments");

@@ -73,6 +73,7 @@ struct Stage2Params {
 };
 void launch_locked_query(const Stage2Params& q, int marker, double* out, hipStream_t stream);
 void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_t stream);
+void launch_turn_scan_rows(const Stage2Params& q, double* out, hipStream_t stream);
 void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream);
 void launch_infprobs(const Stage2Params& q, int marker, uint32_t flags, double* out, hipStream_t stream);

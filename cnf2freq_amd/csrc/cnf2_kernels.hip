@@ -1871,6 +1871,32 @@ void launch_turn_scan(const Stage2Params& q, int marker, double* out, hipStream_
 {
     hipLaunchKernelGGL(turn_scan_kernel, dim3(1024), dim3(64), 0, stream, q, marker, out);
 }
+// every marker of the chromosome: out[len][128][8]
+__global__ __launch_bounds__(64) void turn_scan_rows_kernel(Stage2Params q, double* out)
+{
+    const int k    = threadIdx.x;
+    const int s    = blockIdx.x & 7;
+    const int turn = blockIdx.x >> 3;
+    const int ml   = blockIdx.y;
+    const int xorturn = turn & 54;                                                      // cnF2freq.cpp:508
+    const int shiftx  = (turn >> 6) | ((turn & 1) ? 2 : 0) | ((turn & 8) ? 4 : 0);     // cnF2freq.cpp:509-510
+    const int s2      = s ^ shiftx;
+    double v = s2_fw(q, s, ml, 2, k ^ xorturn) * s2_fw(q, s2, ml, 1, k);
+    v += lane_xor1(v);
+    v += lane_xor2(v);
+    v += dpp_mov_all<0x141>(v);
+    v += lane_xor8(v);
+    v += lane_xor16(v);
+    v += lane_xor32(v);
+    if (k == 0) {
+        double r = (v > 0.0) ? s2_ff(q, s, ml, 2) + s2_ff(q, s2, ml, 1) + log(v) : (double)CNF2_MINFACTOR_F;
+        out[((size_t)ml * 128 + turn) * 8 + s] = r - q.loglik[0];
+    }
+}
+void launch_turn_scan_rows(const Stage2Params& q, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(turn_scan_rows_kernel, dim3(1024, q.len), dim3(64), 0, stream, q, out);
+}
 void launch_haplos_rows(const Stage2Params& q, uint32_t flags, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(haplos_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);

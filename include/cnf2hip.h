@@ -144,6 +144,8 @@ int cnf2_fwbw_store(cnf2_ctx *ctx, int ind, int chrom, double *fwbw_out, double 
  *                       i.e. sum of val over shift modes and admissible paths by state, per marker. */
 int cnf2_locked_query(cnf2_ctx *ctx, int ind, int chrom, int marker, double *val_out);
 int cnf2_turn_scan(cnf2_ctx *ctx, int ind, int chrom, int marker, double *rawervals_out);
+/*  cnf2_turn_scan_rows  the same for every marker of the chromosome in one launch: rows_out[mc][128][8] */
+int cnf2_turn_scan_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out);
 int cnf2_state_posterior(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 /*  cnf2_haplos          rows_out[mc][7][2]: the HAPLOS accumulators HOT LOOP 2 leaves per window slot
  *                       (slot order of cnf2_window_info) before movehaplos: sum of val by the phase with

@@ -291,11 +291,13 @@ def test_turn_scan_matches_reference(capi, case):
     for j in range(len(ped.dous)):
         if not z["ok"][j]:
             continue
+        rows = ctx.turn_scan_rows(j, 0)                   # every marker of the chromosome in one launch
         for ti, m in enumerate(z["turn_markers"]):
             got = ctx.turn_scan(j, 0, int(m))
             want = z["rawervals"][j, ti]
             live = ~np.isnan(want)
             np.testing.assert_allclose(got[live], want[live], rtol=1e-9, atol=1e-8)
+            assert np.array_equal(rows[int(m)], got)
     ctx.close()
 
 
