@@ -652,6 +652,29 @@ def test_hot_loop_2_reductions_match_reference(capi, case):
     ctx.close()
 
 
+def test_error_behaviour_of_the_c_abi(capi):
+    """Errors are status codes with a message, never exceptions or aborts on the library side (the reference
+    aborts, cnF2freq.cpp:21-25): calls before the uploads, out-of-range individuals / chromosomes / markers."""
+    ctx = capi.Context(0)
+    with pytest.raises(capi.Cnf2Error, match="uploaded first"):
+        ctx.sweep(0, 0)
+    ped = synth.make_f2(2, 5, 1, seed=1, chrom_cm=10.0)
+    ctx.upload(ped)
+    with pytest.raises(capi.Cnf2Error, match="out of bounds"):
+        ctx.sweep(0, 3)
+    with pytest.raises(capi.Cnf2Error, match="out of range"):
+        ctx.locked_query(0, 1, 0)
+    with pytest.raises(capi.Cnf2Error, match="out of range"):
+        ctx.fwbw_store(5, 0)
+    with pytest.raises(capi.Cnf2Error, match="marker"):
+        ctx.infprobs(0, 99)
+    with pytest.raises(capi.Cnf2Error, match="marker"):
+        ctx.turn_scan(0, 0, 99)
+    ok = ctx.sweep()                      # the context stays usable after errors
+    assert np.all(np.isfinite(ok["loglik"]))
+    ctx.close()
+
+
 def test_half_spill_recompute_equals_full_spill(capi):
     """Default: alpha-minus stored at every second marker, the odd ones rebuilt in the backward
     pass by one forward step.  Must give exactly what storing every marker gives (even and odd
