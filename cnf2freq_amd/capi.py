@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -73,6 +73,7 @@ def load():
         L.cnf2_descendants.argtypes = [vp, vp]
         L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
+        L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
         L.cnf2_workspace_bytes.argtypes = [vp]
@@ -277,6 +278,11 @@ class Context:
     def emission(self, ind, marker):
         e = np.zeros((8, 64))
         self._chk(self.L.cnf2_emission(self.h, ind, marker, _p(e)), "cnf2_emission")
+        return e
+
+    def emission_paths(self, ind, marker):
+        e = np.zeros((8, 64, 128))
+        self._chk(self.L.cnf2_emission_paths(self.h, ind, marker, _p(e)), "cnf2_emission_paths")
         return e
 
     def selftest_lane_xor(self):

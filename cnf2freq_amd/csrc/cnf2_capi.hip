@@ -294,6 +294,13 @@ int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const dou
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hw, cnt * sizeof(double)));
     ctx->n_rows = n_rows;
     ctx->windows_dirty = true;
+    // a pedigree uploaded against a larger table would index past the new one: drop it, it must be uploaded again
+    for (int32_t r : ctx->ped.row_of)
+        if (r >= n_rows) {
+            ctx->ped = HostPedigree();
+            ctx->windows.clear();
+            break;
+        }
     if (blank) return blank_rows(ctx);
     return copy_rows(ctx, 0, n_rows, allele, sure, hw);
 }
@@ -939,7 +946,9 @@ int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* de
                         for (int x = 0; x < 4; x++) inf[x] += I[k2 * 4 + x];
                         hap[0] += H[k2 * 2];
                         hap[1] += H[k2 * 2 + 1];
-                        if (!P.empty[r]) occ++;                                           // reltreeordered: non-empty only
+                        // reltreeordered holds the individual itself unconditionally (cnF2freq.cpp:3111) and, of its
+                        // ancestors, the non-empty ones only (cnF2freq.cpp:3127-3152)
+                        if (k2 == 0 || !P.empty[r]) occ++;
                     }
                     double norm = sum * 2;                                                // cnF2freq.cpp:3582-3587
                     for (int x = 0; x < occ; x++) norm /= 2;
@@ -993,6 +1002,24 @@ int cnf2_emission(cnf2_ctx* ctx, int ind, int marker, double* e_out)
     launch_emission(p, ind, marker, ctx->d_scratch, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(e_out, ctx->d_scratch, 512 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_emission_paths(cnf2_ctx* ctx, int ind, int marker, double* e_out)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ind < 0 || ind >= (int)ctx->windows.size() || marker < 0 || marker >= ctx->n_markers || !e_out)
+        return fail(ctx, CNF2_ERR_ARG, "bad emission arguments");
+    const size_t n = (size_t)8 * 64 * 128;
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, n))) return rc;
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows = ctx->d_windows + ind;
+    launch_emission_paths(p, marker, ctx->d_scratch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(e_out, ctx->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNF2_OK;
 }

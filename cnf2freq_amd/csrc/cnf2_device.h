@@ -86,6 +86,7 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
                       hipStream_t stream);
 int  fb_fast_blocks_per_cu();
 void launch_emission(const KernelParams& p, int ind, int marker, double* out, hipStream_t stream);
+void launch_emission_paths(const KernelParams& p, int marker, double* out, hipStream_t stream);
 void launch_xor_selftest(double* out, hipStream_t stream);
 int  fb_blocks_per_cu();
 

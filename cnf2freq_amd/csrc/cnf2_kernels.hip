@@ -20,6 +20,7 @@
 // cnF2freq.cpp:5416-5553) and carries beta.
 #include <hip/hip_runtime.h>
 
+#include <string.h>
 #include <type_traits>
 
 #include "cnf2_device.h"
@@ -1445,6 +1446,38 @@ __global__ __launch_bounds__(128) void locked_query_kernel(Stage2Params q, int m
     double lv = s2_ff(q, s, ml, 0) + log(am * e) + s2_ff(q, s, ml, 1) + log(be) - factor;
     double v  = (isfinite(lv) && lv > -200.0) ? exp(lv) : 0.0;
     out[((size_t)s * 64 + g) * 128 + flag2] = v;
+}
+
+// Parity hook: path-resolved emission e_s(g, flag2) = trackpossible<0,0>(..., 2g, flag2, s) of cnF2freq.cpp:1380-1385
+// for one (individual, marker): out[s][g][flag2], through the line terms the stage-2 kernels use.
+__global__ __launch_bounds__(128) void emission_paths_kernel(Stage2Params q, int marker, double* out)
+{
+    const int flag2 = threadIdx.x;            // 0..127
+    const int g     = blockIdx.x & 63;
+    const int s     = blockIdx.x >> 6;
+    const Window w  = q.kp.windows[0];
+    const int f     = flag2 & 1;
+    LaneJob   L0, L1;
+    LineTerms T0, T1;
+    double    cf;
+    bool      attop;
+    s2_lines(q, w, marker, g, s, f, &L0, &L1, &T0, &T1, &cf, &attop);
+    double e;
+    if (attop) e = cf;
+    else {
+        const int fp0 = (flag2 >> 1) & 1, fp1 = (flag2 >> 4) & 1;
+        const int a0 = (flag2 >> (2 + L0.cfg.firstpar)) & 1, o0 = (flag2 >> (2 + (L0.cfg.firstpar ^ 1))) & 1;
+        const int a1 = (flag2 >> (5 + L1.cfg.firstpar)) & 1, o1 = (flag2 >> (5 + (L1.cfg.firstpar ^ 1))) & 1;
+        e = (cf * s2_path_term(L1.cfg, T1, fp1, a1, o1)) * s2_path_term(L0.cfg, T0, fp0, a0, o0);
+    }
+    out[((size_t)s * 64 + g) * 128 + flag2] = e;
+}
+void launch_emission_paths(const KernelParams& p, int marker, double* out, hipStream_t stream)
+{
+    Stage2Params q;
+    memset(&q, 0, sizeof(q));
+    q.kp = p;
+    hipLaunchKernelGGL(emission_paths_kernel, dim3(512), dim3(128), 0, stream, q, marker, out);
 }
 
 // rawervals[turn][s] of cnF2freq.cpp:5686-5752 for one marker (aroundturner, cnF2freq.cpp:498-554):

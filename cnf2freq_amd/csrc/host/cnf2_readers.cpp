@@ -141,28 +141,40 @@ bool read_alpha_gen(FILE* in, Pedigree& P)
                     I.allele[x * 2] = I.allele[x * 2 + 1] = 0;
                     I.sure[x * 2] = I.sure[x * 2 + 1] = 0.0;
                 } else {
-                    double sure1 = 0, sure2 = 0, probsum = 0;
-                    for (int rl1 = 0; rl1 <= data; rl1++)
-                        for (int rl2 = 0; rl2 <= data2; rl2++) {
-                            int    l1 = rl1, l2 = rl2;
-                            double overallprob = (data ? binom_half_pdf(data, l1) : 1) * (data2 ? binom_half_pdf(data2, l2) : 1);
-                            double sureb1, sureb2;
-                            while (true) {
-                                sureb1 = 0.5;
-                                sureb2 = 0.5;
-                                if (l1 + l2) sureb1 = l1 / (double)(l1 + l2);
-                                if (data + data2 - l1 - l2) sureb2 = (data2 - l2) / (double)(data + data2 - l1 - l2);
-                                if (sureb1 + 1e-9 > 1 - sureb2) break;
-                                l1 = data - l1;
-                                l2 = data2 - l2;
+                    // Posterior mean of the two per-allele read fractions given the counts (cnF2freq.cpp:6596-6641).
+                    // A split (k1, k2) says how many of the `data` allele-1 reads and of the `data2` allele-2 reads
+                    // came from the first chromosome; splits are weighted by Binomial(n, 1/2) per allele (tabulated
+                    // once) times the likelihood of the reads under the split's own fractions.  Each split is looked
+                    // at from the side on which the first chromosome is the allele-1-richer one.
+                    const int n1 = data, n2 = data2, nall = n1 + n2;
+                    std::vector<double> w1(n1 + 1, 1.0), w2(n2 + 1, 1.0);
+                    if (n1) for (int k = 0; k <= n1; k++) w1[k] = binom_half_pdf(n1, k);
+                    if (n2) for (int k = 0; k <= n2; k++) w2[k] = binom_half_pdf(n2, k);
+                    struct Frac { double first, second; };
+                    auto fractions = [&](int k1, int k2) {
+                        Frac f = {0.5, 0.5};
+                        if (k1 + k2) f.first = k1 / (double)(k1 + k2);
+                        if (nall - k1 - k2) f.second = (n2 - k2) / (double)(nall - k1 - k2);
+                        return f;
+                    };
+                    double acc1 = 0, acc2 = 0, total = 0;
+                    for (int s1 = 0; s1 <= n1; s1++)
+                        for (int s2 = 0; s2 <= n2; s2++) {
+                            int  k1 = s1, k2 = s2;
+                            Frac f = fractions(k1, k2);
+                            if (!(f.first + 1e-9 > 1 - f.second)) {      // mirror the split (always settles in one step)
+                                k1 = n1 - k1;
+                                k2 = n2 - k2;
+                                f  = fractions(k1, k2);
                             }
-                            overallprob *= pow(sureb1, l1) * pow(1 - sureb1, l2) * pow(sureb2, (data2 - l2)) * pow(1 - sureb2, data - l1);
-                            sure1 += sureb1 * overallprob;
-                            sure2 += sureb2 * overallprob;
-                            probsum += overallprob;
+                            const double like = pow(f.first, k1) * pow(1 - f.first, k2) * pow(f.second, n2 - k2) *
+                                                pow(1 - f.second, n1 - k1);
+                            const double wt = w1[s1] * w2[s2] * like;
+                            acc1 += f.first * wt;
+                            acc2 += f.second * wt;
+                            total += wt;
                         }
-                    sure1 /= probsum;
-                    sure2 /= probsum;
+                    const double sure1 = acc1 / total, sure2 = acc2 / total;
                     uint8_t mk[2] = {2, 1};
                     double  ms[2] = {sure1, sure2};
                     for (int k = 0; k < 2; k++)

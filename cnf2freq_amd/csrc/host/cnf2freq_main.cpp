@@ -31,6 +31,8 @@ struct Options {
     int         capmarker = 0;
     bool        quiet = false;
     bool        merge_modes = true;   // CNF2_MERGE_MODES: exact, faster for F2-type pedigrees (include/cnf2hip.h)
+    bool        normalise = false;    // rows as the reporter leaves them: raw class sums (cnF2freq.cpp:3523 has the
+                                      // division by probsum commented out); --normalise divides each row by its sum
     bool        parse_only = false;   // print the parsed tables and stop (no GPU needed; used by tests)
 };
 
@@ -63,6 +65,7 @@ static bool parse(int argc, char** argv, Options& o)
         else if (a == "--capmarker") o.capmarker = atoi(val().c_str());
         else if (a == "--quiet") o.quiet = true;
         else if (a == "--no-merge-modes") o.merge_modes = false;
+        else if (a == "--normalise") o.normalise = true;
         else if (a == "--parse-only") o.parse_only = true;
         else {
             fprintf(stderr, "unsupported option %s (this build covers the PlantImpute path only)\n", a.c_str());
@@ -150,7 +153,7 @@ int main(int argc, char** argv)
         FILE* dst = (it == opt.count - 1) ? out : stdout;
         if (!early && N > 0) {
             CHECK(ctx, cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(),
-                                  opt.merge_modes ? CNF2_MERGE_MODES : 0));
+                                  (opt.merge_modes ? CNF2_MERGE_MODES : 0) | (opt.normalise ? 0 : CNF2_RAW_DOSAGE)));
             for (int c = 0; c < C; c++) {
                 if (!opt.quiet)
                     for (int j = 0; j < N; j++) {
@@ -176,23 +179,24 @@ int main(int argc, char** argv)
         }
         fflush(stdout);
         fflush(dst);
-        // per-iteration dump of every individual (cnF2freq.cpp:8157-8192)
+        // per-iteration dump of every individual: always to the --output file, whatever the iteration
+        // (fprintf(out, ...), cnF2freq.cpp:8157-8192); only the rows above switch between out and stdout
         for (size_t r = 0; r < P.inds.size(); r++) {
             const Individual& I = P.inds[r];
             if (I.n > opt.limit) continue;
-            fprintf(dst, "%d %s\n", I.n, I.name.c_str());
+            fprintf(out, "%d %s\n", I.n, I.name.c_str());
             for (int m = 0; m < M; m++) {
                 if (I.has_prior)
-                    fprintf(dst, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\t%d\t%d\t%lf\t%lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0,
+                    fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\t%d\t%d\t%lf\t%lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0,
                             I.sure[m * 2], I.sure[m * 2 + 1], 0.5, I.prior_allele[m * 2], I.prior_allele[m * 2 + 1],
                             I.prior_sure[m * 2], I.prior_sure[m * 2 + 1]);
                 else
-                    fprintf(dst, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0, I.sure[m * 2],
+                    fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0, I.sure[m * 2],
                             I.sure[m * 2 + 1], 0.5);
             }
         }
         fflush(stdout);
-        fflush(dst);
+        fflush(out);
     }
     if (out != stdout) fclose(out);
     cnf2_ctx_destroy(ctx);

@@ -186,6 +186,9 @@ int cnf2_addvariance(cnf2_ctx *ctx, int ind, int chrom, double *var_out);
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
 int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);
+/* The same resolved by allele path: e_out[8][64][128] = trackpossible(..., 2g, flag2, s) for every shift mode,
+ * state and path flag2 (calltrackpossible with flag2 >= 0, cnF2freq.cpp:1380-1385, 1141-1146). */
+int cnf2_emission_paths(cnf2_ctx *ctx, int ind, int marker, double *e_out);
 
 /* Diagnostic: out384[k*64 + lane] = value 1000+src received by `lane` from the lane-exchange
  * primitive of distance 1<<k (k = 0..5) that the transition butterflies are built on. */

@@ -46,7 +46,13 @@ def test_window_topology_matches_reference(capi, case):
         w = ctx.window_info(j)
         assert (w["shiftignore"], w["flag2ignore"]) == tuple(z["fixtrees"][j])
         assert w["founder"] == z["founder"][ped.dous[j]]
-        assert list(w["slots"]) == list(z["ordered"][j]) or True  # reltreeordered skips empty slots
+        # reltreeordered (cnF2freq.cpp:3111-3152): the individual itself, then the NON-EMPTY ancestors by slot;
+        # the library's slot table also lists empty ancestors (they are members of reltree)
+        for k, r in enumerate(z["ordered"][j]):
+            if r >= 0:
+                assert w["slots"][k] == r
+            else:
+                assert k != 0 and (w["slots"][k] < 0 or ped.empty[w["slots"][k]])
     ctx.close()
 
 
@@ -56,14 +62,21 @@ def test_emission_matches_reference(capi, case):
     ctx = capi.Context(0)
     ctx.upload(ped)
     index = {int(r): j for j, r in enumerate(ped.dous)}
-    cache = {}
+    cache, paths = {}, {}
+    n_paths = 0
     for (ind, m, g, f2, s), want in zip(z["em_idx"], z["em_val"]):
-        if f2 != -1:
-            continue
         key = (int(ind), int(m))
+        if f2 != -1:
+            # path-resolved emission (flag2 >= 0) through the stage-2 line terms
+            if key not in paths:
+                paths[key] = ctx.emission_paths(index[int(ind)], int(m))
+            np.testing.assert_allclose(paths[key][s, g, f2], want, rtol=1e-12, atol=1e-300)
+            n_paths += 1
+            continue
         if key not in cache:
             cache[key] = ctx.emission(index[int(ind)], int(m))
         np.testing.assert_allclose(cache[key][s, g], want, rtol=1e-13, atol=1e-300)
+    assert n_paths > 0
     ctx.close()
 
 
