@@ -31,6 +31,17 @@ B_UNIT = 8248.0        # algorithmic bytes per individual x marker (SURVEY.md se
 HBM_PEAK = 8.0e12      # MI355X_MICROARCH.md: 8 TB/s
 
 
+def kernel_source_sha():
+    """Identity of the kernel sources the library was built from: PMC traffic measured for another
+    version of the kernels must not be reported next to this one's timing."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cnf2freq_amd", "csrc")
+    for f in ("cnf2_kernels.hip", "cnf2_emtab.h", "cnf2_emission.h", "cnf2_lane.h", "cnf2_device.h"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +68,12 @@ def parse():
                     help="gloo = rehearsal of the multi-rank control flow on one GPU (posteriors staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
+    ap.add_argument("--gather-tile-markers", type=int, default=0,
+                    help="markers per tile of the streaming gather to rank 0 (0 = one chromosome); rank 0 holds "
+                         "2 tiles x world_size, never the whole posterior")
+    ap.add_argument("--workload", default="f2", choices=["f2", "ail", "outbred"],
+                    help="f2 = BASELINE configs 2/4 (headline); ail = config 3 (advanced intercross, 2 founders + 64 F1 + "
+                         "8 generations, tied windows); outbred = config 5's shape (3-generation outbred, 20 %% missing)")
     return ap.parse_args()
 
 
@@ -215,14 +232,42 @@ def main():
     from cnf2freq_amd import capi, synth
     from cnf2freq_amd import dist as cdist
 
-    pos, starts = synth.make_map(args.chroms, args.snps_per_chrom)
-    M = len(pos)
-    n = args.inds
-    ctx = capi.Context(local)
-    ctx.upload_map(pos, starts)
-    sample = generate_on_gpu(ctx, args, rank, device, pos, starts)
-    par, gen, empty, row_of, dous = synth.f2_pedigree_tables(n)
-    ctx.upload_pedigree(par, empty, gen, row_of, dous)
+    sample = None
+    if args.workload == "f2":
+        pos, starts = synth.make_map(args.chroms, args.snps_per_chrom)
+        M = len(pos)
+        n = args.inds
+        ctx = capi.Context(local)
+        ctx.upload_map(pos, starts)
+        sample = generate_on_gpu(ctx, args, rank, device, pos, starts)
+        par, gen, empty, row_of, dous = synth.f2_pedigree_tables(n)
+        ctx.upload_pedigree(par, empty, gen, row_of, dous)
+        workload = ("synthetic F2 intercross, %d individuals x %d SNPs per GPU (%d chromosomes x %d + 1 dummy marker "
+                    "each = %d markers swept), private empty F1 parents, 2 inbred founders"
+                    % (n, args.chroms * args.snps_per_chrom, args.chroms, args.snps_per_chrom, M))
+    else:
+        # BASELINE configs 3 and 5 (shape): generated on the host by cnf2freq_amd.synth, uploaded through the C ABI
+        if args.workload == "ail":
+            chroms = 8 if args.chroms == 20 else args.chroms
+            per_gen = 625 if args.inds == 10000 else max(1, args.inds // 8)
+            ped = synth.make_ail(64, per_gen, 8, args.snps_per_chrom, chroms, seed=3 + rank)
+            workload = ("advanced intercross (BASELINE config 3): 2 inbred founders, 64 genotyped F1, 8 random-mating "
+                        "generations x %d analysed individuals, %d chromosomes x %d SNPs (+1 dummy each)"
+                        % (per_gen, chroms, args.snps_per_chrom))
+        else:
+            chroms = 4 if args.chroms == 20 else args.chroms
+            fams = 2500 if args.inds == 10000 else max(1, args.inds // 4)
+            ped = synth.make_outbred3(fams, 4, args.snps_per_chrom, chroms, seed=2 + rank, missing=0.2)
+            workload = ("3-generation outbred pedigree (BASELINE config 5 shape): %d families of 4 grandparents, 2 parents, "
+                        "4 analysed children, 20%% of genotypes missing, %d chromosomes x %d SNPs (+1 dummy each)"
+                        % (fams, chroms, args.snps_per_chrom))
+        pos, starts = ped.pos, ped.chromstarts
+        M = len(pos)
+        n = len(ped.dous)
+        args.chroms = len(starts) - 1
+        ctx = capi.Context(local)
+        ctx.upload(ped)
+        del ped
 
     factors = torch.empty((n, args.chroms, 8), dtype=torch.float64, device=device)
     do_gather = world > 1 and not args.no_gather
@@ -231,56 +276,61 @@ def main():
     logliks = [torch.empty((n, args.chroms), dtype=torch.float64, device=device) for _ in range(nbuf)]
     dosages = [torch.empty((n, M, 3), dtype=torch.float64, device=device) for _ in range(nbuf)]
     loglik, dosage = logliks[0], dosages[0]
-    gather_list = gather_ll = None
     if overlap:
         ctx.set_grid_reserve(args.reserve_blocks)
     staged = world > 1 and args.backend == "gloo"
-    if do_gather and rank == 0:
-        gdev = torch.device("cpu") if staged else device
-        gather_list = [torch.empty(dosage.shape, dtype=dosage.dtype, device=gdev) for _ in range(world)]
-        gather_ll = [torch.empty(loglik.shape, dtype=loglik.dtype, device=gdev) for _ in range(world)]
+    gdev = torch.device("cpu") if staged else device
+    # The one collective of the path: posteriors to rank 0 (RCCL over xGMI), streamed in marker tiles so that the
+    # root holds 2 tiles x world_size and never the whole posterior (config 4: 60 GB per GPU, 480 GB in all).  The
+    # root "consumes" a tile by folding it into a checksum (a real driver would write it out).
+    tile_markers = args.gather_tile_markers or int(starts[1] - starts[0])
+    tiler = gather_ll = None
+    gsum = torch.zeros(1, dtype=torch.float64, device=gdev)
+    if do_gather:
+        tiler = cdist.TiledGather(n, M, 3, tile_markers, torch.float64, gdev, dst=0, depth=2)
+        if rank == 0:
+            gather_ll = [torch.empty(loglik.shape, dtype=loglik.dtype, device=gdev) for _ in range(world)]
+
+    def consume(m0, m1, parts):
+        for t in parts:
+            gsum.add_(t.sum())
 
     kernel_ms = []
     gather_ms = []
-    pending = [[] for _ in range(nbuf)]     # outstanding gathers reading buffer i
+    pending = [None] * nbuf     # event after the enqueued gathers that read buffer i
     state = {"k": 0}
 
     def drain(i):
-        for w in pending[i]:
-            w.wait()
-        if pending[i]:
-            torch.cuda.synchronize()
-        pending[i] = []
+        if pending[i] is not None:
+            for w in pending[i][0]:
+                w.wait()
+            pending[i][1].synchronize()
+            pending[i] = None
 
     def step():
         i = state["k"] % nbuf
         state["k"] += 1
-        drain(i)                             # the gather that last read this buffer must be done
+        drain(i)                             # the gathers that last read this buffer must be done
         ll_i, dos_i = logliks[i], dosages[i]
         ctx.sweep_device(0, n, factors.data_ptr(), ll_i.data_ptr(), dos_i.data_ptr(),
                          (capi.FULL_SPILL if args.full_spill else 0) | args.extra_flags)
         ctx.sync()
         kernel_ms.append(ctx.last_kernel_ms())
         if do_gather:
-            # the one collective of the path: posteriors to rank 0 over xGMI (RCCL).  With overlap the
-            # call only enqueues it: it runs beside the next sweep and is awaited before its buffer is
-            # reused (and at the end of the timed region).
+            # with overlap the calls below only enqueue: the tile gathers run beside the next sweep (own
+            # streams; the sweep leaves --reserve-blocks workgroup slots to the RCCL kernels) and are awaited
+            # before their buffer is reused and at the end of the timed region
             tg = time.perf_counter()
             src_ll = ll_i.cpu() if staged else ll_i
             src_d = dos_i.cpu() if staged else dos_i
-            if overlap:
-                out_ll = gather_ll if rank == 0 else None
-                out_d = gather_list if rank == 0 else None
-                pending[i].append(dist.gather(src_ll, out_ll, dst=0, async_op=True))
-                pending[i].append(dist.gather(src_d, out_d, dst=0, async_op=True))
-                keep_alive[i] = (src_ll, src_d)
-            else:
-                cdist.gather_to_root(src_ll, 0, gather_ll if rank == 0 else None)
-                cdist.gather_to_root(src_d, 0, gather_list if rank == 0 else None)
-                torch.cuda.synchronize()
+            works = [dist.gather(src_ll, gather_ll if rank == 0 else None, dst=0, async_op=True)]
+            tiler.run(src_d, consume)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending[i] = (works, ev, src_ll, src_d)
+            if not overlap:
+                drain(i)
             gather_ms.append((time.perf_counter() - tg) * 1e3)
-
-    keep_alive = [None] * nbuf
 
     def finish():
         for i in range(nbuf):
@@ -288,7 +338,7 @@ def main():
 
     if do_gather:
         # set up the point-to-point connections of the gather before anything is timed
-        tiny = torch.zeros(8, dtype=torch.float64, device=torch.device("cpu") if staged else device)
+        tiny = torch.zeros(8, dtype=torch.float64, device=gdev)
         cdist.gather_to_root(tiny, 0)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -296,6 +346,7 @@ def main():
     finish()
     kernel_ms.clear()
     gather_ms.clear()
+    gsum.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -318,10 +369,14 @@ def main():
         value = units_per_step * args.steps / dt
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = (float(n) * M * B_UNIT) / (k_ms * 1e-3) / 1e9   # GB/s, this rank's launch
+        # HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json, written by
+        # tools/profile_round.sh): reported only if it was measured for THIS workload and THESE kernel sources
         traffic = None
+        src_sha = kernel_source_sha()
         try:
             tj = json.load(open(args.traffic_file))
-            if tj.get("inds") == n and tj.get("markers") == M:
+            if (tj.get("inds") == n and tj.get("markers") == M and tj.get("kernel_src_sha") == src_sha
+                    and args.workload == "f2" and not args.extra_flags and not args.full_spill):
                 traffic = tj.get("bytes_per_launch")
         except Exception:
             traffic = None
@@ -343,7 +398,7 @@ def main():
         # (exact; the F2's empty F1 parents make the four shift modes that share s0 bit-identical, see DESIGN.md
         # 5b) -- reported next to the headline, never as the headline
         merge_info = None
-        if world == 1 and not args.extra_flags and not args.full_spill and not args.no_merge_probe:
+        if world == 1 and not args.extra_flags and not args.full_spill and not args.no_merge_probe and args.workload == "f2":
             ns = min(n, 512)
             rows_h = dosage[:ns].clone()
             ll_h = loglik.clone()
@@ -365,24 +420,29 @@ def main():
             "value": value, "unit": "individual*marker/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic F2 intercross, %d individuals x %d SNPs per GPU (%d chromosomes x %d + 1 "
-                                   "dummy marker each = %d markers swept), private empty F1 parents, 2 inbred founders"
-                                   % (n, args.chroms * args.snps_per_chrom, args.chroms, args.snps_per_chrom, M),
+            "config": {"workload": workload,
                        "individuals_per_gpu": n, "markers": M, "shift_modes": 8, "states": 64,
                        "parallelism": "individuals sharded over %d GPU(s)%s" % (
-                           world, (", one RCCL gather of posteriors to rank 0 per step" +
-                                   (" (overlapped with the next sweep)" if overlap else "")) if do_gather else "")},
+                           world, (", posteriors gathered to rank 0 per step in tiles of %d markers (%d tiles, rank 0 "
+                                   "holds 2 tiles x %d ranks = %.2f GB)%s"
+                                   % (tile_markers, tiler.n_tiles(), world, tiler.root_bytes() / 1e9,
+                                      ", overlapped with the next sweep" if overlap else "")) if do_gather else "")},
+            # achieved / frac: ALGORITHMIC bytes (8 248 B per unit, textbook forward-backward) over the
+            # kernel's time.  traffic / frac_physical: what the HBM counters saw for the same launch (the half
+            # spill moves about half the textbook bytes), null when not measured for these kernel sources.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
+                         "frac_physical": (traffic / (k_ms * 1e-3) / HBM_PEAK) if traffic else None,
                          "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_unit": B_UNIT},
+                         "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
             "checks": checks,
             "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,
+            "gather_checksum": float(gsum.item()) if do_gather else None,
         }
         if merge_info:
             out["merge_modes"] = merge_info
-        if args.cpu_seconds > 0 and world == 1:      # CPU baseline leg: rank 0 at N = 1 only
+        if args.cpu_seconds > 0 and world == 1 and sample is not None:      # CPU baseline leg: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(sample, pos, starts, args)
                 out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]

@@ -30,6 +30,69 @@ def gather_to_root(t, dst=0, out=None):
     return out
 
 
+class TiledGather:
+    """Streaming gather of a [n_ind, n_markers, k] device (or CPU) tensor to rank `dst` in marker tiles.
+
+    Rank `dst` never holds more than `depth` tiles x world_size (at BASELINE config 4 the
+    posteriors are 60 GB per GPU, 480 GB in all -- they do not fit one GPU, so the root consumes them tile by
+    tile: `consume(m0, m1, parts)` is called on `dst` with the list of world_size tensors [n_ind, m1-m0, k]
+    of ranks 0..world-1, valid until the next call that reuses the buffer).  The marker slice is strided in
+    the source, so every rank packs it into a contiguous staging buffer first; with `depth` = 2 the gather of
+    tile t runs (async_op) while tile t+1 is packed.  One collective (gather) per tile, nothing else."""
+
+    def __init__(self, n_ind, n_markers, k, tile_markers, dtype, device, dst=0, depth=2):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.dst, self.depth = dst, max(1, depth)
+        self.n_markers = n_markers
+        self.tile = max(1, min(int(tile_markers), n_markers))
+        shape = (n_ind, self.tile, k)
+        self.stage = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.recv = None
+        if self.rank == dst and self.world > 1:
+            self.recv = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)]
+                         for _ in range(self.depth)]
+
+    def root_bytes(self):
+        """Bytes this object holds on the root for receiving (the bound the design promises)."""
+        if self.recv is None:
+            return 0
+        return sum(t.numel() * t.element_size() for bufs in self.recv for t in bufs)
+
+    def n_tiles(self):
+        return (self.n_markers + self.tile - 1) // self.tile
+
+    def run(self, src, consume=None):
+        """Gather `src` [n_ind, n_markers, k]; returns the number of tiles sent."""
+        pending = [None] * self.depth    # (work, m0, m1) per buffer
+        def finish(i):
+            if pending[i] is None:
+                return
+            work, m0, m1 = pending[i]
+            if work is not None:
+                work.wait()
+            if self.rank == self.dst and consume is not None:
+                w = m1 - m0
+                parts = ([self.stage[i][:, :w]] if self.world == 1 else [t[:, :w] for t in self.recv[i]])
+                consume(m0, m1, parts)
+            pending[i] = None
+        t = 0
+        for m0 in range(0, self.n_markers, self.tile):
+            m1 = min(m0 + self.tile, self.n_markers)
+            i = t % self.depth
+            finish(i)
+            self.stage[i][:, :m1 - m0].copy_(src[:, m0:m1])
+            work = None
+            if self.world > 1:
+                work = dist.gather(self.stage[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst,
+                                   async_op=True)
+            pending[i] = (work, m0, m1)
+            t += 1
+        for j in range(self.depth):
+            finish((t + j) % self.depth)
+        return t
+
+
 def gather_ragged_to_root(a, dst=0):
     """Gather numpy arrays whose first dimension differs per rank (block partition);
     returns the concatenation on `dst`, None elsewhere."""

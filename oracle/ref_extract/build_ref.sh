@@ -62,6 +62,8 @@ echo '#include "settings.h"' >> "$TU"
 r 146 147
 r 156 160
 r 171 239
+r 242 242
+r 291 291
 r 303 353
 echo 'template<class K, class T, int N = 2> using small_map = std::map<K, T>;' >> "$TU"
 r 372 380
@@ -77,7 +79,9 @@ r 575 795
 r 834 850
 r 853 2445
 r 2448 2514
+r 3045 3097
 r 3099 3187
+r 3190 3412
 r 3462 3496
 r 3553 3570
 r 3577 3616

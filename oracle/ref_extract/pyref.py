@@ -48,6 +48,11 @@ def lib(ieee=True):
         L.ref_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_sweep_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_postmarkerdata.argtypes = [C.c_int]
+        L.ref_get_marker.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_get_counts.argtypes = [C.c_int, C.c_void_p]
+        L.ref_get_variance.argtypes = [C.c_int, C.c_int]
+        L.ref_get_variance.restype = C.c_double
         _libs[key] = L
     return _libs[key]
 
@@ -140,6 +145,29 @@ class RefPed:
         self.L.ref_accumulate(ns.ctypes.data, gens.ctypes.data, len(ns), first, last, desc.ctypes.data, R,
                               inf.ctypes.data, hb.ctypes.data, hc.ctypes.data, hz.ctypes.data)
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
+
+    def postmarkerdata(self):
+        """The reference's own postmarkerdata (cnF2freq.cpp:3190-3412) as main() calls it (8083-8085), on the loaded
+        pedigree (load it with fixtrees_all=False: main runs it straight after the readers).  Returns the state it
+        leaves: allele [R][M][2], sure [R][M][2], hw [R][M], descendants / children / founder [R], variances [R][M]."""
+        R, M = self.ped.n_rec, self.M
+        self.L.ref_postmarkerdata(R + 1)
+        allele = np.zeros((R, M, 2), np.int32)
+        sure = np.zeros((R, M, 2))
+        hw = np.zeros((R, M))
+        var = np.zeros((R, M))
+        cnt = np.zeros((R, 3), np.int32)
+        buf = np.zeros(5)
+        for r in range(R):
+            self.L.ref_get_counts(r + 1, cnt[r].ctypes.data)
+            for m in range(M):
+                self.L.ref_get_marker(r + 1, m, buf.ctypes.data)
+                allele[r, m] = buf[:2]
+                sure[r, m] = buf[2:4]
+                hw[r, m] = buf[4]
+                var[r, m] = self.L.ref_get_variance(r + 1, m)
+        return dict(allele=allele, sure=sure, hw=hw, descendants=cnt[:, 0].copy(), children=cnt[:, 1].copy(),
+                    founder=cnt[:, 2].copy(), variances=var)
 
     def addvariance(self, rec, marker, flag2ignore):
         v = C.c_double(0.0)

@@ -66,3 +66,53 @@ def test_two_rank_sweep_and_gather_equals_single_rank():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _tile_worker(rank, world, port, q):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, M = 5, 23
+    src = torch.arange(n * M * 3, dtype=torch.float64).reshape(n, M, 3) + 1000.0 * rank
+    tg = cdist.TiledGather(n, M, 3, 6, torch.float64, torch.device("cpu"), dst=0, depth=2)
+    got = np.zeros((world, n, M, 3))
+    calls = []
+
+    def consume(m0, m1, parts):
+        calls.append((m0, m1))
+        for r, t in enumerate(parts):
+            got[r, :, m0:m1] = t.numpy()
+
+    nt = tg.run(src, consume)
+    if rank == 0:
+        want = np.stack([(np.arange(n * M * 3, dtype=np.float64).reshape(n, M, 3) + 1000.0 * r) for r in range(world)])
+        ok = (np.array_equal(got, want) and calls == [(0, 6), (6, 12), (12, 18), (18, 23)] and nt == 4
+              and tg.root_bytes() == 2 * world * n * 6 * 3 * 8)
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_marker_tiled_gather_two_ranks():
+    """The root holds depth x world tiles, never the whole posterior (BASELINE config 4 would be 480 GB)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_marker_tiled_gather_single_process():
+    import torch
+    n, M = 3, 10
+    src = torch.rand(n, M, 3, dtype=torch.float64)
+    tg = cdist.TiledGather(n, M, 3, 4, torch.float64, torch.device("cpu"))
+    out = torch.zeros_like(src)
+    tg.run(src, lambda m0, m1, parts: out[:, m0:m1].copy_(parts[0]))
+    assert torch.equal(out, src) and tg.root_bytes() == 0

@@ -15,9 +15,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -- \
         python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $out/$c.log 2>&1 || echo "$c pass failed"
 done
-python3 - "$out" "$tag" <<'PY'
-import csv, glob, json, sys
-out, tag = sys.argv[1], sys.argv[2]
+python3 - "$out" "$tag" "$R" <<'PY'
+import csv, glob, hashlib, json, os, sys
+out, tag, root = sys.argv[1], sys.argv[2], sys.argv[3]
+h = hashlib.sha256()          # same identity as bench.py kernel_source_sha()
+for f in ("cnf2_kernels.hip", "cnf2_emtab.h", "cnf2_emission.h", "cnf2_lane.h", "cnf2_device.h"):
+    h.update(open(os.path.join(root, "cnf2freq_amd", "csrc", f), "rb").read())
+src_sha = h.hexdigest()[:16]
 def rows(pattern):
     for f in glob.glob(out + pattern, recursive=True):
         yield from csv.DictReader(open(f))
@@ -42,7 +46,7 @@ def per_launch(counter):
 fetch_kb, write_kb = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
 inds, markers = 10000, 50020
 fb, wb = fetch_kb * 1024 * 2, write_kb * 1024
-json.dump({"inds": inds, "markers": markers, "kernel": "cnf2::fb_fast_kernel<true>",
+json.dump({"inds": inds, "markers": markers, "kernel": "cnf2::fb_fast_kernel<true>", "kernel_src_sha": src_sha,
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "correction": "FETCH_SIZE x2 on gfx950 for wide coalesced reads; WRITE_SIZE exact (MI355X_MICROARCH.md section HBM); separate --pmc passes",
            "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb,
