@@ -1,0 +1,325 @@
+// cnf2_update.h -- the per-iteration parameter updates that close a haplotyping iteration of cnF2freq
+// (SURVEY.md section 8(f)-4): what processinfprobs (cnF2freq.cpp:4179-4323), updatehaploweights
+// (cnF2freq.cpp:4533-4734), relskewhmm (cnF2freq.cpp:4325-4466), cappedgd and caplogitchange
+// (cnF2freq.cpp:4004-4177) do to one (individual, marker), restated as pure functions over plain numbers.
+// Host + device: the library runs them as kernels over the device-resident accumulators (cnf2_kernels.hip),
+// the host build exists so that the arithmetic is unit-tested without a GPU against the oracle's literal
+// restatement (tests/shim, tests/test_host_update.py).
+//
+// Every parameter p in (0, 1) (a genotype certainty or a haplotype weight) is moved along the flow
+// dp/dt = G(p) of a gradient G for a fixed "time" (scalefactor): the new value q solves
+//     integral_p^q dx / G(x) = scalefactor,
+// found by bisection with a 15-point Gauss-Legendre rule for the integral, inside a cap on how far a value may
+// move in one iteration.  The reference takes the rule from boost::math::quadrature::gauss<double, 15>
+// (cnF2freq.cpp:4150); Boost is not part of this build, the nodes and weights below are the published ones of the
+// 15-point rule and the summation order is Boost's (centre node first, then node pairs outwards).
+#ifndef CNF2_UPDATE_H
+#define CNF2_UPDATE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CNF2_UHD __host__ __device__ inline
+#else
+#define CNF2_UHD inline
+#endif
+
+namespace cnf2 {
+
+// maxdiff is a float in the reference (cnF2freq.cpp:228) and is promoted where it is used
+#define CNF2_MAXDIFF ((double)0.000005f)
+
+struct StepControl {
+    double scalefactor;     // cnF2freq.cpp:3573 (0.013 at start, adapted after every update pass, 6373-6392)
+    double entropyfactor;   // cnF2freq.cpp:3574 (1)
+};
+
+// ------------------------------------------------------------------ 15-point Gauss-Legendre
+CNF2_UHD double gl15_node(int i)
+{
+    const double x[8] = {0.0,
+                         0.20119409399743452230062830339460,
+                         0.39415134707756336989720737098105,
+                         0.57097217260853884753722673725391,
+                         0.72441773136017004741618605461394,
+                         0.84820658341042721620064832077422,
+                         0.93727339240070590430775894771021,
+                         0.98799251802048542848956571858661};
+    return x[i];
+}
+CNF2_UHD double gl15_weight(int i)
+{
+    const double w[8] = {0.20257824192556127288062019996752,
+                         0.19843148532711157645611832644384,
+                         0.18616100001556221102680056186642,
+                         0.16626920581699393355320086048121,
+                         0.13957067792615431444780479451103,
+                         0.10715922046717193501186954668587,
+                         0.07036604748810812470926741645067,
+                         0.03075324199611726835462839357720};
+    return w[i];
+}
+
+template <class F>
+CNF2_UHD double gauss15(F&& f, double a, double b)
+{
+    const double mid = (a + b) * 0.5, half = (b - a) * 0.5;
+    double acc = f(mid) * gl15_weight(0);
+    for (int i = 1; i < 8; i++) {
+        const double fp = f(mid + half * gl15_node(i));
+        const double fm = f(mid + half * -gl15_node(i));
+        acc += (fp + fm) * gl15_weight(i);
+    }
+    return half * acc;
+}
+
+// ------------------------------------------------------------------ cap on one iteration's move
+// caplogitchange (cnF2freq.cpp:4006-4038) with nnn = 3: a value may rise by at most 2p(1-p)/(1+2p) and fall by at
+// most 2p(1-p)/(3-2p); a capped move that stays on the far side of 1/2 counts as a "hit" (the step-size control of
+// cnF2freq.cpp:6373-6392 watches their number).  breakathalf: a move across 1/2 stops half way to it.
+CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits, bool breakathalf)
+{
+    const double room = (2.0 * orig) * (1.0 - orig);
+    const double up = room / (1.0 + 2.0 * orig), down = room / (3.0 - 2.0 * orig);
+    const double top = 1.0 - epsilon;
+    intended = (top < intended) ? top : intended;
+    intended = (intended < epsilon) ? epsilon : intended;
+    const double diff = intended - orig;
+    if (diff > up) {
+        intended = orig + up;
+        if (intended < 0.5) ++*hits;
+    }
+    if (diff < -down) {
+        intended = orig - down;
+        if (intended > 0.5) ++*hits;
+    }
+    if (breakathalf && (intended - 0.5) * (orig - 0.5) < 0) intended = 0.5 * (0.5 + orig);
+    return intended;
+}
+
+// cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): gradient(x) -> dp/dt at x.
+template <class G>
+CNF2_UHD double flow_step(G&& gradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
+{
+    const double top = 1.0 - epsilon;
+    auto pace = [&](double v) -> double {          // dt/dp: reciprocal of the gradient at the clamped position
+        v = (v < epsilon) ? epsilon : ((top < v) ? top : v);
+        return 1.0 / gradient(v);
+    };
+    int          ignored = 0;
+    // bisection bracket: slightly wider than the cap, so that the final cap_step is the one that counts the hit
+    const double lolim = cap_step(epsilon, orig, epsilon, &ignored, breakathalf);
+    const double hilim = cap_step(top, orig, epsilon, &ignored, breakathalf);
+    double       lo = lolim - epsilon * 0.125, hi = hilim + epsilon * 0.125;
+    orig = cap_step(orig, orig, epsilon, &ignored, breakathalf);
+    const double g0 = pace(orig);
+    if (!isfinite(g0) || !scalefactor) lo = hi = orig;
+    const bool falling = g0 < 0;
+    if (falling) hi = orig;
+    else lo = orig;
+    for (int it = 0; it < 51 && scalefactor; it++) {
+        if (lo > hilim || hi < lolim) break;                 // outside the true bounds
+        const double mid = (lo + hi) / 2;
+        const double gm = pace(mid);
+        double       t;                                      // time the flow needs from orig to mid
+        if (((gm < 0) != falling) || !isfinite(gm)) {
+            t = (scalefactor + 0.1) * 1.1;                    // the gradient turns round before mid: too far
+        } else {
+            double a = orig, b = mid;
+            if (a > b) {
+                const double s = a;
+                a = b;
+                b = s;
+            }
+            if (b - a < 1e-10) break;
+            t = gauss15(pace, a, b);
+            if (b != mid) t = -t;
+            if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+        }
+        if (fabs(t - scalefactor) < scalefactor * 1e-3) break;
+        if ((t < scalefactor) != falling) lo = mid;
+        else hi = mid;
+    }
+    if (!scalefactor) lo = hi = orig;
+    return cap_step((lo + hi) / 2, orig, epsilon, hits, breakathalf);
+}
+
+// The data term shared by both updates.  With a current value y of the parameter, g the evidence for "1" gathered
+// at y and h the total evidence, the reference differentiates
+//     val(x) = (H (1-x) log(1-x) + G x log x) / (H (1-x) + G x),   G = g / y,  H = (h - g) / (1 - y)
+// and writes the derivative out as one long polynomial in (y, g, h, log x, log(1-x))
+// (cnF2freq.cpp:4275, 4684).  Multiplying G and H through by y (1 - y) gives the same derivative in the
+// division-free form used here:  a = g (1-y), b = (h-g) y, Q = b (1-x) + a x,
+//     val'(x) = (a b (log x - log(1-x)) + (a - b) Q) / Q^2.
+CNF2_UHD double evidence_slope(double y, double g, double h, double x)
+{
+    const double a = g * (1.0 - y), b = (h - g) * y;
+    const double q = b * (1.0 - x) + a * x;
+    return (a * b * (log(x) - log(1.0 - x)) + (a - b) * q) / (q * q);
+}
+
+// ------------------------------------------------------------------ genotype certainties (processinfprobs)
+// One side (allele index) of one individual at one marker.  inf[v-1] = accumulated evidence for allele value v
+// (moveinfprobs, cnF2freq.cpp:3577-3597); an entry takes part if it is > 0 (the reference iterates a map that
+// holds an entry for every value that was ever added to; values are sums of positive terms).
+struct SideState {
+    int    allele;        // markerdata[side]: 0 unknown, 1, 2, 9
+    double sure;          // markersure[side]
+    int    prior_allele;  // priormarkerdata[side] or 0 when the individual has no prior (not genotyped)
+    double prior_sure;
+};
+
+// Returns true when the side's allele / sure are to be overwritten with *new_allele / *new_sure
+// (cnF2freq.cpp:4303-4313: non-empty individuals that have a prior, i.e. that were genotyped).
+CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side, bool empty, bool has_prior,
+                               int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure)
+{
+    double sum = 0;
+    for (int v = 0; v < 2; v++)
+        if (inf[v] > 0) sum += inf[v];
+    const double ef = sc.entropyfactor;                       // exp(0 * -0.01 * iter) * entropyfactor
+    const double epsilon = CNF2_MAXDIFF / (children + 1);
+    double       out[2] = {0, 0};
+    for (int v = 0; v < 2; v++) {
+        if (!(inf[v] > 0)) continue;
+        const int value = v + 1;
+        double    curprob = 0.5;
+        if (s.allele != 0) curprob = fabs((s.allele == value ? 1 : 0) - s.sure);
+        const double evidence = inf[v];
+        double       priord = 0;
+        if (s.prior_allele != 0) {                            // cnF2freq.cpp:4245-4268
+            double priorprob = 1.0 - s.prior_sure;
+            if (value != s.prior_allele) priorprob = 1.0 - priorprob;
+            if (priorprob == 0) priord -= 10000;
+            else if (priorprob == 1) priord += 10000;
+            else {
+                priorprob = priorprob < 1e-14 ? 1e-14 : (priorprob > 1 - 1e-14 ? 1 - 1e-14 : priorprob);
+                priord += log(priorprob) - log(1 - priorprob);
+            }
+        }
+        auto gradient = [&](double x) -> double {
+            double d = evidence_slope(curprob, evidence, sum, x);
+            d += ef * log(1 / x - 1);                         // entropy term
+            d += ef * priord;
+            return d;
+        };
+        out[v] = flow_step(gradient, curprob, epsilon, sc.scalefactor, hits, false);
+    }
+    int    best = 0;
+    double bestprob = 0;
+    for (int v = 0; v < 2; v++) {
+        if (!(inf[v] > 0)) continue;
+        if (out[v] > bestprob - (side ? 1e-30 : 0)) {          // cnF2freq.cpp:4292-4300
+            best = v + 1;
+            bestprob = out[v];
+        }
+    }
+    if (!empty && (best != 0 || bestprob > 0) && has_prior) {
+        *new_allele = best;
+        *new_sure = 1.0 - bestprob;
+        return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ phase-consistency ratio (relskewhmm)
+// The two-state chain over the markers [first, end) of one chromosome: emission (1 - w, w) from the haplotype
+// weights, transition "stay" with probability relhaplo[m].  ratio[m - first] = posterior of state 1 as the
+// constructor leaves it (cnF2freq.cpp:4340-4441; forward values include the emission at m, the backward pass
+// includes the emissions after m).  fw is scratch of 2 (end - first) doubles.
+CNF2_UHD void phase_ratio(const double* hw, const double* relhaplo, int first, int end, double* fw, double* ratio)
+{
+    double s0 = 0.5, s1 = 0.5;
+    auto emit = [&](int m) {
+        const double w = hw[m];
+        s0 *= fabs(1 - w);
+        s1 *= fabs(0 - w);
+    };
+    auto move = [&](int m) {
+        const double n = relhaplo[m], nb = 1 - n;
+        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+        s0 = t0;
+        s1 = t1;
+    };
+    auto rescue = [&]() {
+        if (s0 + s1 < 1e-10) {
+            s0 *= 1e20;
+            s1 *= 1e20;
+        }
+    };
+    for (int m = first; m < end; m++) {
+        emit(m);
+        fw[(m - first) * 2] = s0;
+        fw[(m - first) * 2 + 1] = s1;
+        rescue();
+        move(m);
+    }
+    s0 = s1 = 0.5;
+    const int last = end - first - 1;
+    ratio[last] = fw[last * 2 + 1] / (fw[last * 2] + fw[last * 2 + 1]);
+    for (int m = end - 2; m >= first; m--) {
+        emit(m + 1);
+        move(m);
+        rescue();
+        const double r0 = s0 * fw[(m - first) * 2], r1 = s1 * fw[(m - first) * 2 + 1];
+        ratio[m - first] = r1 / (r0 + r1);
+    }
+}
+
+// ------------------------------------------------------------------ haplotype weights (updatehaploweights)
+// One marker of one individual whose chromosome has any information (some haplocount != 0) and whose weight is
+// neither 0 nor 1 (locked).  haplobase / haplocount are read AND rewritten (the reference leaves the adjusted
+// values in place, cnF2freq.cpp:4660-4676: they are what a later pass of the same iteration sees).
+CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0,
+                                   double sure1, double phaseratio, int children, int descendants,
+                                   const StepControl& sc, bool breakathalf, int* hits)
+{
+    const double scorea = 1.0 - sure0;
+    double       scoreb = 1.0 - sure1;
+    if (a0 != a1) scoreb = 1 - scoreb;
+    double similarity = scorea * scoreb + (1 - scorea) * (1 - scoreb);
+    if (!*haplocount || similarity == 1.0) {
+        *haplocount = (*haplocount < 1.0) ? 1.0 : *haplocount;
+        *haplobase  = hw * *haplocount;
+    } else {
+        if (similarity >= 1 - CNF2_MAXDIFF) similarity = 1 - CNF2_MAXDIFF;
+        double count = *haplocount;
+        *haplobase -= count * hw;
+        count = count - similarity * count;
+        *haplobase += count * hw;
+        *haplobase *= *haplocount / count;
+        if (*haplobase < 0) *haplobase = 0;
+        if (*haplobase >= *haplocount) *haplobase = *haplocount;
+    }
+    const double ef = sc.entropyfactor;
+    const double b = *haplobase, c = *haplocount;
+    auto gradient = [&](double x) -> double {
+        double d = evidence_slope(hw, b, c, x);
+        d += ((1 - similarity) * 1 * (ef * log(1 / x - 1)) + (phaseratio - x) / (x - x * x) * descendants);
+        return d;
+    };
+    return flow_step(gradient, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
+}
+
+// Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).
+struct StepHistory {
+    int oldhits = 0, oldhits2 = 0;
+};
+CNF2_UHD void adapt_scalefactor(StepControl* sc, StepHistory* h, int hits, int n_analysed)
+{
+    const int  mx = h->oldhits > h->oldhits2 ? h->oldhits : h->oldhits2;
+    const int  mn = h->oldhits < h->oldhits2 ? h->oldhits : h->oldhits2;
+    const int  floorhits = n_analysed / 7;                    // dous.size() / TURNBITS
+    const bool bad = hits > mx;
+    if (bad) sc->scalefactor /= 1.1;
+    const bool good = hits < (mn > floorhits ? mn : floorhits) * 0.99;
+    if (good) sc->scalefactor *= 1.21;
+    sc->scalefactor *= 0.997;
+    h->oldhits2 = h->oldhits;
+    h->oldhits  = hits;
+}
+
+} // namespace cnf2
+#endif

@@ -189,6 +189,20 @@ int cnf2o_sweep_batch(const cnf2o_ped *P, const int *inds, const int *gens, int 
                       int first, int last, double *factors_out, double *factor_out,
                       double *dosage_out, int mode, int n_threads);
 
+/* ---- per-iteration parameter updates (cnf2_oracle_iter.c; PARITY UNPINNED, see the header of that file) ---- */
+double cnf2o_caplogitchange(double intended, double orig, double epsilon, int *hitnnn, int breakathalf);
+int    cnf2o_processinfprobs(const double inf_in[2], const int present[2], int side, int curmarker, double cursure,
+                             int has_prior, int priorval, double priorsure, int empty, int children,
+                             double scalefactor, double entropyfactor, int *hitnnn, double inf_out[2],
+                             int *out_allele, double *out_sure);
+void   cnf2o_relskew_ratio(const double *haploweight, const double *relhaplo, int firstmarker, int endmarker,
+                           double *ratio);
+void   cnf2o_updatehaploweights(int n_chrom, const int *chromstarts, double *haploweight, double *haplobase,
+                                double *haplocount, const int32_t *allele, const double *sure, const double *relhaplo,
+                                int children, int descendants, double scalefactor, double entropyfactor, int *hitnnn);
+double cnf2o_scalefactor_step(double scalefactor, int hitnnn, int *old, int n_dous);
+double cnf2o_gauss15_reciprocal_linear(double slope, double icpt, double a, double b);
+
 #ifdef __cplusplus
 }
 #endif

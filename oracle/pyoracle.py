@@ -51,13 +51,14 @@ class _Fwbw(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (building the checker is not using it)."""
-    src = os.path.join(_HERE, "cnf2_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("cnf2_oracle.c", "cnf2_oracle_iter.c", "cnf2_oracle_pre.c")]
+    srcs = [f for f in srcs if os.path.exists(f)]
     if (not force and os.path.exists(_LIB)
-            and os.path.getmtime(_LIB) >= max(os.path.getmtime(src),
-                                              os.path.getmtime(os.path.join(_HERE, "cnf2_oracle.h")))):
+            and os.path.getmtime(_LIB) >= max([os.path.getmtime(f) for f in srcs] +
+                                              [os.path.getmtime(os.path.join(_HERE, "cnf2_oracle.h"))])):
         return _LIB
     subprocess.check_call(["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared",
-                           "-o", _LIB, src, "-lm"], cwd=_HERE)
+                           "-o", _LIB] + srcs + ["-lm"], cwd=_HERE)
     return _LIB
 
 
@@ -108,6 +109,20 @@ def lib():
         L.cnf2o_sweep_batch.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.cnf2o_sweep_batch.restype = C.c_int
+        D = C.c_double
+        IP = C.POINTER(C.c_int)
+        L.cnf2o_caplogitchange.argtypes = [D, D, D, IP, C.c_int]
+        L.cnf2o_caplogitchange.restype = D
+        L.cnf2o_processinfprobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, D, C.c_int, C.c_int, D, C.c_int,
+                                            C.c_int, D, D, IP, C.c_void_p, IP, C.POINTER(D)]
+        L.cnf2o_processinfprobs.restype = C.c_int
+        L.cnf2o_relskew_ratio.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.cnf2o_updatehaploweights.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, D, D, IP]
+        L.cnf2o_scalefactor_step.argtypes = [D, C.c_int, C.c_void_p, C.c_int]
+        L.cnf2o_scalefactor_step.restype = D
+        L.cnf2o_gauss15_reciprocal_linear.argtypes = [D, D, D, D]
+        L.cnf2o_gauss15_reciprocal_linear.restype = D
         _lib = L
     return _lib
 

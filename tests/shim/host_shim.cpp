@@ -2,6 +2,7 @@
 // (tests/test_host_emission.py).  Compiled with g++ from the same headers the HIP
 // kernels include; contains no algorithmic code of its own beyond the lane loop.
 #include <string.h>
+#include <vector>
 
 #include "cnf2_lane.h"
 #include "cnf2_emtab.h"
@@ -21,6 +22,8 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
     derive_founders(P);
     return P;
 }
+
+#include "cnf2_update.h"
 
 extern "C" {
 
@@ -224,5 +227,61 @@ int shim_accum_infprobs(int n_rec, const int32_t* par, const uint8_t* empty, con
         for (int g = 0; g < 64; g++)
             if (wg[s * 64 + g] != 0.0) accum_infprobs(w, slot, g, s, wg[s * 64 + g], no_ties != 0, inf_out, hz_out);
     return w.n_groups;
+}
+
+// ---- per-iteration updates (cnf2_update.h) ----
+double shim_cap_step(double intended, double orig, double epsilon, int* hits, int breakathalf)
+{
+    return cnf2::cap_step(intended, orig, epsilon, hits, breakathalf != 0);
+}
+double shim_gauss15_reciprocal_linear(double slope, double icpt, double a, double b)
+{
+    return cnf2::gauss15([&](double x) { return 1.0 / (slope * x + icpt); }, a, b);
+}
+double shim_evidence_slope(double y, double g, double h, double x) { return cnf2::evidence_slope(y, g, h, x); }
+int shim_update_certainty(const double* inf, int side, int allele, double sure, int has_prior, int prior_allele,
+                          double prior_sure, int empty, int children, double scalefactor, double entropyfactor,
+                          int* hits, int* new_allele, double* new_sure)
+{
+    cnf2::SideState s = {allele, sure, has_prior ? prior_allele : 0, prior_sure};
+    cnf2::StepControl sc = {scalefactor, entropyfactor};
+    return cnf2::update_certainty(inf, s, side, empty != 0, has_prior != 0, children, sc, hits, new_allele, new_sure) ? 1 : 0;
+}
+void shim_phase_ratio(const double* hw, const double* relhaplo, int first, int end, double* ratio)
+{
+    std::vector<double> fw((size_t)(end - first) * 2);
+    cnf2::phase_ratio(hw, relhaplo, first, end, fw.data(), ratio);
+}
+// updatehaploweights for one individual: every marker of the chromosomes that have any haplocount
+void shim_update_haploweights(int n_chrom, const int* chromstarts, double* hw, double* haplobase, double* haplocount,
+                              const int32_t* allele, const double* sure, const double* relhaplo, int children,
+                              int descendants, double scalefactor, double entropyfactor, int* hits)
+{
+    cnf2::StepControl sc = {scalefactor, entropyfactor};
+    for (int c = 0; c < n_chrom; c++) {
+        const int c0 = chromstarts[c], c1 = chromstarts[c + 1];
+        bool any = false;
+        for (int k = c0; k < c1; k++) any |= (haplocount[k] != 0);
+        if (!any) continue;
+        std::vector<double> fw((size_t)(c1 - c0) * 2), ratio(c1 - c0);
+        cnf2::phase_ratio(hw, relhaplo, c0, c1, fw.data(), ratio.data());
+        for (int j = c0; j < c1; j++) {
+            if (!(hw[j] != 0 && hw[j] != 1)) continue;
+            hw[j] = cnf2::update_haploweight(hw[j], &haplobase[j], &haplocount[j], allele[j * 2], allele[j * 2 + 1],
+                                             sure[j * 2], sure[j * 2 + 1], ratio[j - c0], children, descendants, sc,
+                                             false, hits);
+        }
+    }
+}
+double shim_adapt_scalefactor(double scalefactor, int hits, int* old, int n_analysed)
+{
+    cnf2::StepControl sc = {scalefactor, 1.0};
+    cnf2::StepHistory h;
+    h.oldhits = old[0];
+    h.oldhits2 = old[1];
+    cnf2::adapt_scalefactor(&sc, &h, hits, n_analysed);
+    old[0] = h.oldhits;
+    old[1] = h.oldhits2;
+    return sc.scalefactor;
 }
 }
