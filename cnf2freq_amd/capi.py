@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CNF2HIP_LIB: another build of the same library (kernel A/B timing); still the HIP path, never a fallback
 LIB_PATH = os.environ.get("CNF2HIP_LIB") or os.path.join(_HERE, "libcnf2hip.so")
 
-OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES = 1, 2, 4, 8, 16, 32
+OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP = 1, 2, 4, 8, 16, 32, 64, 128
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -72,6 +72,7 @@ def load():
         L.cnf2_addvariance.argtypes = [vp, i32, i32, vp]
         L.cnf2_descendants.argtypes = [vp, vp]
         L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
+        L.cnf2_sweep_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
@@ -268,6 +269,33 @@ class Context:
         self._chk(self.L.cnf2_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(inf), _p(hb), _p(hc), _p(hz),
                                          0 if ties else NO_TIES), "cnf2_accumulate")
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
+
+    def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False):
+        """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device."""
+        ind_end = self.n_ind if ind_end is None else ind_end
+        n = ind_end - ind_begin
+        desc = np.ascontiguousarray(desc, np.int32)
+        factors = np.zeros((n, self.n_chrom, 8))
+        loglik = np.zeros((n, self.n_chrom))
+        dos = np.zeros((n, self.n_markers, 3))
+        inf = np.zeros((self.n_rec, self.n_markers, 2, 2))
+        hb = np.zeros((self.n_rec, self.n_markers))
+        hc = np.zeros((self.n_rec, self.n_markers))
+        hz = np.zeros((n, self.n_markers, 2))
+        self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(factors), _p(loglik), _p(dos),
+                                               _p(inf), _p(hb), _p(hc), _p(hz),
+                                               (0 if ties else NO_TIES) | (RAW_DOSAGE if raw else 0)),
+                  "cnf2_sweep_accumulate")
+        return dict(factors=factors, loglik=loglik, dosage=dos, infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
+
+    def sweep_accumulate_device(self, desc, ind_begin, ind_end, d_factors, d_loglik, d_dosage, d_inf, d_hb, d_hc, d_hz,
+                                flags=0):
+        """Device-pointer form (ints): outputs and accumulators stay on the GPU; only enqueues (use sync())."""
+        desc = np.ascontiguousarray(desc, np.int32)
+        self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), C.c_void_p(d_factors),
+                                               C.c_void_p(d_loglik), C.c_void_p(d_dosage), C.c_void_p(d_inf),
+                                               C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
+                                               flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
 
     def addvariance(self, ind, chrom=0):
         mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])

@@ -63,6 +63,17 @@ struct cnf2_ctx {
     size_t  factors_cap = 0, loglik_cap = 0, dosage_cap = 0;
     double* d_scratch = nullptr;     // small parity buffers
     size_t  scratch_cap = 0;
+
+    // batched HOT LOOP 2 (cnf2_sweep_accumulate)
+    std::vector<int32_t> slot_rec;   // [n_dous][7] record per window slot (derive_window), -1 none
+    int32_t* d_slot_rec = nullptr;
+    int32_t* d_desc = nullptr;
+    uint8_t* d_rec_empty = nullptr;
+    size_t   rec_cap = 0;
+    double*  d_wbuf = nullptr;
+    size_t   wbuf_cap = 0;
+    double * d_acc_inf = nullptr, *d_acc_hb = nullptr, *d_acc_hc = nullptr, *d_acc_hz = nullptr;
+    size_t   acc_inf_cap = 0, acc_hb_cap = 0, acc_hc_cap = 0, acc_hz_cap = 0;
 };
 
 static std::string g_create_error;
@@ -162,6 +173,14 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_loglik);
     (void)hipFree(ctx->d_dosage);
     (void)hipFree(ctx->d_scratch);
+    (void)hipFree(ctx->d_slot_rec);
+    (void)hipFree(ctx->d_desc);
+    (void)hipFree(ctx->d_rec_empty);
+    (void)hipFree(ctx->d_wbuf);
+    (void)hipFree(ctx->d_acc_inf);
+    (void)hipFree(ctx->d_acc_hb);
+    (void)hipFree(ctx->d_acc_hc);
+    (void)hipFree(ctx->d_acc_hz);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev2);
@@ -378,12 +397,17 @@ static int prepare_windows(cnf2_ctx* ctx)
     HIP_TRY(ctx, hipMemcpyAsync(P.row_hom.data(), ctx->d_rowflags, ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->windows.resize(n_dous);
-    for (int j = 0; j < n_dous; j++) derive_window(P, P.dous[j], &ctx->windows[j], nullptr);
+    ctx->slot_rec.assign((size_t)n_dous * 7, -1);
+    for (int j = 0; j < n_dous; j++) derive_window(P, P.dous[j], &ctx->windows[j], ctx->slot_rec.data() + (size_t)j * 7);
     if (ctx->d_windows) HIP_TRY(ctx, hipFree(ctx->d_windows));
+    if (ctx->d_slot_rec) HIP_TRY(ctx, hipFree(ctx->d_slot_rec));
     ctx->d_windows = nullptr;
+    ctx->d_slot_rec = nullptr;
     if (n_dous > 0) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_windows, sizeof(Window) * n_dous));
         HIP_TRY(ctx, hipMemcpy(ctx->d_windows, ctx->windows.data(), sizeof(Window) * n_dous, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slot_rec, sizeof(int32_t) * 7 * n_dous));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_slot_rec, ctx->slot_rec.data(), sizeof(int32_t) * 7 * n_dous, hipMemcpyHostToDevice));
     }
     ctx->windows_dirty = false;
     return CNF2_OK;
@@ -868,106 +892,180 @@ int cnf2_descendants(cnf2_ctx* ctx, int32_t* desc_out)
     return CNF2_OK;
 }
 
-// HOT LOOP 2 with its reductions (cnF2freq.cpp:5416-5577, 5876-5902 with moveinfprobs / movehaplos 3577-3616)
-// for the analysed individuals [ind_begin, ind_end), in that order: the per-slot accumulator rows of every
-// chromosome (haplos_rows_kernel, infprobs_rows_kernel) are reduced per individual on the host exactly as the
-// reference does after each locus.  Parity level: one store run per individual and chromosome.
-int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* descendants, double* infprobs_out,
-                    double* haplobase_out, double* haplocount_out, double* homozyg_out, uint32_t flags)
+// Batched HOT LOOP 2 with its reductions (cnF2freq.cpp:5416-5577, 5876-5902 with moveinfprobs / movehaplos
+// 3577-3616) for the analysed individuals [ind_begin, ind_end): the sweep kernels run in their accumulate
+// instantiation (they leave the posterior weights wg(s, g) of every marker in a batch buffer next to the usual
+// outputs), acc_rows_kernel turns them into the per-record accumulators on the device.  Jobs go in batches sized
+// to the memory that is free (4 KB per individual x marker of weights).
+int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* descendants, double* factors_out,
+                          double* loglik_out, double* dosage_out, double* infprobs, double* haplobase,
+                          double* haplocount, double* homozyg, uint32_t flags)
 {
     int rc = ready(ctx);
     if (rc) return rc;
     const int n_all = (int)ctx->windows.size();
-    if (!descendants || !infprobs_out || !haplobase_out || !haplocount_out || !homozyg_out || ind_begin < 0 ||
-        ind_end > n_all || ind_begin > ind_end)
+    if (!descendants || !infprobs || !haplobase || !haplocount || !homozyg || ind_begin < 0 || ind_end > n_all ||
+        ind_begin > ind_end)
         return fail(ctx, CNF2_ERR_ARG, "bad accumulate arguments");
+    const bool out_dev = (flags & CNF2_OUT_DEVICE) != 0, acc_dev = (flags & CNF2_ACC_DEVICE) != 0;
+    if (out_dev && (!factors_out || !loglik_out || !dosage_out)) return fail(ctx, CNF2_ERR_ARG, "output pointer is NULL");
     const HostPedigree& P = ctx->ped;
-    const size_t M = (size_t)ctx->n_markers;
-    std::fill(infprobs_out, infprobs_out + (size_t)P.n_rec * M * 4, 0.0);
-    std::fill(haplobase_out, haplobase_out + (size_t)P.n_rec * M, 0.0);
-    std::fill(haplocount_out, haplocount_out + (size_t)P.n_rec * M, 0.0);
-    std::fill(homozyg_out, homozyg_out + (size_t)(ind_end - ind_begin) * M * 2, 0.0);
-    const float  maxdiff = 0.000005f;                                        // cnF2freq.cpp:228
-    const uint32_t kf = (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0;
-    std::vector<double> hrows, irows, hwrow[7];
-    for (int j = ind_begin; j < ind_end; j++) {
-        Window  w;
-        int32_t slot_rec[7];
-        derive_window(P, P.dous[j], &w, slot_rec);
-        // haploweight of the window members (movehaplos tests it): one row each, read back
-        for (int k = 0; k < 7; k++) {
-            hwrow[k].clear();
-            if (slot_rec[k] < 0) continue;
-            hwrow[k].resize(M);
-            HIP_TRY(ctx, hipMemcpy(hwrow[k].data(), ctx->d_hw + (size_t)ctx->windows[j].row[k] * M, M * sizeof(double),
-                                   hipMemcpyDeviceToHost));
-        }
-        const double descf = descendants[P.dous[j]];
-        for (int c = 0; c < ctx->n_chrom; c++) {
-            const int first = ctx->chromstarts[c], mc = ctx->chromstarts[c + 1] - first;
-            Stage2Params q;
-            double*      d_out = nullptr;
-            rc = run_store(ctx, j, c, &q, (size_t)mc * 44, &d_out);
-            if (rc) return rc;
-            launch_haplos_rows(q, kf, d_out, ctx->stream);
-            launch_infprobs_rows(q, kf, d_out + (size_t)mc * 14, ctx->stream);
-            HIP_TRY(ctx, hipGetLastError());
-            hrows.resize((size_t)mc * 14);
-            irows.resize((size_t)mc * 30);
-            double loglik = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(hrows.data(), d_out, hrows.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(irows.data(), d_out + (size_t)mc * 14, irows.size() * sizeof(double),
-                                        hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(&loglik, q.loglik, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (std::isnan(loglik) || loglik < (double)CNF2_MINFACTOR_F) continue;       // cnF2freq.cpp:5403
-            for (int ml = 0; ml < mc; ml++) {
-                const size_t  m  = (size_t)first + ml;
-                const double* I  = irows.data() + (size_t)ml * 30;
-                const double* H  = hrows.data() + (size_t)ml * 14;
-                // the analysed individual's own allele-index-0 entries (its slots: slot 0 and any tie with it)
-                double self0 = 0.0;
-                for (int k = 0; k < 7; k++)
-                    if (slot_rec[k] == slot_rec[0]) self0 += I[(k * 2 + 0) * 2 + 0] + I[(k * 2 + 0) * 2 + 1];
-                const double sum = 1.0 / self0;                                           // cnF2freq.cpp:5880-5885
-                double* hz = homozyg_out + ((size_t)(j - ind_begin) * M + m) * 2;
-                hz[0] = I[28] * sum;
-                hz[1] = I[29] * sum;
-                for (int k = 0; k < 7; k++) {                                             // reltree: unique members
-                    const int r = slot_rec[k];
-                    if (r < 0) continue;
-                    bool dup = false;
-                    for (int k2 = 0; k2 < k; k2++) dup |= (slot_rec[k2] == r);
-                    if (dup) continue;
-                    double inf[4] = {0, 0, 0, 0}, hap[2] = {0, 0};
-                    int    occ = 0;
-                    for (int k2 = k; k2 < 7; k2++) {
-                        if (slot_rec[k2] != r) continue;
-                        for (int x = 0; x < 4; x++) inf[x] += I[k2 * 4 + x];
-                        hap[0] += H[k2 * 2];
-                        hap[1] += H[k2 * 2 + 1];
-                        // reltreeordered holds the individual itself unconditionally (cnF2freq.cpp:3111) and, of its
-                        // ancestors, the non-empty ones only (cnF2freq.cpp:3127-3152)
-                        if (k2 == 0 || !P.empty[r]) occ++;
-                    }
-                    double norm = sum * 2;                                                // cnF2freq.cpp:3582-3587
-                    for (int x = 0; x < occ; x++) norm /= 2;
-                    norm *= descf;
-                    double* dst = infprobs_out + ((size_t)r * M + m) * 4;
-                    for (int x = 0; x < 4; x++) dst[x] += inf[x] * norm;
-                    if (hap[0] != 0.0 || hap[1] != 0.0) {                                 // cnF2freq.cpp:3601-3616
-                        if (fabs(hwrow[k][m] - 0.5) < 0.5 - 1e-12) {
-                            const double b1 = hap[0] + exp(-400.0) * maxdiff * maxdiff * 0.5;
-                            const double b2 = hap[1] + exp(-400.0) * maxdiff * maxdiff * 0.5;
-                            haplobase_out[(size_t)r * M + m] += b1 / (b1 + b2) * descf;
-                            haplocount_out[(size_t)r * M + m] += descf;
-                        }
-                    }
+    const int    n = ind_end - ind_begin;
+    const size_t M = (size_t)ctx->n_markers, R = (size_t)P.n_rec;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // per-record tables
+    if (ctx->rec_cap < R) {
+        if (ctx->d_desc) HIP_TRY(ctx, hipFree(ctx->d_desc));
+        if (ctx->d_rec_empty) HIP_TRY(ctx, hipFree(ctx->d_rec_empty));
+        ctx->d_desc = nullptr;
+        ctx->d_rec_empty = nullptr;
+        ctx->rec_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_desc, sizeof(int32_t) * R));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rec_empty, R));
+        ctx->rec_cap = R;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_desc, descendants, sizeof(int32_t) * R, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_rec_empty, P.empty.data(), R, hipMemcpyHostToDevice));
+
+    // accumulators and sweep outputs
+    double *a_inf = infprobs, *a_hb = haplobase, *a_hc = haplocount, *a_hz = homozyg;
+    if (!acc_dev) {
+        if ((rc = ensure(ctx, &ctx->d_acc_inf, &ctx->acc_inf_cap, R * M * 4))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_acc_hb, &ctx->acc_hb_cap, R * M))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_acc_hc, &ctx->acc_hc_cap, R * M))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_acc_hz, &ctx->acc_hz_cap, (size_t)(n > 0 ? n : 1) * M * 2))) return rc;
+        a_inf = ctx->d_acc_inf;
+        a_hb  = ctx->d_acc_hb;
+        a_hc  = ctx->d_acc_hc;
+        a_hz  = ctx->d_acc_hz;
+    }
+    if (!(flags & CNF2_ACC_KEEP)) {
+        HIP_TRY(ctx, hipMemsetAsync(a_inf, 0, R * M * 4 * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(a_hb, 0, R * M * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(a_hc, 0, R * M * sizeof(double), ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(a_hz, 0, (size_t)n * M * 2 * sizeof(double), ctx->stream));
+    const size_t nf = (size_t)n * ctx->n_chrom * 8, nl = (size_t)n * ctx->n_chrom, nd = (size_t)n * M * 3;
+    double *d_f = factors_out, *d_l = loglik_out, *d_d = dosage_out;
+    if (!out_dev) {
+        if ((rc = ensure(ctx, &ctx->d_factors, &ctx->factors_cap, nf ? nf : 1))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_loglik, &ctx->loglik_cap, nl ? nl : 1))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_dosage, &ctx->dosage_cap, nd ? nd : 1))) return rc;
+        d_f = ctx->d_factors;
+        d_l = ctx->d_loglik;
+        d_d = ctx->d_dosage;
+    }
+    if (n > 0) {
+        // job list: untied windows (fast kernel) first, tied ones (general kernel) after
+        std::vector<Job> jobs;
+        size_t           n_fast = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int c = 0; c < ctx->n_chrom; c++)
+                for (int j = 0; j < n; j++) {
+                    const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
+                    if (tied != (pass == 1)) continue;
+                    Job jb;
+                    jb.ind = j;
+                    jb.first = ctx->chromstarts[c];
+                    jb.last = ctx->chromstarts[c + 1] - 1;
+                    jb.chrom = c;
+                    jobs.push_back(jb);
                 }
+            if (pass == 0) n_fast = jobs.size();
+        }
+        if ((rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, jobs.size() + 1))) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice));
+
+        const int    mlen = max_chrom_len(ctx);
+        const size_t stride = (size_t)mlen * 528;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        free_b += ctx->spill_bytes + ctx->wbuf_cap * sizeof(double);
+        // spill: one slot per resident wave, at most a quarter of what is free
+        int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu;
+        const size_t per_blk = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
+        if ((size_t)grid_cap * per_blk > free_b / 4) grid_cap = (int)(free_b / 4 / per_blk);
+        if (grid_cap < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the spill of one block");
+        {
+            size_t capd = ctx->spill_bytes / sizeof(double);
+            rc = ensure(ctx, &ctx->d_spill, &capd, (size_t)grid_cap * CNF2_WAVES_PER_BLOCK * stride);
+            ctx->spill_bytes = capd * sizeof(double);
+            if (rc) return rc;
+        }
+        // weights: 512 doubles per (job, marker); batch = what fits in half of the rest
+        const size_t per_job = (size_t)mlen * 512;
+        size_t       batch = (free_b - (size_t)grid_cap * per_blk) / 2 / (per_job * sizeof(double));
+        if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the weights of one job (%zu MB)", per_job >> 17);
+        if (batch > jobs.size()) batch = jobs.size();
+        if (batch > 1000000) batch = 1000000;
+        if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
+
+        KernelParams p;
+        base_params(ctx, &p);
+        p.windows      = ctx->d_windows + ind_begin;
+        p.spill        = ctx->d_spill;
+        p.spill_stride = stride;
+        p.factors      = d_f;
+        p.loglik       = d_l;
+        p.dosage       = d_d;
+        p.flags        = ((flags & CNF2_RAW_DOSAGE) ? KP_RAW_DOSAGE : 0) | ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
+        p.wbuf         = ctx->d_wbuf;
+        p.wstride      = (size_t)mlen;
+        AccParams q;
+        memset(&q, 0, sizeof(q));
+        q.flags     = (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0;
+        q.slot_rec  = ctx->d_slot_rec + (size_t)ind_begin * 7;
+        q.desc      = ctx->d_desc;
+        q.rec_empty = ctx->d_rec_empty;
+        q.acc_inf   = a_inf;
+        q.acc_hb    = a_hb;
+        q.acc_hc    = a_hc;
+        q.acc_hz    = a_hz;
+        q.max_len   = mlen;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int pass = 0; pass < 2; pass++) {
+            const size_t lo = pass ? n_fast : 0, hi = pass ? jobs.size() : n_fast;
+            for (size_t b0 = lo; b0 < hi; b0 += batch) {
+                const size_t nb = (hi - b0 < batch) ? hi - b0 : batch;
+                p.jobs   = ctx->d_jobs + b0;
+                p.n_jobs = (int)nb;
+                int grid = (int)((nb + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+                if (grid > grid_cap) grid = grid_cap;
+                if (pass == 0) launch_fb_fast_w(p, grid, ctx->stream);
+                else launch_fb_w(p, grid, ctx->stream);
+                HIP_TRY(ctx, hipGetLastError());
+                q.kp     = p;
+                q.n_jobs = (int)nb;
+                launch_acc_rows(q, ctx->stream);
+                HIP_TRY(ctx, hipGetLastError());
             }
         }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->timed = true;
     }
+    if (!out_dev) {
+        if (factors_out) HIP_TRY(ctx, hipMemcpyAsync(factors_out, d_f, nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (loglik_out) HIP_TRY(ctx, hipMemcpyAsync(loglik_out, d_l, nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (dosage_out) HIP_TRY(ctx, hipMemcpyAsync(dosage_out, d_d, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!acc_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(infprobs, a_inf, R * M * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(haplobase, a_hb, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(haplocount, a_hc, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(homozyg, a_hz, (size_t)n * M * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!out_dev || !acc_dev) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNF2_OK;
+}
+
+// The accumulators alone, into host arrays (zeroed first): the form the parity tests use.
+int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* descendants, double* infprobs_out,
+                    double* haplobase_out, double* haplocount_out, double* homozyg_out, uint32_t flags)
+{
+    return cnf2_sweep_accumulate(ctx, ind_begin, ind_end, descendants, nullptr, nullptr, nullptr, infprobs_out,
+                                 haplobase_out, haplocount_out, homozyg_out,
+                                 flags & ~(uint32_t)(CNF2_OUT_DEVICE | CNF2_ACC_DEVICE | CNF2_ACC_KEEP));
 }
 
 int cnf2_addvariance(cnf2_ctx* ctx, int ind, int chrom, double* var_out)

@@ -60,7 +60,33 @@ struct KernelParams {
     // debug store (fwbw_store): reference layout for ONE job
     double*        dbg_fwbw;     // [8][len][3][64]
     double*        dbg_factors;  // [8][len][3]
+    // accumulate mode (STOREW instantiations): posterior weights wg(s, g) = exp(scales - factor) alphaminus beta of
+    // every marker of every job of the launch, [job][wstride markers][4][64 lanes][2] in the sweep's own
+    // lane / register layout (lane = chain << 3 | l, registers 2k, 2k+1)
+    double*        wbuf;
+    size_t         wstride;      // markers per job slot
 };
+
+// Inputs of the batched HOT LOOP 2 kernel (acc_rows_kernel): the weights a STOREW sweep left for `n_jobs` jobs and
+// where the per-record accumulators live.  After every locus the reference scales homozyg, then moveinfprobs /
+// movehaplos add the thread-private sums to the window members (cnF2freq.cpp:5876-5902, 3577-3616): done here with
+// f64 atomics, one wave per (job, marker).
+struct AccParams {
+    KernelParams   kp;           // windows (offset to ind_begin), jobs (offset to the batch), rows, wbuf, loglik, factors
+    int            n_jobs;       // jobs in this batch
+    int            max_len;      // longest chromosome of the batch (grid.y)
+    uint32_t       flags;        // KP_NO_TIES
+    const int32_t* slot_rec;     // [n_ind][7] record per window slot, -1 none (offset like windows)
+    const int32_t* desc;         // [n_rec] individ::descendants
+    const uint8_t* rec_empty;    // [n_rec]
+    double*        acc_inf;      // [n_rec][n_markers][2][2]
+    double*        acc_hb;       // [n_rec][n_markers] haplobase
+    double*        acc_hc;       // [n_rec][n_markers] haplocount
+    double*        acc_hz;       // [n_ind][n_markers][2] homozyg of the analysed individual (offset like windows)
+};
+void launch_acc_rows(const AccParams& q, hipStream_t stream);
+void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream);
+void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
 
 // Inputs of the stage-2 parity kernels: the reference-layout store of ONE individual x chromosome.
 struct Stage2Params {

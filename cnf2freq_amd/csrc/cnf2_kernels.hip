@@ -27,6 +27,7 @@
 #include "cnf2_lane.h"
 #include "cnf2_emtab.h"
 #include "cnf2_accum.h"
+#include "cnf2_acctab.h"
 
 namespace cnf2 {
 
@@ -331,7 +332,7 @@ __device__ __forceinline__ double chain_normaliser(const double (&v)[8], double*
     return inv;
 }
 
-template <bool DEBUG_STORE>
+template <bool DEBUG_STORE, bool STOREW = false>
 __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 {
     __shared__ double lds_tab[CNF2_WAVES_PER_BLOCK][64];
@@ -491,6 +492,16 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
                     }
                 }
                 D     = chain_sum(D);
+                if (STOREW) {
+                    // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta = wj * ws / D
+                    const double sw = (D > 0.0) ? ws / D : 0.0;
+                    double*      wp = p.wbuf + ((size_t)job * p.wstride + (m - first)) * 512;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        double2 v2 = make_double2(sw != 0.0 ? sw * wj[2 * k] : 0.0, sw != 0.0 ? sw * wj[2 * k + 1] : 0.0);
+                        *(double2*)(wp + k * 128 + lane * 2) = v2;
+                    }
+                }
                 n_tot = chain_sum(n_tot);
                 n_a1  = chain_sum(n_a1);
                 n_b1  = chain_sum(n_b1);
@@ -734,7 +745,7 @@ struct BwdState {
 // HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
 // spill traffic for ~15 % more arithmetic.
-template <bool HALF>
+template <bool HALF, bool STOREW = false>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
     // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
@@ -971,6 +982,15 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+            if (STOREW) {
+                // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta for the batched HOT LOOP 2 kernel
+                double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const d2v v = {scale != 0.0 ? scale * wj[2 * k] : 0.0, scale != 0.0 ? scale * wj[2 * k + 1] : 0.0};
+                    __builtin_nontemporal_store(v, (d2v*)(wp + k * 128 + lane * 2));
+                }
+            }
             // this marker's own emission is only needed for the beta step: formed here, after the sums, so
             // that it does not occupy registers across them
             double e[8];
@@ -1880,6 +1900,235 @@ __global__ __launch_bounds__(256) void addvariance_kernel(KernelParams p, int fi
     }
 }
 
+// =====================================================================================
+// Batched HOT LOOP 2: every accumulator of cnF2freq.cpp:5416-5577 for one (job, marker)
+// per wavefront, from the posterior weights a STOREW sweep left behind, through the table form of cnf2_acctab.h:
+//   1. lane = table entry (P, f, sp, k): its AK_COUNT per-line sums (acc_entry) into LDS;
+//   2. lane = (shift mode, low state bits) as in the sweep, registers = high state bits: the partial contractions
+//      v (by f, s0), u (by f), z (by f, allele value) of wg with the restricted totals / HOMOZYGOUS probe sums;
+//   3. lane = accumulator: 16-term dot products;
+//   4. the per-locus reductions of doit (homozyg scale, moveinfprobs, movehaplos; cnF2freq.cpp:5876-5902,
+//      3577-3616) with f64 atomics into the per-record arrays.
+// Not tuned beyond the algebra (the table entries are evaluated by the plain host/device code of cnf2_accum.h).
+// =====================================================================================
+#define ACC_TAB (64 * AK_COUNT)
+#define ACC_LDS (ACC_TAB + 64 + 32 + 64 + 48)
+__global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
+{
+    __shared__ double lds[CNF2_WAVES_PER_BLOCK][ACC_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job  = blockIdx.x;
+    const int ml   = blockIdx.y * CNF2_WAVES_PER_BLOCK + wib;
+    const KernelParams& p = q.kp;
+    const Job jb = p.jobs[job];
+    const int len = jb.last - jb.first + 1;
+    if (ml >= len) return;
+    const int    m  = jb.first + ml;
+    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
+    if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                     // cnF2freq.cpp:5403
+    const Window w = p.windows[jb.ind];
+    double* tab = lds[wib];                    // [64 entries][AK_COUNT]
+    double* vt  = tab + ACC_TAB;               // [f][s0][16]
+    double* ut  = vt + 64;                     // [f][16]
+    double* zt  = ut + 32;                     // [f][i][16]
+    double* out = zt + 64;                     // [44]: inf 28, hz 2, hap 14
+
+    // posterior weights of this lane's 8 states
+    double x[8];
+    {
+        const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double2 v2 = *(const double2*)(wp + k * 128 + lane * 2);
+            x[2 * k]     = v2.x;
+            x[2 * k + 1] = v2.y;
+        }
+    }
+    Slot slot[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) slot[k] = load_slot(p, w.row[k] < 0 ? 0 : w.row[k], m);
+    const bool no_ties    = (q.flags & KP_NO_TIES) != 0;
+    const bool root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    const int  n_combo    = (no_ties || root_attop) ? 1 : (1 << w.n_groups);
+    const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
+    AccRoot ar[2];
+    acc_root(slot[0], root_attop, 0, &ar[0]);
+    acc_root(slot[0], root_attop, 1, &ar[1]);
+    if (lane < 44) out[lane] = 0.0;
+
+    for (int combo = 0; combo < n_combo; combo++) {
+        // ---- 1. table entries
+        wave_lds_fence();
+        {
+            double e[AK_COUNT];
+            const int f_e = (lane >> 4) & 1;
+            if (ar[f_e].live) acc_entry(w, slot, lane, combo, no_ties, ar[f_e], e);
+            else
+                for (int k = 0; k < AK_COUNT; k++) e[k] = 0.0;
+            for (int k = 0; k < AK_COUNT; k++) tab[lane * AK_COUNT + k] = e[k];
+        }
+        wave_lds_fence();
+        // ---- 2. partial contractions
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const double cf = ar[f].live ? ar[f].cf[s0] : 0.0;
+            const double* t1 = tab + (size_t)((1 << 5) | (f << 4) | (s2 << 3)) * AK_COUNT;    // line 1 entries of this chain
+            double tr = 0.0, th0 = 0.0, th1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double cx = cf * x[j];
+                if (cx != 0.0) {
+                    tr += cx * t1[j * AK_COUNT + AK_R];
+                    th0 += cx * t1[j * AK_COUNT + AK_HZ + 0];
+                    th1 += cx * t1[j * AK_COUNT + AK_HZ + 1];
+                }
+            }
+            // v: sum over s2 (lane bit 5); z: over s0 and s2 (lane bits 3, 5)
+            tr += lane_xor32(tr);
+            th0 += lane_xor32(th0);
+            th1 += lane_xor32(th1);
+            th0 += lane_xor8(th0);
+            th1 += lane_xor8(th1);
+            const int e0 = (s1 << 3) | lo;
+            if (s2 == 0) vt[(f * 2 + s0) * 16 + e0] = tr;
+            if (s2 == 0 && s0 == 0) {
+                zt[(f * 2 + 0) * 16 + e0] = th0;
+                zt[(f * 2 + 1) * 16 + e0] = th1;
+            }
+            // u: per high state j, sum over the chain's 8 lanes and over s0, s1 (lane bits 0-4)
+            const double r0 = tab[(size_t)((0 << 5) | (f << 4) | (s1 << 3) | lo) * AK_COUNT + AK_R];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double cx = cf * x[j];
+                double       pj = (cx != 0.0) ? cx * r0 : 0.0;
+                pj = chain_sum(pj);
+                pj += lane_xor8(pj);
+                pj += lane_xor16(pj);
+                if ((lane & 31) == 0) ut[f * 16 + (s2 << 3) + j] = pj;
+            }
+        }
+        wave_lds_fence();
+        // ---- 3. lane = accumulator
+        if (lane < 44) {
+            double acc = 0.0;
+            if (lane < 28) {                                   // inf[slot][allele index][i]
+                const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
+                if (slotk == 0) {
+                    for (int f = 0; f < 2; f++) {
+                        if (!ar[f].live) continue;
+                        if (root_attop) {
+                            const int side = (f == ax) ? 0 : 1;
+                            double    vsum = 0.0;
+                            for (int e = 0; e < 16; e++) vsum += vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
+                            acc += vsum * (ar[f].Rs[side][i] / (ar[f].Rs[side][0] + ar[f].Rs[side][1]));
+                        } else {
+                            const int P = (f == ax) ? 0 : 1;                                   // fr = P ? f ^ 1 : f
+                            for (int e = 0; e < 16; e++) {
+                                const double wt = P ? ut[f * 16 + e] : vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
+                                acc += mul0(tab[(size_t)((P << 5) | (f << 4) | e) * AK_COUNT + AK_WROOT + i], wt);
+                            }
+                        }
+                    }
+                } else if (!root_attop) {
+                    const int P = slotk >= 4, rel = slotk - (1 + 3 * P);                       // 0 parent, 1 / 2 grandparents
+                    const int kind = rel == 0 ? AK_WPAR + ax * 2 + i : AK_WGP + ((rel - 1) * 2 + ax) * 2 + i;
+                    for (int f = 0; f < 2; f++) {
+                        if (!ar[f].live) continue;
+                        for (int e = 0; e < 16; e++) {
+                            const double wt = P ? ut[f * 16 + e] : vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
+                            acc += mul0(tab[(size_t)((P << 5) | (f << 4) | e) * AK_COUNT + kind], wt);
+                        }
+                    }
+                }
+            } else if (lane < 30) {                            // homozyg[i]
+                const int i = lane - 28;
+                for (int f = 0; f < 2; f++) {
+                    if (!ar[f].live) continue;
+                    double t = 0.0;
+                    for (int e = 0; e < 16; e++)
+                        t += mul0(tab[(size_t)((0 << 5) | (f << 4) | e) * AK_COUNT + AK_HZ + i], zt[(f * 2 + i) * 16 + e]);
+                    acc += ar[f].hzscale[i] * t;
+                }
+            } else {                                           // haplos[slot][phase]
+                const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
+                if (slotk == 0) {
+                    for (int f = 0; f < 2; f++) {
+                        if (!ar[f].live) continue;
+                        const int s0v = f ^ ph;                                                // phase = f ^ s0
+                        for (int e = 0; e < 16; e++)
+                            acc += mul0(tab[(size_t)((0 << 5) | (f << 4) | e) * AK_COUNT + AK_R], vt[(f * 2 + s0v) * 16 + e]);
+                    }
+                } else if (!root_attop) {
+                    const int P = slotk >= 4, rel = slotk - (1 + 3 * P);
+                    for (int f = 0; f < 2; f++) {
+                        if (!ar[f].live) continue;
+                        for (int e = 0; e < 16; e++) {
+                            const double wt = P ? ut[f * 16 + e] : vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
+                            acc += mul0(tab[(size_t)((P << 5) | (f << 4) | e) * AK_COUNT + AK_HAP + rel * 2 + ph], wt);
+                        }
+                    }
+                }
+            }
+            out[lane] += acc;
+        }
+    }
+    wave_lds_fence();
+    // ---- 4. per-locus reductions (cnF2freq.cpp:5876-5902)
+    const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
+    if (lane < 7) {
+        const int k = lane, r = srec[k];
+        // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
+        const bool upd = (w.flags[k] & SLOT_PRESENT) && !(slot[k].a0 == slot[k].a1 && slot[k].s0 == slot[k].s1);
+        if (!upd) out[30 + k * 2] = out[30 + k * 2 + 1] = 0.0;
+        (void)r;
+    }
+    wave_lds_fence();
+    double self0 = 0.0;
+    for (int k = 0; k < 7; k++)
+        if (srec[k] == srec[0]) self0 += out[(k * 2 + 0) * 2 + 0] + out[(k * 2 + 0) * 2 + 1];
+    const double sum = 1.0 / self0;                                                            // cnF2freq.cpp:5880-5885
+    if (lane < 2) q.acc_hz[((size_t)jb.ind * p.n_markers + m) * 2 + lane] = out[28 + lane] * sum;
+    if (lane < 7) {
+        const int k = lane, r = srec[k];
+        bool first = r >= 0;
+        for (int k2 = 0; k2 < k; k2++) first = first && (srec[k2] != r);                      // reltree: unique members
+        if (first) {
+            double inf[4] = {0, 0, 0, 0}, h0 = 0.0, h1 = 0.0;
+            int    occ = 0;
+            for (int k2 = k; k2 < 7; k2++) {
+                if (srec[k2] != r) continue;
+                for (int t = 0; t < 4; t++) inf[t] += out[k2 * 4 + t];
+                h0 += out[30 + k2 * 2];
+                h1 += out[30 + k2 * 2 + 1];
+                // reltreeordered: the individual itself always, ancestors only when non-empty (cnF2freq.cpp:3111-3152)
+                if (k2 == 0 || !q.rec_empty[r]) occ++;
+            }
+            const double descf = (double)q.desc[srec[0]];
+            double       norm = sum * 2;                                                       // cnF2freq.cpp:3582-3587
+            for (int t = 0; t < occ; t++) norm /= 2;
+            norm *= descf;
+            double* dst = q.acc_inf + ((size_t)r * p.n_markers + m) * 4;
+            for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
+            if (h0 != 0.0 || h1 != 0.0) {                                                      // cnF2freq.cpp:3601-3616
+                if (fabs(slot[k].hw - 0.5) < 0.5 - 1e-12) {
+                    const double md = (double)0.000005f;
+                    const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+                    const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+                    atomicAdd(q.acc_hb + (size_t)r * p.n_markers + m, b1 / (b1 + b2) * descf);
+                    atomicAdd(q.acc_hc + (size_t)r * p.n_markers + m, descf);
+                }
+            }
+        }
+    }
+}
+
+void launch_acc_rows(const AccParams& q, hipStream_t stream)
+{
+    dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(acc_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
+}
+
 void launch_addvariance(const KernelParams& p, int first, int len, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(addvariance_kernel, dim3(len), dim3(256), 0, stream, p, first, out);
@@ -1954,6 +2203,15 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
                       hipStream_t stream)
 {
     hipLaunchKernelGGL(row_flags_kernel, dim3(n_rows), dim3(256), 0, stream, allele8, sure, n_markers, flags);
+}
+
+void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_fast_kernel<true, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_kernel<false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
 int fb_fast_blocks_per_cu()

@@ -52,12 +52,15 @@ enum {
     CNF2_NO_TIES      = 1u << 3, /* drop ignoreflag2's all-or-none rule (cnF2freq.cpp:3484-3486) */
     CNF2_FULL_SPILL   = 1u << 4, /* store alpha-minus at every marker instead of every second one and
                                     recomputing the others in the backward pass (same results) */
-    CNF2_MERGE_MODES  = 1u << 5  /* sweep bit-identical shift modes once: for a window whose two parents are
+    CNF2_MERGE_MODES  = 1u << 5, /* sweep bit-identical shift modes once: for a window whose two parents are
                                     homozygous with equal sure at every marker (e.g. the private empty F1
                                     parents of an F2, cnF2freq.cpp:6515-6527) the modes that differ in the
                                     parents' shift bits carry the same alpha/beta; four such individuals
                                     share a wavefront.  Same outputs for all 8 modes (rows to rounding).
                                     Ignored together with CNF2_FULL_SPILL. */
+    CNF2_ACC_DEVICE   = 1u << 6, /* cnf2_sweep_accumulate: the four accumulator pointers are device pointers owned by the
+                                    caller (a multi-GPU driver all-reduces them in place) */
+    CNF2_ACC_KEEP     = 1u << 7  /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
 };
 
 typedef struct cnf2_ctx cnf2_ctx;
@@ -165,7 +168,7 @@ int cnf2_infprobs(cnf2_ctx *ctx, int ind, int chrom, int marker, double *inf_out
  *                       total) instead of the 128-path fan-out. */
 int cnf2_infprobs_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint32_t flags);
 
-/* HOT LOOP 2 with its reductions (parity level): for the analysed individuals
+/* HOT LOOP 2 with its reductions: for the analysed individuals
  * [ind_begin, ind_end), in that order, the per-locus accumulators of cnF2freq.cpp:5416-5577 are formed on the GPU
  * (closed forms: cnf2_haplos, cnf2_infprobs_rows) and reduced per individual as the reference does after every
  * locus (cnF2freq.cpp:5876-5902): homozyg scaled by 1 / sum of the individual's own allele-index-0 infprobs;
@@ -176,6 +179,17 @@ int cnf2_infprobs_rows(cnf2_ctx *ctx, int ind, int chrom, double *rows_out, uint
 int cnf2_descendants(cnf2_ctx *ctx, int32_t *desc_out);
 int cnf2_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *descendants, double *infprobs_out,
                     double *haplobase_out, double *haplocount_out, double *homozyg_out, uint32_t flags);
+/* The product form: one call = one haplotyping sweep of doit<> over the individuals (cnF2freq.cpp:5294-5583, 5876-5902):
+ * the outputs of cnf2_sweep (may be NULL unless CNF2_OUT_DEVICE) AND the per-record accumulators, all individuals and
+ * chromosomes batched on the device.  The sweep kernels run in their accumulate instantiation (posterior weights of
+ * every (individual, marker, shift mode, state) into a batch buffer); one more kernel forms every accumulator of a
+ * locus through per-line tables (cnf2_acctab.h) and applies homozyg's scale, moveinfprobs and movehaplos with f64
+ * atomics.  CNF2_ACC_DEVICE: infprobs / haplobase / haplocount / homozyg are caller-owned device buffers
+ * ([n_rec][M][2][2], [n_rec][M], [n_rec][M], [ind_end - ind_begin][M][2]); several GPUs that share ancestors sum
+ * the first three with one all-reduce (the reference's reduce calls, cnF2freq.cpp:6245-6254). */
+int cnf2_sweep_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *descendants, double *factors_out,
+                          double *loglik_out, double *dosage_out, double *infprobs, double *haplobase,
+                          double *haplocount, double *homozyg, uint32_t flags);
 
 /* Pre-processing user of the emission (parity level): individ::addvariance
  * (cnF2freq.cpp:1489-1558, called by postmarkerdata for every marker, cnF2freq.cpp:3373-3389) for one analysed

@@ -708,3 +708,56 @@ def test_half_spill_recompute_equals_full_spill(capi):
         d = ctx.sweep()["dosage"][:, first:last + 1]
         np.testing.assert_allclose(d, want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
+
+
+def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
+    """cnf2_sweep_accumulate (the product form of HOT LOOP 2: every individual and chromosome in batched launches,
+    table form of the accumulators, reductions with atomics on the device) against the oracle's accumulate
+    (pinned bit-exact on the reference's own moveinfprobs / movehaplos): advanced intercross with active ties
+    (general kernel + tie combinations), outbred with missing data, and an F2 over three ragged chromosomes.
+    The sweep outputs that come with it must be those of cnf2_sweep."""
+    peds = [synth.make_ail(4, 6, 3, 9, 1, seed=5, chrom_cm=20.0, missing=0.05),
+            synth.make_outbred3(2, 3, 11, 1, seed=3, missing=0.2, random_hw=True, random_sure=True),
+            synth.make_random_windows(24, 5, seed=43)]
+    f2 = synth.make_f2(5, 17, 1, seed=3, chrom_cm=20.0, missing=0.1)
+    f2.chromstarts = np.array([0, 1, 6, 18], np.int32)
+    f2.pos = np.concatenate([[0.0], np.arange(5) * 0.7, np.arange(12) * 1.3])
+    peds.append(f2)
+    for ped in peds:
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        desc = ctx.descendants()
+        got = ctx.sweep_accumulate(desc)
+        plain = ctx.sweep()
+        assert np.array_equal(got["factors"], plain["factors"]) and np.array_equal(got["loglik"], plain["loglik"])
+        np.testing.assert_allclose(got["dosage"], plain["dosage"], rtol=1e-12, atol=1e-15)
+        o = oracle_ped(ped)
+        for c in range(len(ped.chromstarts) - 1):
+            first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+            want = o.accumulate(ped.dous, ped.gen[ped.dous], desc, first=first, last=last)
+            for k, sl in (("infprobs", np.s_[:, first:last + 1]), ("haplobase", np.s_[:, first:last + 1]),
+                          ("haplocount", np.s_[:, first:last + 1]), ("homozyg", np.s_[:, first:last + 1])):
+                np.testing.assert_allclose(got[k][sl], want[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+        # a sub-range of individuals gives that range's homozyg and (for disjoint windows) its share of the rest
+        part = ctx.sweep_accumulate(desc, 1, 3)
+        np.testing.assert_allclose(part["homozyg"], got["homozyg"][1:3], rtol=1e-12, atol=1e-15, equal_nan=True)
+        ctx.close()
+
+
+def test_batched_accumulate_rows_equal_the_per_individual_hooks(capi):
+    """The table form inside the batched kernel against the per-individual closed-form hooks (cnf2_haplos,
+    cnf2_infprobs_rows), which read the reference-layout store: same accumulators before the reductions.  Checked
+    through an individual without relatives in the batch, where the reductions are the identity up to known factors."""
+    ped = synth.make_outbred3(1, 1, 13, 1, seed=6, missing=0.15, random_hw=True, random_sure=True)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = np.ones(ped.n_rec, np.int32)
+    got = ctx.sweep_accumulate(desc)
+    inf, hz = ctx.infprobs_rows(0, 0)
+    slots = ctx.window_info(0)["slots"]
+    self0 = inf[:, 0, 0, :].sum(axis=1)                       # the individual's own allele-index-0 mass
+    for k, r in enumerate(slots):
+        # every member occupies one slot: norm = sum * 2 / 2 * descendants = 1 / self0
+        np.testing.assert_allclose(got["infprobs"][r], inf[:, k] / self0[:, None, None], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(got["homozyg"][0], hz / self0[:, None], rtol=1e-9, atol=1e-13)
+    ctx.close()

@@ -231,3 +231,42 @@ def test_closed_form_infprobs_matches_fanout(shim, maker):
             np.testing.assert_allclose(hz, want_hz, rtol=1e-9, atol=1e-13)
             checked += 1
     assert checked > 0
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.make_random_windows(40, 4, seed=21),
+    lambda: synth.make_random_windows(40, 3, seed=22),
+    lambda: synth.make_outbred3(2, 2, 7, 1, seed=8, missing=0.25, random_hw=True, random_sure=True),
+    lambda: synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2),
+    lambda: synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+])
+def test_table_form_of_all_accumulators_matches_fanout(shim, maker):
+    """cnf2_acctab.h (every HOT LOOP 2 accumulator of one (individual, marker) as 16-term dot products of per-line
+    tables with partial contractions of wg: what the batched accumulate kernel evaluates) against the oracle's
+    brute-force fan-outs: infprobs / homozyg (GENOSPROBE, GENOS, HOMOZYGOUS) and haplos (updatehaplo)."""
+    ped = maker()
+    o = oracle_ped(ped)
+    checked = tied = 0
+    for ind in ped.dous:
+        slots = np.zeros(17, np.int32)
+        ng = shim.shim_window(*_ped_args(ped), int(ind), _p(slots))
+        for m in (0, ped.n_markers - 1):
+            wg = _mode_weights(o, ped, ind, m)
+            if wg is None:
+                continue
+            inf, hz, hap = np.zeros((7, 2, 2)), np.zeros(2), np.zeros((7, 2))
+            shim.shim_acc_contract(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
+                                   int(ind), m, _p(np.ascontiguousarray(wg)), 0, _p(inf), _p(hz), _p(hap))
+            want, want_hz = o.infprobs_row(int(ind), m, int(ped.gen[ind]))
+            want_hap = o.haplos_row(int(ind), m, int(ped.gen[ind]))
+            got, got_hap = np.zeros_like(want), np.zeros_like(want_hap)
+            for k in range(7):
+                if slots[3 + k] >= 0:
+                    got[slots[3 + k]] += inf[k]
+                    got_hap[slots[3 + k]] += hap[k]
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(hz, want_hz, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(got_hap, want_hap, rtol=1e-9, atol=1e-13)
+            checked += 1
+            tied += int(ng > 0)
+    assert checked > 0
