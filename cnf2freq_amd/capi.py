@@ -24,7 +24,8 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_fixparents_scan", "cnf2_variances",
+    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -73,6 +74,11 @@ def load():
         L.cnf2_descendants.argtypes = [vp, vp]
         L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_sweep_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
+        L.cnf2_fixparents_scan.argtypes = [vp, vp, i32, vp]
+        L.cnf2_variances.argtypes = [vp, vp, i32, i32, vp]
+        L.cnf2_snapshot_priors.argtypes = [vp, vp]
+        L.cnf2_update_pass.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, C.c_uint32]
+        L.cnf2_download_rows.argtypes = [vp, i32, i32, vp, vp, vp]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
@@ -296,6 +302,41 @@ class Context:
                                                C.c_void_p(d_loglik), C.c_void_p(d_dosage), C.c_void_p(d_inf),
                                                C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
                                                flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
+
+    def fixparents_scan(self, recs):
+        recs = np.ascontiguousarray(recs, np.int32)
+        ok = np.zeros((len(recs), self.n_markers, 2), np.uint8)
+        self._chk(self.L.cnf2_fixparents_scan(self.h, _p(recs), len(recs), _p(ok)), "cnf2_fixparents_scan")
+        return ok
+
+    def variances(self, recs, ordered=True):
+        recs = np.ascontiguousarray(recs, np.int32)
+        v = np.zeros((len(recs), self.n_markers))
+        self._chk(self.L.cnf2_variances(self.h, _p(recs), len(recs), 1 if ordered else 0, _p(v)), "cnf2_variances")
+        return v
+
+    def snapshot_priors(self, has_prior):
+        hp = np.ascontiguousarray(has_prior, np.uint8)
+        assert len(hp) == self.n_rec
+        self._chk(self.L.cnf2_snapshot_priors(self.h, _p(hp)), "cnf2_snapshot_priors")
+
+    def update_pass(self, chrom, children, descendants, scalefactor, entropyfactor=1.0, acc=None):
+        """acc: dict with host arrays infprobs / haplobase / haplocount (updated in place), or None for the
+        accumulators the last sweep_accumulate(..., keep=True) left in the context.  Returns hitnnn."""
+        ch = np.ascontiguousarray(children, np.int32)
+        de = np.ascontiguousarray(descendants, np.int32)
+        hits = np.zeros(1, np.int32)
+        a = (None, None, None) if acc is None else (_p(acc["infprobs"]), _p(acc["haplobase"]), _p(acc["haplocount"]))
+        self._chk(self.L.cnf2_update_pass(self.h, chrom, _p(ch), _p(de), a[0], a[1], a[2], scalefactor, entropyfactor,
+                                          _p(hits), 0), "cnf2_update_pass")
+        return int(hits[0])
+
+    def download_rows(self, row0, n):
+        allele = np.zeros((n, self.n_markers, 2), np.uint8)
+        sure = np.zeros((n, self.n_markers, 2))
+        hw = np.zeros((n, self.n_markers))
+        self._chk(self.L.cnf2_download_rows(self.h, row0, n, _p(allele), _p(sure), _p(hw)), "cnf2_download_rows")
+        return allele, sure, hw
 
     def addvariance(self, ind, chrom=0):
         mc = int(self.chromstarts[chrom + 1] - self.chromstarts[chrom])

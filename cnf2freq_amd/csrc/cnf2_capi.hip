@@ -74,6 +74,25 @@ struct cnf2_ctx {
     size_t   wbuf_cap = 0;
     double * d_acc_inf = nullptr, *d_acc_hb = nullptr, *d_acc_hc = nullptr, *d_acc_hz = nullptr;
     size_t   acc_inf_cap = 0, acc_hb_cap = 0, acc_hc_cap = 0, acc_hz_cap = 0;
+
+    // per-iteration updates (cnf2_update_pass) and pre-processing scans
+    uint8_t* d_prior_allele8 = nullptr;
+    double2* d_prior_sure = nullptr;
+    uint8_t* d_has_prior = nullptr;      // [n_rec]
+    bool     priors_set = false;
+    int32_t* d_row_of = nullptr;
+    int32_t* d_children = nullptr;
+    int32_t* d_chromstarts = nullptr;
+    size_t   upd_rec_cap = 0;
+    uint8_t* d_anyinfo = nullptr;
+    size_t   anyinfo_cap = 0;
+    double * d_fw = nullptr, *d_ratio = nullptr;
+    size_t   fw_cap = 0, ratio_cap = 0;
+    int*     d_hits = nullptr;
+    Window*  d_scanwin = nullptr;
+    size_t   scanwin_cap = 0;
+    uint8_t* d_okout = nullptr;
+    size_t   okout_cap = 0;
 };
 
 static std::string g_create_error;
@@ -181,6 +200,18 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_acc_hb);
     (void)hipFree(ctx->d_acc_hc);
     (void)hipFree(ctx->d_acc_hz);
+    (void)hipFree(ctx->d_prior_allele8);
+    (void)hipFree(ctx->d_prior_sure);
+    (void)hipFree(ctx->d_has_prior);
+    (void)hipFree(ctx->d_row_of);
+    (void)hipFree(ctx->d_children);
+    (void)hipFree(ctx->d_chromstarts);
+    (void)hipFree(ctx->d_anyinfo);
+    (void)hipFree(ctx->d_fw);
+    (void)hipFree(ctx->d_ratio);
+    (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_scanwin);
+    (void)hipFree(ctx->d_okout);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev2);
@@ -313,6 +344,7 @@ int cnf2_upload_rows(cnf2_ctx* ctx, int n_rows, const uint8_t* allele, const dou
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hw, cnt * sizeof(double)));
     ctx->n_rows = n_rows;
     ctx->windows_dirty = true;
+    ctx->priors_set = false;
     // a pedigree uploaded against a larger table would index past the new one: drop it, it must be uploaded again
     for (int32_t r : ctx->ped.row_of)
         if (r >= n_rows) {
@@ -904,10 +936,11 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
     int rc = ready(ctx);
     if (rc) return rc;
     const int n_all = (int)ctx->windows.size();
-    if (!descendants || !infprobs || !haplobase || !haplocount || !homozyg || ind_begin < 0 || ind_end > n_all ||
-        ind_begin > ind_end)
-        return fail(ctx, CNF2_ERR_ARG, "bad accumulate arguments");
     const bool out_dev = (flags & CNF2_OUT_DEVICE) != 0, acc_dev = (flags & CNF2_ACC_DEVICE) != 0;
+    const bool acc_given = infprobs && haplobase && haplocount && homozyg;
+    const bool acc_none = !infprobs && !haplobase && !haplocount && !homozyg;    // keep them in the context
+    if (!descendants || (!acc_given && !(acc_none && !acc_dev)) || ind_begin < 0 || ind_end > n_all || ind_begin > ind_end)
+        return fail(ctx, CNF2_ERR_ARG, "bad accumulate arguments");
     if (out_dev && (!factors_out || !loglik_out || !dosage_out)) return fail(ctx, CNF2_ERR_ARG, "output pointer is NULL");
     const HostPedigree& P = ctx->ped;
     const int    n = ind_end - ind_begin;
@@ -1049,7 +1082,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         if (loglik_out) HIP_TRY(ctx, hipMemcpyAsync(loglik_out, d_l, nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (dosage_out) HIP_TRY(ctx, hipMemcpyAsync(dosage_out, d_d, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (!acc_dev) {
+    if (!acc_dev && acc_given) {
         HIP_TRY(ctx, hipMemcpyAsync(infprobs, a_inf, R * M * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(haplobase, a_hb, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(haplocount, a_hc, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1066,6 +1099,236 @@ int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* de
     return cnf2_sweep_accumulate(ctx, ind_begin, ind_end, descendants, nullptr, nullptr, nullptr, infprobs_out,
                                  haplobase_out, haplocount_out, homozyg_out,
                                  flags & ~(uint32_t)(CNF2_OUT_DEVICE | CNF2_ACC_DEVICE | CNF2_ACC_KEEP));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-iteration parameter updates on the device
+// ------------------------------------------------------------------------------------------------
+int cnf2_snapshot_priors(cnf2_ctx* ctx, const uint8_t* has_prior)
+{
+    if (!ctx || !has_prior) return fail(ctx, CNF2_ERR_ARG, "bad prior arguments");
+    if (!ctx->d_allele8 || ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "rows and pedigree must be uploaded first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t cnt = (size_t)ctx->n_rows * ctx->n_markers;
+    if (ctx->d_prior_allele8) HIP_TRY(ctx, hipFree(ctx->d_prior_allele8));
+    if (ctx->d_prior_sure) HIP_TRY(ctx, hipFree(ctx->d_prior_sure));
+    if (ctx->d_has_prior) HIP_TRY(ctx, hipFree(ctx->d_has_prior));
+    ctx->d_prior_allele8 = nullptr;
+    ctx->d_prior_sure = nullptr;
+    ctx->d_has_prior = nullptr;
+    ctx->priors_set = false;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prior_allele8, cnt));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prior_sure, cnt * sizeof(double2)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_has_prior, ctx->ped.n_rec));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior_allele8, ctx->d_allele8, cnt, hipMemcpyDeviceToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior_sure, ctx->d_sure, cnt * sizeof(double2), hipMemcpyDeviceToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_has_prior, has_prior, ctx->ped.n_rec, hipMemcpyHostToDevice));
+    ctx->priors_set = true;
+    return CNF2_OK;
+}
+
+int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const int32_t* descendants, double* infprobs,
+                     double* haplobase, double* haplocount, double scalefactor, double entropyfactor, int* hits_out,
+                     uint32_t flags)
+{
+    if (!ctx || !children || !descendants || !hits_out) return fail(ctx, CNF2_ERR_ARG, "bad update arguments");
+    if (!ctx->d_allele8 || ctx->ped.n_rec == 0 || !ctx->d_rho) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
+    if (!ctx->priors_set) return fail(ctx, CNF2_ERR_STATE, "cnf2_snapshot_priors must be called after the rows were uploaded");
+    if (chrom < 0 || chrom >= ctx->n_chrom) return fail(ctx, CNF2_ERR_ARG, "chromosome out of range");
+    const bool acc_dev = (flags & CNF2_ACC_DEVICE) != 0;
+    const bool given = infprobs && haplobase && haplocount;
+    if (acc_dev && !given) return fail(ctx, CNF2_ERR_ARG, "accumulator pointers are NULL");
+    const HostPedigree& P = ctx->ped;
+    const size_t R = (size_t)P.n_rec, M = (size_t)ctx->n_markers;
+    // a row that is written must belong to one record (all empty individuals may share the blank row: never written)
+    {
+        std::vector<int32_t> owner(ctx->n_rows, -1);
+        for (int r = 0; r < P.n_rec; r++) {
+            if (P.empty[r]) continue;
+            if (owner[P.row_of[r]] >= 0) return fail(ctx, CNF2_ERR_ARG, "records %d and %d share genotype row %d: updates need one row per non-empty record", owner[P.row_of[r]], r, P.row_of[r]);
+            owner[P.row_of[r]] = r;
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (ctx->upd_rec_cap < R) {
+        if (ctx->d_row_of) HIP_TRY(ctx, hipFree(ctx->d_row_of));
+        if (ctx->d_children) HIP_TRY(ctx, hipFree(ctx->d_children));
+        ctx->d_row_of = ctx->d_children = nullptr;
+        ctx->upd_rec_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_row_of, sizeof(int32_t) * R));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_children, sizeof(int32_t) * R));
+        ctx->upd_rec_cap = R;
+    }
+    if (ctx->rec_cap < R) {
+        if (ctx->d_desc) HIP_TRY(ctx, hipFree(ctx->d_desc));
+        if (ctx->d_rec_empty) HIP_TRY(ctx, hipFree(ctx->d_rec_empty));
+        ctx->d_desc = nullptr;
+        ctx->d_rec_empty = nullptr;
+        ctx->rec_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_desc, sizeof(int32_t) * R));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rec_empty, R));
+        ctx->rec_cap = R;
+    }
+    if (!ctx->d_chromstarts) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chromstarts, sizeof(int32_t) * 65536));
+    if (ctx->n_chrom + 1 > 65536) return fail(ctx, CNF2_ERR_ARG, "too many chromosomes");
+    if (!ctx->d_hits) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_hits, sizeof(int)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_row_of, P.row_of.data(), sizeof(int32_t) * R, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_children, children, sizeof(int32_t) * R, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc, descendants, sizeof(int32_t) * R, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rec_empty, P.empty.data(), R, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chromstarts, ctx->chromstarts.data(), sizeof(int32_t) * (ctx->n_chrom + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hits, 0, sizeof(int), ctx->stream));
+    if ((rc = ensure(ctx, &ctx->d_anyinfo, &ctx->anyinfo_cap, R * ctx->n_chrom))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_fw, &ctx->fw_cap, R * M * 2))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_ratio, &ctx->ratio_cap, R * M))) return rc;
+    double *a_inf = infprobs, *a_hb = haplobase, *a_hc = haplocount;
+    if (!acc_dev) {
+        if ((rc = ensure(ctx, &ctx->d_acc_inf, &ctx->acc_inf_cap, R * M * 4))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_acc_hb, &ctx->acc_hb_cap, R * M))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_acc_hc, &ctx->acc_hc_cap, R * M))) return rc;
+        a_inf = ctx->d_acc_inf;
+        a_hb  = ctx->d_acc_hb;
+        a_hc  = ctx->d_acc_hc;
+        if (given) {
+            HIP_TRY(ctx, hipMemcpyAsync(a_inf, infprobs, R * M * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(a_hb, haplobase, R * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(a_hc, haplocount, R * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    UpdateParams u;
+    memset(&u, 0, sizeof(u));
+    u.n_rec = P.n_rec;
+    u.n_markers = ctx->n_markers;
+    u.n_chrom = ctx->n_chrom;
+    u.chrom = chrom;
+    u.first = ctx->chromstarts[chrom];
+    u.last = ctx->chromstarts[chrom + 1] - 1;
+    u.chromstarts_host_upto = ctx->chromstarts[chrom + 1];
+    u.chromstarts = ctx->d_chromstarts;
+    u.row_of = ctx->d_row_of;
+    u.rec_empty = ctx->d_rec_empty;
+    u.has_prior = ctx->d_has_prior;
+    u.children = ctx->d_children;
+    u.descendants = ctx->d_desc;
+    u.allele8 = ctx->d_allele8;
+    u.sure = ctx->d_sure;
+    u.hw = ctx->d_hw;
+    u.prior_allele8 = ctx->d_prior_allele8;
+    u.prior_sure = ctx->d_prior_sure;
+    u.acc_inf = a_inf;
+    u.acc_hb = a_hb;
+    u.acc_hc = a_hc;
+    u.anyinfo = ctx->d_anyinfo;
+    u.fw = ctx->d_fw;
+    u.ratio = ctx->d_ratio;
+    u.relhaplo = 0.5;
+    u.scalefactor = scalefactor;
+    u.entropyfactor = entropyfactor;
+    u.hits = ctx->d_hits;
+    launch_update_pass(u, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->windows_dirty = true;          // rows changed: the "homozygous everywhere" flags must be derived again
+    HIP_TRY(ctx, hipMemcpyAsync(hits_out, ctx->d_hits, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (!acc_dev && given) {
+        HIP_TRY(ctx, hipMemcpyAsync(infprobs, a_inf, R * M * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(haplobase, a_hb, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(haplocount, a_hc, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_download_rows(cnf2_ctx* ctx, int row0, int n, uint8_t* allele, double* sure, double* hw)
+{
+    if (!ctx || !allele || !sure || !hw) return fail(ctx, CNF2_ERR_ARG, "bad row arguments");
+    if (!ctx->d_allele8) return fail(ctx, CNF2_ERR_STATE, "no rows uploaded");
+    if (row0 < 0 || n < 0 || row0 + n > ctx->n_rows) return fail(ctx, CNF2_ERR_ARG, "row range out of bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t M = ctx->n_markers, cnt = (size_t)n * M;
+    std::vector<uint8_t> packed(cnt);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(packed.data(), ctx->d_allele8 + (size_t)row0 * M, cnt, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cnt; i++) {
+        allele[i * 2]     = packed[i] & 15;
+        allele[i * 2 + 1] = packed[i] >> 4;
+    }
+    HIP_TRY(ctx, hipMemcpy(sure, ctx->d_sure + (size_t)row0 * M, cnt * sizeof(double2), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hw, ctx->d_hw + (size_t)row0 * M, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return CNF2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-processing users of the emission for ARBITRARY records (postmarkerdata, cnF2freq.cpp:3190-3412)
+// ------------------------------------------------------------------------------------------------
+// windows of the records recs[0..n): mode 0 = no founder flag anywhere (the state in which main() calls
+// postmarkerdata: fixtrees has not run), mode 1 = the flags fixtrees has left when the records are processed in
+// ascending order (a member's flag counts if its record index is <= the record's own, cnF2freq.cpp:3373-3389),
+// mode 2 = every flag (fixtrees has run on everybody)
+static int scan_windows(cnf2_ctx* ctx, const int32_t* recs, int n, int mode)
+{
+    const HostPedigree& P = ctx->ped;
+    std::vector<Window> ws(n);
+    for (int i = 0; i < n; i++) {
+        if (recs[i] < 0 || recs[i] >= P.n_rec) return fail(ctx, CNF2_ERR_ARG, "record out of range at %d", i);
+        int32_t slot_rec[7];
+        derive_window(P, recs[i], &ws[i], slot_rec);
+        for (int k = 0; k < 7; k++) {
+            if (slot_rec[k] < 0) continue;
+            if (mode == 0 || (mode == 1 && slot_rec[k] > recs[i])) ws[i].flags[k] &= (uint8_t)~SLOT_FOUNDER;
+        }
+    }
+    int rc = ensure(ctx, &ctx->d_scanwin, &ctx->scanwin_cap, (size_t)n);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_scanwin, ws.data(), sizeof(Window) * n, hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
+int cnf2_fixparents_scan(cnf2_ctx* ctx, const int32_t* recs, int n, uint8_t* ok_out)
+{
+    if (!ctx || !recs || !ok_out || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad scan arguments");
+    if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
+    if (n == 0) return CNF2_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = scan_windows(ctx, recs, n, 0);
+    if (rc) return rc;
+    const size_t cnt = (size_t)n * ctx->n_markers * 2;
+    if ((rc = ensure(ctx, &ctx->d_okout, &ctx->okout_cap, cnt))) return rc;
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows = ctx->d_scanwin;
+    launch_okvals(p, n, ctx->d_okout, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ok_out, ctx->d_okout, cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_variances(cnf2_ctx* ctx, const int32_t* recs, int n, int ordered, double* var_out)
+{
+    if (!ctx || !recs || !var_out || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad scan arguments");
+    if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
+    if (n == 0) return CNF2_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t M = ctx->n_markers;
+    // in slabs: one block per (record, marker)
+    const int slab = 4096;
+    int rc;
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)(n < slab ? n : slab) * M))) return rc;
+    for (int i0 = 0; i0 < n; i0 += slab) {
+        const int k = n - i0 < slab ? n - i0 : slab;
+        if ((rc = scan_windows(ctx, recs + i0, k, ordered ? 1 : 2))) return rc;
+        KernelParams p;
+        base_params(ctx, &p);
+        p.windows = ctx->d_scanwin;
+        launch_addvariance_batch(p, k, ctx->d_scratch, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(var_out + (size_t)i0 * M, ctx->d_scratch, (size_t)k * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CNF2_OK;
 }
 
 int cnf2_addvariance(cnf2_ctx* ctx, int ind, int chrom, double* var_out)

@@ -85,6 +85,37 @@ struct AccParams {
     double*        acc_hz;       // [n_ind][n_markers][2] homozyg of the analysed individual (offset like windows)
 };
 void launch_acc_rows(const AccParams& q, hipStream_t stream);
+
+// Inputs of the per-iteration update kernels (cnf2_update.h): what doit does after the sweep of chromosome `chrom`
+// (cnF2freq.cpp:6232-6392): processinfprobs for the markers of that chromosome, updatehaploweights for every marker
+// of the chromosomes swept so far in this iteration.
+struct UpdateParams {
+    int            n_rec, n_markers, n_chrom, chrom, first, last;   // first / last marker of `chrom`
+    int            chromstarts_host_upto;                           // chromstarts[chrom + 1]
+    const int32_t* chromstarts;   // device [n_chrom + 1]
+    const int32_t* row_of;        // [n_rec]
+    const uint8_t* rec_empty;     // [n_rec]
+    const uint8_t* has_prior;     // [n_rec] priormarkerdata exists (the individual was genotyped)
+    const int32_t* children;      // [n_rec] analysed children (cnF2freq.cpp:5248-5260)
+    const int32_t* descendants;   // [n_rec]
+    uint8_t*       allele8;       // rows, updated in place
+    double2*       sure;
+    double*        hw;
+    const uint8_t* prior_allele8; // rows as they were read (cnF2freq.cpp:6664-6665)
+    const double2* prior_sure;
+    double*        acc_inf;       // [n_rec][n_markers][2][2] cleared as it is consumed
+    double*        acc_hb;        // [n_rec][n_markers] rewritten as the reference leaves it
+    double*        acc_hc;
+    uint8_t*       anyinfo;       // [n_rec][n_chrom] scratch
+    double*        fw;            // [n_rec][n_markers][2] scratch
+    double*        ratio;         // [n_rec][n_markers] scratch
+    double         relhaplo;      // 0.5 on this path (cnF2freq.cpp:2496)
+    double         scalefactor, entropyfactor;
+    int*           hits;          // device counter
+};
+void launch_update_pass(const UpdateParams& u, hipStream_t stream);
+void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
+void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
 

@@ -28,6 +28,7 @@
 #include "cnf2_emtab.h"
 #include "cnf2_accum.h"
 #include "cnf2_acctab.h"
+#include "cnf2_update.h"
 
 namespace cnf2 {
 
@@ -1687,7 +1688,9 @@ __device__ __forceinline__ int tp_upflagit(int flag, int parnum, int genwidth)  
 // NOEQ: zeropropagate = NO_EQUIVALENCE (cnF2freq.cpp:42): alleles are matched but an unknown incoming value is
 // not bound (cnF2freq.cpp:311), every level weighs 0.5 instead of its phase weight (cnF2freq.cpp:1229-1233) and
 // below the root only the traced line is followed (cnF2freq.cpp:1291); used by addvariance.
-template <int GW, bool NOEQ = false>
+// CI: CORRECTIONINFERENCE is set (postmarkerdata, cnF2freq.cpp:8083-8085): a pair of equal alleles weighs 0 / 1 whatever
+// its sure values are (cnF2freq.cpp:1235).
+template <int GW, bool NOEQ = false, bool CI = false>
 __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slot, int inmv, double secondval,
                           unsigned flag, int flag99, int localshift, int update, double updateval, double* inf)
 {
@@ -1719,7 +1722,7 @@ __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slo
     } else if (mainsecondval != 0.0) mainsecondval /= baseval;
     f2n ^= (firstpar ^ localshift) & 1;                                  // cpp:1227
     if (NOEQ) baseval *= 0.5;                                            // cpp:1229-1233
-    else if (d.a0 == d.a1 && d.s0 == d.s1) baseval *= (f2n ? 1.0 : 0.0); // cpp:1235-1239
+    else if (d.a0 == d.a1 && (CI || d.s0 == d.s1)) baseval *= (f2n ? 1.0 : 0.0); // cpp:1235-1239
     else baseval *= fabs((f2n ? 1.0 : 0.0) - d.hw);                      // cpp:1245
     if constexpr (GW > 1) {
         if (baseval != 0.0 && !attopnow) {                               // cpp:1271
@@ -1727,7 +1730,7 @@ __device__ double tp_path(const KernelParams& p, const Window& w, int m, int slo
             auto recurse = [&](int fp, int mv, double sv) -> double {    // recursetrackpossible, cpp:984-986, 1035-1057
                 const int child = slot == 0 ? (fp ? 4 : 1) : slot + 1 + fp;
                 if (!(w.flags[child] & SLOT_PRESENT)) return 1.0 + sv;   // cpp:1043-1046
-                return tp_path<GW / 2, NOEQ>(p, w, m, child, mv, sv, (unsigned)tp_upflagit(upflag, fp, GW),
+                return tp_path<GW / 2, NOEQ, CI>(p, w, m, child, mv, sv, (unsigned)tp_upflagit(upflag, fp, GW),
                                        tp_upflagit(upflag2, fp, GW), tp_upflagit(upshift, fp, GW >> 1), down,
                                        updateval, inf);
             };
@@ -1863,7 +1866,7 @@ __global__ __launch_bounds__(256) void addvariance_kernel(KernelParams p, int fi
 {
     __shared__ double red_ok[8][256], red_full[256];
     const int    m  = first + blockIdx.x;
-    const Window w  = p.windows[0];
+    const Window w  = p.windows[blockIdx.y];
     const Slot   me = load_slot(p, w.row[0], m);
     double ok[8], full = 0.0;
 #pragma unroll
@@ -1896,8 +1899,177 @@ __global__ __launch_bounds__(256) void addvariance_kernel(KernelParams p, int fi
     if (threadIdx.x == 0) {
         double sq = 0.0;
         for (int k = 0; k < 8; k++) sq += red_ok[k][0] * red_ok[k][0];
-        out[blockIdx.x] = red_full[0] != 0.0 ? sq : nan("");
+        out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red_full[0] != 0.0 ? sq : nan("");
     }
+}
+
+// fixparents' admissibility test (cnF2freq.cpp:1411-1431) for window y of p.windows at every marker: is there a state i
+// and a path flag2 of parity b with a non-zero emission under shift mode 0, CORRECTIONINFERENCE set?  out[y][m][b].
+// One thread per (marker, parity); the loop ends at the first non-zero value, as the reference's does.
+__global__ __launch_bounds__(256) void okvals_kernel(KernelParams p, uint8_t* out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_markers * 2) return;
+    const int    m = t >> 1, b = t & 1;
+    const Window w = p.windows[blockIdx.y];
+    uint8_t      ok = 0;
+    for (int i = 0; i < 64 && !ok; i++)
+        for (int flag2 = b; flag2 < 128; flag2 += 2) {
+            const double v = tp_path<4, false, true>(p, w, m, 0, 0, 0.0, (unsigned)(i * 2), flag2, 0, 0, 0.0, nullptr);
+            if (v != 0.0) {
+                ok = 1;
+                break;
+            }
+        }
+    out[((size_t)blockIdx.y * p.n_markers + m) * 2 + b] = ok;
+}
+void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(okvals_kernel, dim3((p.n_markers * 2 + 255) / 256, n_windows), dim3(256), 0, stream, p, out);
+}
+void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(addvariance_kernel, dim3(p.n_markers, n_windows), dim3(256), 0, stream, p, 0, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-iteration parameter updates on the device (cnf2_update.h; processinfprobs / updatehaploweights,
+// cnF2freq.cpp:4179-4323, 4533-4734), after the sweep of chromosome `chrom` has been accounted for.
+// ---------------------------------------------------------------------------------------------------
+// One thread per (record, marker of the chromosome): both sides in order (side 1 sees side 0's result only through
+// the accumulators, which are per side), then the record's evidence at the marker is cleared.
+__global__ __launch_bounds__(256) void certainty_update_kernel(UpdateParams u)
+{
+    const int len = u.last - u.first + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * len) return;
+    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool   has_prior = u.has_prior[r] != 0, empty = u.rec_empty[r] != 0;
+    uint8_t ap = u.allele8[i];
+    double2 su = u.sure[i];
+    const uint8_t pap = has_prior ? u.prior_allele8[i] : 0;
+    const double2 psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
+    const StepControl sc = {u.scalefactor, u.entropyfactor};
+    int  hits = 0;
+    bool changed = false;
+    for (int side = 0; side < 2; side++) {
+        if (!(inf[side * 2] > 0) && !(inf[side * 2 + 1] > 0)) continue;
+        SideState s;
+        s.allele = side ? (ap >> 4) : (ap & 15);
+        s.sure = side ? su.y : su.x;
+        s.prior_allele = side ? (pap >> 4) : (pap & 15);
+        s.prior_sure = side ? psu.y : psu.x;
+        int    na;
+        double ns;
+        if (update_certainty(inf + side * 2, s, side, empty, has_prior, u.children[r], sc, &hits, &na, &ns)) {
+            if (side) {
+                ap = (uint8_t)((ap & 15) | (na << 4));
+                su.y = ns;
+            } else {
+                ap = (uint8_t)((ap & 0xF0) | na);
+                su.x = ns;
+            }
+            changed = true;
+        }
+    }
+    inf[0] = inf[1] = inf[2] = inf[3] = 0.0;                  // infprobs[j][side].clear() (cnF2freq.cpp:4315)
+    if (changed) {
+        u.allele8[i] = ap;
+        u.sure[i] = su;
+    }
+    if (hits) atomicAdd(u.hits, hits);
+}
+
+// One thread per (record, chromosome <= chrom): does the chromosome hold any information (haplocount != 0), and if
+// so the phase-consistency ratio of every marker (relskewhmm; relhaplo is the constant the PlantImpute path keeps).
+__global__ __launch_bounds__(64) void phase_ratio_kernel(UpdateParams u)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= u.n_rec * (u.chrom + 1)) return;
+    const int r = t / (u.chrom + 1), c = t % (u.chrom + 1);
+    const int c0 = u.chromstarts[c], c1 = u.chromstarts[c + 1];
+    const double* hc = u.acc_hc + (size_t)r * u.n_markers;
+    bool any = false;
+    for (int k = c0; k < c1 && !any; k++) any = hc[k] != 0.0;
+    u.anyinfo[(size_t)r * u.n_chrom + c] = any ? 1 : 0;
+    if (!any) return;
+    const double* hw = u.hw + (size_t)u.row_of[r] * u.n_markers;
+    double* fw = u.fw + ((size_t)r * u.n_markers + c0) * 2;
+    double* ratio = u.ratio + (size_t)r * u.n_markers + c0;
+    // phase_ratio() of cnf2_update.h with a constant relhaplo
+    double s0 = 0.5, s1 = 0.5;
+    const double n = u.relhaplo, nb = 1 - n;
+    for (int m = c0; m < c1; m++) {
+        const double w = hw[m];
+        s0 *= fabs(1 - w);
+        s1 *= fabs(0 - w);
+        fw[(m - c0) * 2] = s0;
+        fw[(m - c0) * 2 + 1] = s1;
+        if (s0 + s1 < 1e-10) {
+            s0 *= 1e20;
+            s1 *= 1e20;
+        }
+        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+        s0 = t0;
+        s1 = t1;
+    }
+    s0 = s1 = 0.5;
+    const int last = c1 - c0 - 1;
+    ratio[last] = fw[last * 2 + 1] / (fw[last * 2] + fw[last * 2 + 1]);
+    for (int m = c1 - 2; m >= c0; m--) {
+        const double w = hw[m + 1];
+        s0 *= fabs(1 - w);
+        s1 *= fabs(0 - w);
+        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+        s0 = t0;
+        s1 = t1;
+        if (s0 + s1 < 1e-10) {
+            s0 *= 1e20;
+            s1 *= 1e20;
+        }
+        const double r0 = s0 * fw[(m - c0) * 2], r1 = s1 * fw[(m - c0) * 2 + 1];
+        ratio[m - c0] = r1 / (r0 + r1);
+    }
+}
+
+// One thread per (record, marker of the chromosomes <= chrom)
+__global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
+{
+    const int    upto = u.chromstarts[u.chrom + 1];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * upto) return;
+    const int r = (int)(t / upto), m = (int)(t % upto);
+    int c = 0;
+    while (m >= u.chromstarts[c + 1]) c++;
+    if (!u.anyinfo[(size_t)r * u.n_chrom + c]) return;
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const double hw = u.hw[i];
+    if (!(hw != 0.0 && hw != 1.0)) return;                                  // cnF2freq.cpp:4591
+    const uint8_t ap = u.allele8[i];
+    const double2 su = u.sure[i];
+    const size_t  k = (size_t)r * u.n_markers + m;
+    double hb = u.acc_hb[k], hcv = u.acc_hc[k];
+    const StepControl sc = {u.scalefactor, u.entropyfactor};
+    int hits = 0;
+    const double nw = update_haploweight(hw, &hb, &hcv, ap & 15, ap >> 4, su.x, su.y, u.ratio[k], u.children[r],
+                                         u.descendants[r], sc, false, &hits);
+    u.acc_hb[k] = hb;
+    u.acc_hc[k] = hcv;
+    u.hw[i] = nw;
+    if (hits) atomicAdd(u.hits, hits);
+}
+
+void launch_update_pass(const UpdateParams& u, hipStream_t stream)
+{
+    const int    len = u.last - u.first + 1;
+    const size_t n1 = (size_t)u.n_rec * len;
+    hipLaunchKernelGGL(certainty_update_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u);
+    const int n2 = u.n_rec * (u.chrom + 1);
+    hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+    const size_t n3 = (size_t)u.n_rec * u.chromstarts_host_upto;
+    hipLaunchKernelGGL(haploweight_update_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream, u);
 }
 
 // =====================================================================================

@@ -1,0 +1,394 @@
+// cnf2_engine.cpp -- see cnf2_engine.h.
+#include "cnf2_engine.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+namespace cnf2host {
+
+Engine::Engine(Pedigree& ped, cnf2_ctx* c, const EngineOptions& o) : P(ped), ctx(c), opt(o) {}
+
+void Engine::check(int rc, const char* what)
+{
+    if (rc != CNF2_OK) {
+        fprintf(stderr, "%s failed (%d): %s\n", what, rc, cnf2_last_error(ctx));
+        abort();   // the reference aborts on any failure (cnF2freq.cpp:21-25)
+    }
+}
+
+void Engine::upload()
+{
+    M = P.n_markers();
+    C = (int)P.chromstarts.size() - 1;
+    // one row per individual (row 0 stays the blank row): the updates write rows in place, and postmarkerdata locks a
+    // haplotype weight even in individuals without data, so rows cannot be shared the way a single sweep allows
+    build_tables(P, T, false);
+    N = (int)T.dous.size();
+    check(cnf2_upload_map(ctx, P.pos.data(), M, P.chromstarts.data(), C, nullptr), "cnf2_upload_map");
+    check(cnf2_upload_rows(ctx, T.n_rows, T.allele.data(), T.sure.data(), T.hw.data()), "cnf2_upload_rows");
+    check(cnf2_upload_pedigree(ctx, (int)P.inds.size(), T.par.data(), T.empty.data(), T.gen.data(), T.row_of.data(),
+                               T.dous.data(), N),
+          "cnf2_upload_pedigree");
+    std::vector<uint8_t> has_prior(P.inds.size());
+    for (size_t r = 0; r < P.inds.size(); r++) has_prior[r] = P.inds[r].has_prior ? 1 : 0;
+    check(cnf2_snapshot_priors(ctx, has_prior.data()), "cnf2_snapshot_priors");
+    descendants_.assign(P.inds.size(), 0);
+    children_.assign(P.inds.size(), 0);
+    variances_.assign(P.inds.size() * (size_t)M, 0.0);
+    lockstart_.assign(P.inds.size() * (size_t)(C > 0 ? C : 1), 0);
+}
+
+void Engine::push_rows()
+{
+    const int R = (int)P.inds.size();
+    std::vector<uint8_t> allele((size_t)R * M * 2);
+    std::vector<double>  sure((size_t)R * M * 2), hw((size_t)R * M);
+    for (int r = 0; r < R; r++) {
+        const Individual& I = P.inds[r];
+        std::copy(I.allele.begin(), I.allele.end(), allele.begin() + (size_t)r * M * 2);
+        std::copy(I.sure.begin(), I.sure.end(), sure.begin() + (size_t)r * M * 2);
+        std::copy(I.hw.begin(), I.hw.end(), hw.begin() + (size_t)r * M);
+    }
+    if (R > 0) check(cnf2_update_rows(ctx, 1, R, allele.data(), sure.data(), hw.data()), "cnf2_update_rows");
+}
+
+void Engine::pull_rows()
+{
+    const int R = (int)P.inds.size();
+    if (R == 0) return;
+    std::vector<uint8_t> allele((size_t)R * M * 2);
+    std::vector<double>  sure((size_t)R * M * 2), hw((size_t)R * M);
+    check(cnf2_download_rows(ctx, 1, R, allele.data(), sure.data(), hw.data()), "cnf2_download_rows");
+    for (int r = 0; r < R; r++) {
+        Individual& I = P.inds[r];
+        std::copy(allele.begin() + (size_t)r * M * 2, allele.begin() + (size_t)(r + 1) * M * 2, I.allele.begin());
+        std::copy(sure.begin() + (size_t)r * M * 2, sure.begin() + (size_t)(r + 1) * M * 2, I.sure.begin());
+        std::copy(hw.begin() + (size_t)r * M, hw.begin() + (size_t)(r + 1) * M, I.hw.begin());
+    }
+}
+
+// dosureval (cnF2freq.cpp:3084-3097): certainty from the number of supporting relatives and the product of their odds
+static double sureval_from(int what, int /*count*/, double oddsproduct)
+{
+    if (oddsproduct == 0) return 0;
+    double t = exp(log(oddsproduct) / what * 4);
+    return t / (1 + t);
+}
+
+void Engine::postmarkerdata(int indcount)
+{
+    const int R = (int)P.inds.size();
+    // individuals the reference's loops reach: numbers 1 .. indcount - 1
+    auto in_scope = [&](int r) { return P.inds[r].n < indcount; };
+    std::vector<int32_t> recs;
+    for (int r = 0; r < R; r++)
+        if (in_scope(r)) recs.push_back(r);
+    const unsigned char UNKNOWN = 0, SEXMARKER = 9;
+    typedef std::map<int, std::pair<int, double>> ValMap;     // allele value -> (supporting count, product of odds)
+    int any, anyrem;
+    do {
+        for (int r : recs) children_[r] = 0;
+        // fixkid (cnF2freq.cpp:1470-1487): a child without a genotype takes the allele of a homozygous parent
+        for (int r : recs) {
+            Individual& I = P.inds[r];
+            for (int g = 0; g < M; g++) {
+                if (I.allele[g * 2] != UNKNOWN || I.allele[g * 2 + 1] != UNKNOWN) continue;
+                for (int p = 0; p < 2; p++) {
+                    if (I.pars[p] < 0) continue;
+                    const Individual& Q = P.inds[I.pars[p]];
+                    if (Q.allele[g * 2] == UNKNOWN || Q.allele[g * 2] != Q.allele[g * 2 + 1]) continue;
+                    I.allele[g * 2 + p] = Q.allele[g * 2];
+                    I.sure[g * 2 + p]   = 0.5;
+                }
+            }
+        }
+        // descendant counts (cnF2freq.cpp:3224-3255): every individual sends what it has not yet sent to both parents;
+        // the counts are never reset, so a further round of the outer loop sends everything again (reference behaviour)
+        {
+            std::vector<int> upsent(R, 0);
+            bool changed;
+            do {
+                changed = false;
+                for (int r : recs) {
+                    int now = descendants_[r] ? descendants_[r] : 1;
+                    now -= upsent[r];
+                    if (now > 0) {
+                        for (int k = 0; k < 2; k++)
+                            if (P.inds[r].pars[k] >= 0) descendants_[P.inds[r].pars[k]] += now;
+                        upsent[r] += now;
+                        changed = true;
+                    }
+                }
+            } while (changed);
+            for (int r : recs)
+                if (descendants_[r] == 0) descendants_[r] = 1;
+        }
+        for (int r : recs)
+            for (int k = 0; k < 2; k++)
+                if (P.inds[r].pars[k] >= 0) children_[P.inds[r].pars[k]]++;
+        // fixparents (cnF2freq.cpp:1392-1468): the admissibility test runs on the GPU for every individual and marker
+        push_rows();
+        std::vector<uint8_t> ok(recs.size() * (size_t)M * 2);
+        if (!recs.empty()) check(cnf2_fixparents_scan(ctx, recs.data(), (int)recs.size(), ok.data()), "cnf2_fixparents_scan");
+        std::vector<std::vector<ValMap>> vals(R);
+        for (int r : recs) vals[r].resize(M);
+        for (size_t q = 0; q < recs.size(); q++) {
+            const int r = recs[q];
+            Individual& I = P.inds[r];
+            for (int k = 0; k < 2; k++)
+                if (I.pars[k] >= 0 && vals[I.pars[k]].empty()) vals[I.pars[k]].resize(M);
+            for (int g = 0; g < M; g++) {
+                const bool ok0 = ok[(q * M + g) * 2] != 0, ok1 = ok[(q * M + g) * 2 + 1] != 0;
+                if (!ok0 && !ok1) {
+                    fprintf(stderr, "Clearing %d:%d (was %d,%d)\n", I.n, g, I.allele[g * 2], I.allele[g * 2 + 1]);
+                    I.allele[g * 2] = I.allele[g * 2 + 1] = UNKNOWN;
+                    I.sure[g * 2] = I.sure[g * 2 + 1] = 0.0;
+                }
+                if (ok0 == ok1) continue;                      // only an interpretation that stands alone is passed on
+                const int flag2 = ok1 ? 1 : 0;
+                for (int k = 0; k < 2; k++) {
+                    if (I.pars[k] < 0) continue;
+                    const int u = (k ^ flag2) & 1;
+                    const int value = I.allele[g * 2 + u];
+                    if (value == UNKNOWN) continue;
+                    ValMap& vm = vals[I.pars[k]][g];
+                    int     oldcount = 0;
+                    double  oldodds = 1;
+                    auto it = vm.find(value);
+                    if (it != vm.end()) {
+                        oldcount = it->second.first;
+                        oldodds  = it->second.second;
+                    }
+                    double probit = I.sure[g * 2] + I.sure[g * 2 + 1];
+                    probit /= (1 - probit);
+                    vm[value] = std::make_pair(oldcount + 1, oldodds * probit);
+                }
+            }
+        }
+        // corrections (cnF2freq.cpp:3281-3366, latephase is never set)
+        any = 0;
+        anyrem = 0;
+        for (int r : recs) {
+            Individual& I = P.inds[r];
+            if (vals[r].empty()) continue;
+            for (int g = 0; g < M; g++) {
+                ValMap&   vm = vals[r][g];
+                const int known = (I.allele[g * 2] != UNKNOWN) + (I.allele[g * 2 + 1] != UNKNOWN);
+                const int oldany = any;
+                if (known == 2) continue;
+                vm.erase(UNKNOWN);
+                if (I.allele[g * 2] != UNKNOWN) vm.insert(std::make_pair((int)I.allele[g * 2], std::make_pair(children_[r], I.sure[g * 2])));
+                if (I.allele[g * 2 + 1] != UNKNOWN)
+                    vm.insert(std::make_pair((int)I.allele[g * 2 + 1], std::make_pair(children_[r], I.sure[g * 2 + 1])));
+                if (vm.size() >= 3) fprintf(stderr, "Error, too many matches: %d\t%d\n", I.n, g);
+                if (vm.size() == 2) {
+                    auto a = vm.begin(), b = ++vm.begin();
+                    const int knowncount = a->second.first + b->second.first;
+                    I.allele[g * 2]     = (uint8_t)a->first;
+                    I.allele[g * 2 + 1] = (uint8_t)b->first;
+                    I.sure[g * 2]       = sureval_from(knowncount, a->second.first, a->second.second);
+                    I.sure[g * 2 + 1]   = sureval_from(knowncount, b->second.first, b->second.second);
+                    any++;
+                } else if (vm.size() == 1 && known == 0) {
+                    any++;
+                    auto a = vm.begin();
+                    I.allele[g * 2]     = (uint8_t)a->first;
+                    I.allele[g * 2 + 1] = UNKNOWN;
+                    I.sure[g * 2]       = sureval_from(a->second.first, a->second.first, a->second.second);
+                    I.sure[g * 2 + 1]   = 0.0;
+                }
+                if (any != oldany && !opt.quiet)
+                    printf("Correction at %d, marker %d (%d;%d) (%lf;%lf)\n", I.n, g, I.allele[g * 2], I.allele[g * 2 + 1],
+                           I.sure[g * 2], I.sure[g * 2 + 1]);
+            }
+            for (int g = 0; g < M; g++)
+                if (I.allele[g * 2] == SEXMARKER) std::swap(I.allele[g * 2], I.allele[g * 2 + 1]);
+        }
+        fprintf(stderr, "Number of corrected genotypes: %d\n", any);
+    } while (any > anyrem);
+
+    // variances with the record's own window, founder flags as fixtrees has assigned them so far (cnF2freq.cpp:3373-3389)
+    push_rows();
+    if (!recs.empty()) {
+        std::vector<double> var(recs.size() * (size_t)M);
+        check(cnf2_variances(ctx, recs.data(), (int)recs.size(), 1, var.data()), "cnf2_variances");
+        for (size_t q = 0; q < recs.size(); q++)
+            for (int g = 0; g < M; g++) {
+                const double v = var[q * M + g];
+                if (v == v) variances_[(size_t)recs[q] * M + g] = v;       // NaN: the reference leaves the entry alone
+            }
+    }
+    // lockhaplos (cnF2freq.cpp:3045-3081): per chromosome, lock the phase at the marker of largest variance
+    for (int r : recs) {
+        Individual& I = P.inds[r];
+        for (int c = 0; c < C; c++) {
+            int& ls = lockstart_[(size_t)r * C + c];
+            if (ls >= P.chromstarts[c + 1]) ls = 0;
+            int    bestpos = -1;
+            double bestvar = 0;
+            for (int j = std::max(P.chromstarts[c], ls); j != P.chromstarts[c + 1]; j++)
+                if (variances_[(size_t)r * M + j] > bestvar) {
+                    bestpos = j;
+                    bestvar = variances_[(size_t)r * M + j];
+                }
+            if (bestpos == -1) continue;
+            if (!opt.quiet) printf("Fixing point: %d %d %d\n", I.n, c + 1, bestpos);
+            I.hw[bestpos] = I.hw[bestpos] <= 0.5 ? 0 : 1;
+            ls = bestpos + 1;
+        }
+    }
+    push_rows();
+}
+
+bool Engine::deserialize(const char* path)
+{
+    FILE* f = fopen(path, "rt");
+    if (!f) return false;
+    printf("deserialize started.\n");
+    std::vector<char> buf(1 << 16);
+    auto getline = [&](std::string& line) -> bool {
+        if (!fgets(buf.data(), (int)buf.size(), f)) return false;
+        line = buf.data();
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        return true;
+    };
+    std::string line;
+    while (getline(line)) {
+        // a header is exactly "<number> <name>"
+        int  n = 0, used = 0;
+        char name[256], extra[8];
+        if (sscanf(line.c_str(), "%d %255s%n %1s", &n, name, &used, extra) != 2) continue;
+        int r = -1;
+        auto it = P.index.find(name);
+        if (it != P.index.end()) r = it->second;
+        if (r < 0 || P.inds[r].n != n) {
+            fprintf(stderr, "Supposed individual header not a header: %s\n", line.c_str());
+            continue;
+        }
+        Individual& I = P.inds[r];
+        int oldphase = 0, switches = 0;
+        for (int i = 0; i < M; i++) {
+            if (!getline(line)) break;
+            double hw, negshift, s1, s2;
+            int    a, b;
+            if (sscanf(line.c_str(), "%lf %d %d %lf %lf %lf", &hw, &a, &b, &negshift, &s1, &s2) != 6) {
+                fprintf(stderr, "Reading haplotype for marker %d for individual %s failed: %s\n", i, I.name.c_str(), line.c_str());
+                continue;
+            }
+            I.hw[i] = hw;
+            bool inv = false, match = true;
+            if (!(a == I.allele[i * 2] && b == I.allele[i * 2 + 1])) {
+                if (!(b == I.allele[i * 2] && a == I.allele[i * 2 + 1])) {
+                    fprintf(stderr, "Genotype mismatch for marker %d for individual %s (%d,%d) to  (%d,%d)\n", i, I.name.c_str(),
+                            I.allele[i * 2], I.allele[i * 2 + 1], a, b);
+                    match = false;
+                } else inv = true;
+            }
+            I.allele[i * 2]     = (uint8_t)a;
+            I.allele[i * 2 + 1] = (uint8_t)b;
+            I.sure[i * 2]       = s1;
+            I.sure[i * 2 + 1]   = s2;
+            if (hw == 0.5 || a == b || !match) continue;
+            const int newphase = 1 + ((hw > 0.5) ^ inv);
+            if (oldphase && oldphase != newphase) switches++;
+            oldphase = newphase;
+        }
+        const bool par_data = (I.pars[0] >= 0 && !P.inds[I.pars[0]].empty) || (I.pars[1] >= 0 && !P.inds[I.pars[1]].empty);
+        if (children_[r] || par_data) printf("Switches %d %s\t%d\n", I.n, I.name.c_str(), switches);
+    }
+    fclose(f);
+    printf("deserialize finished.\n");
+    push_rows();
+    return true;
+}
+
+void Engine::iteration(FILE* out)
+{
+    const int R = (int)P.inds.size();
+    // children = analysed children of every individual (cnF2freq.cpp:5222-5260)
+    std::fill(children_.begin(), children_.end(), 0);
+    for (int j = 0; j < N; j++)
+        for (int k = 0; k < 2; k++)
+            if (P.inds[T.dous[j]].pars[k] >= 0) children_[P.inds[T.dous[j]].pars[k]]++;
+    std::vector<int32_t> desc(descendants_.begin(), descendants_.end());
+    for (auto& d : desc)
+        if (d == 0) d = 1;     // postmarkerdata leaves no zero; a run without it counts every individual once
+    std::vector<double> factors((size_t)N * C * 8), loglik((size_t)N * C), dosage((size_t)N * M * 3);
+    const uint32_t rowflag = opt.normalise ? 0 : CNF2_RAW_DOSAGE;
+    if (N > 0) {
+        if (opt.update)
+            check(cnf2_sweep_accumulate(ctx, 0, N, desc.data(), factors.data(), loglik.data(), dosage.data(), nullptr, nullptr,
+                                        nullptr, nullptr, rowflag),
+                  "cnf2_sweep_accumulate");
+        else
+            check(cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(),
+                             (opt.merge_modes ? CNF2_MERGE_MODES : 0) | rowflag),
+                  "cnf2_sweep");
+    }
+    for (int c = 0; c < C; c++) {
+        if (!opt.quiet)
+            for (int j = 0; j < N; j++) {
+                int32_t w[17];
+                check(cnf2_window_info(ctx, j, w), "cnf2_window_info");
+                double mx = -1e15;               // the two printf of cnF2freq.cpp:5399-5401
+                for (int s = 0; s < 8; s++) mx = std::max(mx, factors[((size_t)j * C + c) * 8 + s]);
+                printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
+                       P.inds[T.dous[j]].gen < 2 ? 2 : 8);
+            }
+        for (int j = 0; j < N; j++) {            // cnF2freq.cpp:6183-6188
+            fprintf(out, "%s:%d\n", P.inds[T.dous[j]].name.c_str(), c + 1);
+            const double ll = loglik[(size_t)j * C + c];
+            const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
+            if (!skipped)
+                for (int m = P.chromstarts[c]; m < P.chromstarts[c + 1]; m++) {
+                    const double* d = &dosage[((size_t)j * M + m) * 3];
+                    fprintf(out, "%.5lf\t%.5lf\t%.5lf\n", d[0], d[1], d[2]);
+                }
+            fprintf(out, "\n");
+        }
+        fflush(out);
+        if (!opt.update || N == 0) continue;
+        // cnF2freq.cpp:6232-6392: the update pass after this chromosome
+        for (int r = 0; r < R; r++) fprintf(out, "FIRST PASS: %d\n", P.inds[r].n);
+        int hits = 0;
+        check(cnf2_update_pass(ctx, c, children_.data(), desc.data(), nullptr, nullptr, nullptr, scalefactor_, entropyfactor_,
+                               &hits, 0),
+              "cnf2_update_pass");
+        for (int r = 0; r < R; r++) fprintf(out, "SKEWNESS PASS: %d\n", P.inds[r].n);
+        const int  mx = std::max(oldhits_, oldhits2_), mn = std::min(oldhits_, oldhits2_);
+        const bool bad = hits > mx;
+        if (bad) scalefactor_ /= 1.1;
+        const bool good = hits < std::max(mn, N / 7) * 0.99;
+        if (good) scalefactor_ *= 1.21;
+        scalefactor_ *= 0.997;
+        oldhits2_ = oldhits_;
+        oldhits_  = hits;
+        last_hits_ = hits;
+        fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
+    }
+    if (opt.update && N > 0) pull_rows();
+}
+
+void Engine::dump(FILE* out, int limit)
+{
+    for (size_t r = 0; r < P.inds.size(); r++) {
+        const Individual& I = P.inds[r];
+        if (I.n > limit) continue;
+        fprintf(out, "%d %s\n", I.n, I.name.c_str());
+        for (int m = 0; m < M; m++) {
+            if (I.has_prior)
+                fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\t%d\t%d\t%lf\t%lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0,
+                        I.sure[m * 2], I.sure[m * 2 + 1], 0.5, I.prior_allele[m * 2], I.prior_allele[m * 2 + 1],
+                        I.prior_sure[m * 2], I.prior_sure[m * 2 + 1]);
+            else
+                fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0, I.sure[m * 2],
+                        I.sure[m * 2 + 1], 0.5);
+        }
+    }
+}
+
+}  // namespace cnf2host

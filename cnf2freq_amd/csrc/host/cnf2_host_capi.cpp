@@ -1,0 +1,137 @@
+// cnf2_host_capi.cpp -- implementation of include/cnf2host.h: the engine of the `cnF2freq` command line
+// (cnf2_engine.cpp) driven from arrays.
+#include "../../../include/cnf2host.h"
+
+#include <stdio.h>
+
+#include <string>
+
+#include "cnf2_engine.h"
+
+using namespace cnf2host;
+
+struct cnf2h_run {
+    Pedigree  P;
+    cnf2_ctx* ctx = nullptr;
+    Engine*   E = nullptr;
+};
+
+static std::string g_err;
+
+extern "C" {
+
+const char* cnf2h_last_error(void) { return g_err.c_str(); }
+
+cnf2h_run* cnf2h_create(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const uint8_t* has_prior,
+                        const uint8_t* allele, const double* sure, const double* hw, const double* pos, int n_markers,
+                        const int32_t* chromstarts, int n_chrom, const int32_t* dous, int n_dous, int quiet)
+{
+    if (n_rec <= 0 || !par || !empty || !gen || !has_prior || !allele || !sure || !hw || !pos || n_markers <= 0 || !chromstarts ||
+        n_chrom <= 0 || !dous || n_dous < 0) {
+        g_err = "bad arguments";
+        return nullptr;
+    }
+    cnf2h_run* run = new cnf2h_run();
+    Pedigree&  P = run->P;
+    P.pos.assign(pos, pos + n_markers);
+    P.chromstarts.assign(chromstarts, chromstarts + n_chrom + 1);
+    P.index["0"] = -1;
+    const size_t M = (size_t)n_markers;
+    for (int r = 0; r < n_rec; r++) {
+        Individual I;
+        I.n = r + 1;
+        I.name = "r" + std::to_string(r);
+        I.gen = gen[r];
+        I.empty = empty[r] != 0;
+        I.pars[0] = par[r * 2];
+        I.pars[1] = par[r * 2 + 1];
+        I.allele.assign(allele + (size_t)r * M * 2, allele + (size_t)(r + 1) * M * 2);
+        I.sure.assign(sure + (size_t)r * M * 2, sure + (size_t)(r + 1) * M * 2);
+        I.hw.assign(hw + (size_t)r * M, hw + (size_t)(r + 1) * M);
+        I.has_prior = has_prior[r] != 0;
+        if (I.has_prior) {
+            I.prior_allele = I.allele;
+            I.prior_sure = I.sure;
+        }
+        P.index[I.name] = r;
+        P.inds.push_back(I);
+    }
+    P.dous.assign(dous, dous + n_dous);
+    if (cnf2_ctx_create(0, &run->ctx) != CNF2_OK) {
+        g_err = cnf2_last_error(nullptr);
+        delete run;
+        return nullptr;
+    }
+    EngineOptions eo;
+    eo.quiet = quiet != 0;
+    run->E = new Engine(P, run->ctx, eo);
+    run->E->upload();
+    return run;
+}
+
+void cnf2h_destroy(cnf2h_run* run)
+{
+    if (!run) return;
+    delete run->E;
+    cnf2_ctx_destroy(run->ctx);
+    delete run;
+}
+
+int cnf2h_postmarkerdata(cnf2h_run* run, int indcount)
+{
+    if (!run) return -2;
+    run->E->postmarkerdata(indcount);
+    return 0;
+}
+
+int cnf2h_iteration(cnf2h_run* run, const char* rows_path, int update)
+{
+    if (!run) return -2;
+    FILE* f = fopen(rows_path ? rows_path : "/dev/null", "a");
+    if (!f) {
+        g_err = "cannot open rows file";
+        return -2;
+    }
+    run->E->set_update(update != 0);
+    run->E->iteration(f);
+    fclose(f);
+    return 0;
+}
+
+int cnf2h_dump(cnf2h_run* run, const char* path, int limit)
+{
+    if (!run || !path) return -2;
+    FILE* f = fopen(path, "a");
+    if (!f) return -2;
+    run->E->dump(f, limit);
+    fclose(f);
+    return 0;
+}
+
+int cnf2h_deserialize(cnf2h_run* run, const char* path)
+{
+    if (!run || !path) return -2;
+    return run->E->deserialize(path) ? 0 : -2;
+}
+
+int cnf2h_get_state(cnf2h_run* run, uint8_t* allele, double* sure, double* hw, int32_t* descendants, int32_t* children,
+                    double* variances, double* scalefactor, int32_t* last_hits)
+{
+    if (!run) return -2;
+    const Pedigree& P = run->P;
+    const size_t    M = P.pos.size();
+    for (size_t r = 0; r < P.inds.size(); r++) {
+        const Individual& I = P.inds[r];
+        if (allele) std::copy(I.allele.begin(), I.allele.end(), allele + r * M * 2);
+        if (sure) std::copy(I.sure.begin(), I.sure.end(), sure + r * M * 2);
+        if (hw) std::copy(I.hw.begin(), I.hw.end(), hw + r * M);
+        if (descendants) descendants[r] = run->E->descendants()[r];
+        if (children) children[r] = run->E->children()[r];
+    }
+    if (variances) std::copy(run->E->variances().begin(), run->E->variances().end(), variances);
+    if (scalefactor) *scalefactor = run->E->scalefactor();
+    if (last_hits) *last_hits = run->E->last_hits();
+    return 0;
+}
+
+}  // extern "C"

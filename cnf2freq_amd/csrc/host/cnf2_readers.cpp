@@ -220,7 +220,7 @@ void cap_markers(Pedigree& P, int cap)
     }
 }
 
-void build_tables(const Pedigree& P, Tables& T)
+void build_tables(const Pedigree& P, Tables& T, bool share_blank)
 {
     const size_t M = P.pos.size();
     const int    R = (int)P.inds.size();
@@ -243,7 +243,7 @@ void build_tables(const Pedigree& P, Tables& T)
         for (size_t x = 0; x < M && blank; x++)
             if (I.allele[x * 2] || I.allele[x * 2 + 1] || I.sure[x * 2] != 0.0 || I.sure[x * 2 + 1] != 0.0 || I.hw[x] != 0.5)
                 blank = false;
-        if (blank) continue;
+        if (blank && share_blank) continue;
         T.row_of[r] = T.n_rows++;
         T.allele.insert(T.allele.end(), I.allele.begin(), I.allele.end());
         T.sure.insert(T.sure.end(), I.sure.begin(), I.sure.end());

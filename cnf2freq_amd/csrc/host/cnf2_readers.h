@@ -58,7 +58,9 @@ struct Tables {
     std::vector<double>  hw;       // [rows][M]
     int                  n_rows = 0;
 };
-void build_tables(const Pedigree& P, Tables& T);
+// share_blank: every individual whose data equals the blank row maps to row 0 (a single sweep); otherwise one row per
+// individual, row_of[r] = r + 1 (runs that write rows in place)
+void build_tables(const Pedigree& P, Tables& T, bool share_blank = true);
 
 }  // namespace cnf2host
 #endif

@@ -1,0 +1,102 @@
+"""ctypes binding of libcnf2host.so (include/cnf2host.h): the host side of a cnF2freq run -- postmarkerdata, the
+haplotyping iteration with its device-side updates, dump / deserialize -- driven from arrays.  Same code as the
+`cnF2freq` executable; everything numeric goes on to libcnf2hip.so (no CPU compute path here either)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnf2host.so")
+
+SYMBOLS = ["cnf2h_create", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration", "cnf2h_dump",
+           "cnf2h_deserialize", "cnf2h_get_state"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcnf2host.so is not built: run `make -C cnf2freq_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.cnf2h_create.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32]
+        L.cnf2h_create.restype = vp
+        L.cnf2h_destroy.argtypes = [vp]
+        L.cnf2h_destroy.restype = None
+        L.cnf2h_last_error.restype = C.c_char_p
+        L.cnf2h_postmarkerdata.argtypes = [vp, i32]
+        L.cnf2h_iteration.argtypes = [vp, C.c_char_p, i32]
+        L.cnf2h_dump.argtypes = [vp, C.c_char_p, i32]
+        L.cnf2h_deserialize.argtypes = [vp, C.c_char_p]
+        L.cnf2h_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Run:
+    """One run over a cnf2freq_amd.synth.Pedigree (records that are not `empty` count as genotyped, i.e. they have
+    priors, unless has_prior is given)."""
+
+    def __init__(self, ped, has_prior=None, quiet=True):
+        self.L = load()
+        a, s, h = ped.dense()
+        self.n_rec, self.M = ped.n_rec, ped.n_markers
+        hp = (1 - np.asarray(ped.empty)).astype(np.uint8) if has_prior is None else np.ascontiguousarray(has_prior, np.uint8)
+        args = [np.ascontiguousarray(ped.par, np.int32), np.ascontiguousarray(ped.empty, np.uint8),
+                np.ascontiguousarray(ped.gen, np.int32), hp, np.ascontiguousarray(a, np.uint8),
+                np.ascontiguousarray(s, np.float64), np.ascontiguousarray(h, np.float64),
+                np.ascontiguousarray(ped.pos, np.float64)]
+        cs = np.ascontiguousarray(ped.chromstarts, np.int32)
+        dous = np.ascontiguousarray(ped.dous, np.int32)
+        self.h = self.L.cnf2h_create(ped.n_rec, *[_p(x) for x in args[:8]], self.M, _p(cs), len(cs) - 1, _p(dous),
+                                     len(dous), 1 if quiet else 0)
+        if not self.h:
+            raise RuntimeError("cnf2h_create: %s" % self.L.cnf2h_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cnf2h_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def postmarkerdata(self, indcount=None):
+        rc = self.L.cnf2h_postmarkerdata(self.h, self.n_rec + 1 if indcount is None else indcount)
+        assert rc == 0
+
+    def iteration(self, rows_path=None, update=True):
+        rc = self.L.cnf2h_iteration(self.h, None if rows_path is None else str(rows_path).encode(), 1 if update else 0)
+        assert rc == 0
+
+    def dump(self, path, limit=1000000):
+        assert self.L.cnf2h_dump(self.h, str(path).encode(), limit) == 0
+
+    def deserialize(self, path):
+        assert self.L.cnf2h_deserialize(self.h, str(path).encode()) == 0
+
+    def state(self):
+        R, M = self.n_rec, self.M
+        allele = np.zeros((R, M, 2), np.uint8)
+        sure = np.zeros((R, M, 2))
+        hw = np.zeros((R, M))
+        desc = np.zeros(R, np.int32)
+        ch = np.zeros(R, np.int32)
+        var = np.zeros((R, M))
+        sf = C.c_double(0)
+        hits = C.c_int(0)
+        rc = self.L.cnf2h_get_state(self.h, _p(allele), _p(sure), _p(hw), _p(desc), _p(ch), _p(var), C.byref(sf),
+                                    C.byref(hits))
+        assert rc == 0
+        return dict(allele=allele, sure=sure, hw=hw, descendants=desc, children=ch, variances=var,
+                    scalefactor=sf.value, hits=hits.value)

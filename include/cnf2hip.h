@@ -197,6 +197,37 @@ int cnf2_sweep_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32
  * (every term zero).  Brute force over (shift mode 0-1, flag, path) with trackpossible<false, NO_EQUIVALENCE>. */
 int cnf2_addvariance(cnf2_ctx *ctx, int ind, int chrom, double *var_out);
 
+/* The same two pre-processing users for ARBITRARY records, batched (postmarkerdata runs them on every individual,
+ * cnF2freq.cpp:3257-3279, 3373-3389):
+ *  cnf2_fixparents_scan  ok_out[n][M][2]: fixparents' admissibility test (cnF2freq.cpp:1411-1431): is any (state, path of
+ *                        parity b) possible at the marker under shift mode 0 with CORRECTIONINFERENCE set, no founder flag
+ *                        assigned yet (main() calls postmarkerdata before any fixtrees, cnF2freq.cpp:8083-8085)
+ *  cnf2_variances        var_out[n][M] as cnf2_addvariance; ordered != 0: founder flags as fixtrees has assigned them when
+ *                        the records are visited in ascending order (an ancestor's flag counts if its record index is not
+ *                        above the record's own), else every flag. */
+int cnf2_fixparents_scan(cnf2_ctx *ctx, const int32_t *recs, int n, uint8_t *ok_out);
+int cnf2_variances(cnf2_ctx *ctx, const int32_t *recs, int n, int ordered, double *var_out);
+
+/* Per-iteration parameter updates on the device (processinfprobs cnF2freq.cpp:4179-4323,
+ * updatehaploweights 4533-4734, cappedgd 4040-4177 with an own 15-point Gauss-Legendre rule; toulbar2 and the phase
+ * inversions it decides stay out: negshift is never set, no haplotype is inverted between iterations).
+ *  cnf2_snapshot_priors  remembers the rows as they are now as priormarkerdata / priormarkersure (what readalphadata
+ *                        copies at cnF2freq.cpp:6664-6665); has_prior[n_rec] = the record was genotyped.  Call after
+ *                        cnf2_upload_rows / cnf2_upload_pedigree, before any correction is written to the rows.
+ *  cnf2_update_pass      what doit does after the sweep of chromosome `chrom` (cnF2freq.cpp:6232-6392): new markerdata /
+ *                        markersure from the infprobs of that chromosome's markers (then cleared), new haplotype weights
+ *                        for every marker of chromosomes 0..chrom (haplobase / haplocount are rewritten as the reference
+ *                        leaves them), written straight into the rows; *hits_out = hitnnn of this pass.  Accumulators:
+ *                        NULL = the ones cnf2_sweep_accumulate left in the context; device pointers with CNF2_ACC_DEVICE;
+ *                        else host arrays (uploaded, updated, copied back).  children[n_rec]: analysed children per record
+ *                        (cnF2freq.cpp:5248-5260), descendants[n_rec].  Non-empty records must not share a row.
+ *  cnf2_download_rows    rows [row0, row0 + n) back to the host in the layout of cnf2_upload_rows. */
+int cnf2_snapshot_priors(cnf2_ctx *ctx, const uint8_t *has_prior);
+int cnf2_update_pass(cnf2_ctx *ctx, int chrom, const int32_t *children, const int32_t *descendants, double *infprobs,
+                     double *haplobase, double *haplocount, double scalefactor, double entropyfactor, int *hits_out,
+                     uint32_t flags);
+int cnf2_download_rows(cnf2_ctx *ctx, int row0, int n, uint8_t *allele, double *sure, double *hw);
+
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */
 int cnf2_emission(cnf2_ctx *ctx, int ind, int marker, double *e_out);

@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
-GOLDEN_CASES = ["f2_implicit_f1", "outbred3_missing", "random_windows"]
+GOLDEN_CASES = ["f2_implicit_f1", "outbred3_missing", "random_windows", "f2_ungenotyped"]
 
 
 def pytest_configure(config):

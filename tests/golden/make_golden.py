@@ -20,6 +20,8 @@ seeds) and the reference's outputs for them -- data only, no reference text:
   G11 HOT LOOP 2 with its reductions over all analysed individuals in order (moveinfprobs / movehaplos,
      cpp:5876-5902, 3577-3616): per-record infprobs, haplobase, haplocount and per-individual homozyg, for the
      descendant counts stored next to them (acc_desc)
+  G12 the reference's own postmarkerdata (cpp:3190-3412 with fixkid / fixparents 1392-1487, lockhaplos 3045-3081) run on
+     the inputs as main() does: pm_allele / pm_sure / pm_hw / pm_descendants / pm_children / pm_variances
   G10 variances[record][marker] of individ::addvariance with the record's own flag2ignore (NaN where the
      function leaves the entry alone)                                                    (cpp:1489-1558, 3373-3389)
 """
@@ -31,6 +33,9 @@ import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_STACKSIZE", "128M")
+# postmarkerdata's loops are OpenMP loops over individuals whose results depend on the visiting order (founder flags
+# appear as fixtrees reaches each individual, cnF2freq.cpp:3373-3389): one thread = ascending order, reproducible
+os.environ["OMP_NUM_THREADS"] = "1"
 
 from cnf2freq_amd import synth  # noqa: E402
 from oracle.ref_extract.pyref import RefPed  # noqa: E402
@@ -43,7 +48,21 @@ CASES = {
                                                    seed=777, missing=0.2, random_hw=True,
                                                    random_sure=True)),
     "random_windows": (synth.make_random_windows, dict(n_windows=24, n_markers=6, seed=4242)),
+    # an analysed individual that is in the .ped but has no genotype line (empty, all unknown): the window root is
+    # itself empty (reltreeordered[0] is set unconditionally, cnF2freq.cpp:3111)
+    "f2_ungenotyped": (None, dict()),
 }
+
+
+def make_f2_ungenotyped():
+    ped = synth.make_f2(5, 11, 1, seed=321, chrom_cm=25.0, missing=0.1)
+    r = int(ped.dous[2])
+    ped.empty = ped.empty.copy()
+    ped.row_of = ped.row_of.copy()
+    ped.empty[r] = 1
+    ped.row_of[r] = 0
+    ped.founder_flags()
+    return ped
 
 
 def ped_inputs(ped):
@@ -53,7 +72,11 @@ def ped_inputs(ped):
 
 def generate(name):
     ctor, kw = CASES[name]
-    ped = ctor(**kw)
+    ped = make_f2_ungenotyped() if ctor is None else ctor(**kw)
+    # G12 first, on its own load of the pedigree: the reference's postmarkerdata exactly as main() runs it (straight
+    # after the readers, no fixtrees before; cnF2freq.cpp:8083-8085) -- genotypes after fixkid / fixparents inference,
+    # certainties, haplotype weights after lockhaplos, descendant and children counts, variances
+    pm = RefPed(ped, ieee=True, fixtrees_all=False).postmarkerdata()
     R = RefPed(ped, ieee=True)
     rs = np.random.RandomState(99)
     out = {"in_" + k: v for k, v in ped_inputs(ped).items()}
@@ -124,10 +147,11 @@ def generate(name):
             if v is not None:
                 variances[rec, m] = v
     out.update(variances=variances, variances_flag2ignore=var_f2i)
-    from oracle.pyoracle import OraclePed  # only for the descendant counts (an input of the reference call)
-    a_, s_, h_ = ped.dense()
-    desc = OraclePed(a_, s_, h_, ped.par, ped.empty, ped.pos).descendants()
+    # descendant counts: the reference's own (individ::descendants after postmarkerdata, cnF2freq.cpp:3224-3255)
+    desc = pm["descendants"].astype(np.int32)
     acc = R.accumulate(ped.dous, ped.gen[ped.dous], desc)
+    out.update(pm_allele=pm["allele"].astype(np.uint8), pm_sure=pm["sure"], pm_hw=pm["hw"],
+               pm_descendants=pm["descendants"], pm_children=pm["children"], pm_variances=pm["variances"])
     out.update(acc_desc=desc, acc_infprobs=acc["infprobs"], acc_haplobase=acc["haplobase"],
                acc_haplocount=acc["haplocount"], acc_homozyg=acc["homozyg"])
     out.update(fixtrees=fix, rel=rel, ordered=ordered, factors=factors, factor=factor, ok=ok,

@@ -31,6 +31,17 @@ def test_header_symbols_exported(lib):
     assert sorted(capi.SYMBOLS) == decl
 
 
+def test_host_library_exports_its_header(lib):
+    """libcnf2host.so (the host side of a run, include/cnf2host.h) loads without a GPU and exports what it declares."""
+    from cnf2freq_amd import host
+    text = open(os.path.join(ROOT, "include", "cnf2host.h")).read()
+    decl = sorted(set(re.findall(r"\b(cnf2h_[a-z0-9_]+)\s*\(", text)))
+    L = host.load()
+    for name in decl:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(host.SYMBOLS) == decl
+
+
 def test_no_device_is_an_error_not_a_fallback(lib):
     import torch
     if torch.cuda.is_available():

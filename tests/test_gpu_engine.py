@@ -1,0 +1,242 @@
+"""GPU suite: what surrounds the sweep in a cnF2freq run, through libcnf2host.so
+(include/cnf2host.h, the engine the `cnF2freq` executable links) and the update entry points of libcnf2hip.so:
+  * postmarkerdata (fixkid / fixparents inference, descendants, variances, lockhaplos) against the reference's own
+    postmarkerdata run on the same inputs (goldens G12, tests/golden/make_golden.py);
+  * the per-iteration updates on the device against the oracle's literal restatement of processinfprobs /
+    updatehaploweights (parity unpinned there: Boost's quadrature is absent from the image);
+  * whole iterations: parameters move, the dump round-trips through --deserialize, the demo files of the reference."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cnf2freq_amd import synth
+from conftest import GOLDEN_CASES, ROOT, load_golden, oracle_ped
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def libs():
+    import __graft_entry__ as g
+    g.build()
+    from cnf2freq_amd import capi, host
+    assert capi.load().cnf2_device_count() >= 1
+    host.load()
+    return capi, host
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_postmarkerdata_matches_reference(libs, case):
+    capi, host = libs
+    ped, z = load_golden(case)
+    run = host.Run(ped)
+    run.postmarkerdata()
+    st = run.state()
+    assert np.array_equal(st["descendants"], z["pm_descendants"])
+    assert np.array_equal(st["children"], z["pm_children"])
+    assert np.array_equal(st["allele"], z["pm_allele"])
+    np.testing.assert_allclose(st["sure"], z["pm_sure"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(st["variances"], z["pm_variances"], rtol=1e-9, atol=1e-14)
+    assert np.array_equal(st["hw"], z["pm_hw"]), "lockhaplos picked other markers"
+    assert (st["hw"] != ped.dense()[2]).any(), "the fixture should lock some haplotype weights"
+    run.close()
+
+
+def test_fixparents_scan_against_oracle_emission(libs):
+    """cnf2_fixparents_scan: 'is any (state, path of parity b) possible' under shift mode 0 with
+    CORRECTIONINFERENCE set and no founder flags, against the oracle's path-resolved emission."""
+    capi, _ = libs
+    from oracle.pyoracle import OraclePed
+    ped = synth.make_random_windows(12, 4, seed=5)
+    ped.sure = ped.sure.copy()
+    ped.sure[ped.sure < 0.015] = 0.0                       # exact zeros make some parities impossible
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    recs = np.arange(ped.n_rec, dtype=np.int32)
+    got = ctx.fixparents_scan(recs)
+    a, s, h = ped.dense()
+    o = OraclePed(a, s, h, ped.par, ped.empty, ped.pos, founder=np.zeros(ped.n_rec, np.uint8), correction_inference=1,
+                  apply_founder_flags=False)
+    seen = set()
+    for r in range(ped.n_rec):
+        for m in range(ped.n_markers):
+            for b in range(2):
+                want = any(o.emission(r, m, i, f2, 0) != 0.0 for i in range(64) for f2 in range(b, 128, 2))
+                assert bool(got[r, m, b]) == want
+                seen.add(want)
+    assert seen == {True, False}
+    ctx.close()
+
+
+def _oracle_update(ped, acc, children, desc, chrom, scalefactor, allele, sure, hw, prior_allele, prior_sure, has_prior):
+    """processinfprobs for the markers of `chrom`, updatehaploweights for chromosomes <= chrom, per record, through
+    the oracle's literal restatement (cnf2_oracle_iter.c).  Arrays are per record and modified in place."""
+    from oracle import pyoracle
+    O = pyoracle.lib()
+    cs = np.ascontiguousarray(ped.chromstarts, np.int32)
+    hits = C.c_int(0)
+    M = ped.n_markers
+    for r in range(ped.n_rec):
+        for m in range(int(cs[chrom]), int(cs[chrom + 1])):
+            for side in range(2):
+                inf = np.ascontiguousarray(acc["infprobs"][r, m, side])
+                present = (inf > 0).astype(np.int32)
+                if not present.any():
+                    continue
+                out = np.zeros(2)
+                oa, os_ = C.c_int(0), C.c_double(0)
+                if O.cnf2o_processinfprobs(_p(inf), _p(present), side, int(allele[r, m, side]), float(sure[r, m, side]),
+                                           int(has_prior[r]), int(prior_allele[r, m, side]), float(prior_sure[r, m, side]),
+                                           int(ped.empty[r]), int(children[r]), scalefactor, 1.0, C.byref(hits), _p(out),
+                                           C.byref(oa), C.byref(os_)):
+                    allele[r, m, side] = oa.value
+                    sure[r, m, side] = os_.value
+            acc["infprobs"][r, m] = 0
+        sub = np.ascontiguousarray(cs[:chrom + 2])
+        a32 = np.ascontiguousarray(allele[r], np.int32)
+        O.cnf2o_updatehaploweights(chrom + 1, _p(sub), _p(hw[r]), _p(acc["haplobase"][r]), _p(acc["haplocount"][r]), _p(a32),
+                                   _p(np.ascontiguousarray(sure[r])), _p(np.full(M, 0.5)), int(children[r]), int(desc[r]),
+                                   scalefactor, 1.0, C.byref(hits))
+    return hits.value
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.make_outbred3(2, 3, 9, 2, seed=3, missing=0.2),
+    lambda: synth.make_f2(6, 8, 2, seed=9, chrom_cm=30.0, missing=0.15),
+    lambda: synth.make_ail(4, 6, 3, 7, 1, seed=5, chrom_cm=20.0, missing=0.05),
+])
+def test_update_pass_matches_oracle(libs, maker):
+    """One full haplotyping sweep on the GPU, then the update passes of every chromosome on the GPU against the
+    oracle's processinfprobs / updatehaploweights fed with the same accumulators: new genotypes, certainties,
+    haplotype weights, haplobase / haplocount as left behind, and the hit counter."""
+    capi, _ = libs
+    ped = maker()
+    # one row per record (updates write rows in place)
+    a, s, h = ped.dense()
+    ped.allele, ped.sure, ped.hw = np.concatenate([a[:1] * 0, a]).astype(np.uint8), np.concatenate([s[:1] * 0, s]), \
+        np.concatenate([h[:1] * 0 + 0.5, h])
+    ped.row_of = np.arange(1, ped.n_rec + 1, dtype=np.int32)
+    rs = np.random.RandomState(1)
+    ped.hw[1:] = np.where(rs.rand(*ped.hw[1:].shape) < 0.2, 0.5, 0.1 + 0.8 * rs.rand(*ped.hw[1:].shape))
+    ped.hw[1:][ped.empty == 1] = 0.5
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    has_prior = (1 - ped.empty).astype(np.uint8)
+    ctx.snapshot_priors(has_prior)
+    desc = ctx.descendants()
+    children = np.zeros(ped.n_rec, np.int32)
+    for r in ped.dous:
+        for k in range(2):
+            if ped.par[r, k] >= 0:
+                children[ped.par[r, k]] += 1
+    acc = ctx.sweep_accumulate(desc)
+    want_acc = {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")}
+    allele = ped.allele[1:].astype(np.int32).copy()
+    sure, hw = ped.sure[1:].copy(), ped.hw[1:].copy()
+    prior_allele, prior_sure = allele.copy(), sure.copy()
+    moved = 0
+    for c in range(len(ped.chromstarts) - 1):
+        hits = ctx.update_pass(c, children, desc, 0.013, 1.0, acc)
+        want_hits = _oracle_update(ped, want_acc, children, desc, c, 0.013, allele, sure, hw, prior_allele, prior_sure,
+                                   has_prior)
+        assert hits == want_hits
+        ga, gs, gh = ctx.download_rows(1, ped.n_rec)
+        assert np.array_equal(ga, allele)
+        np.testing.assert_allclose(gs, sure, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gh, hw, rtol=1e-9, atol=1e-12)
+        for k in ("haplobase", "haplocount"):
+            np.testing.assert_allclose(acc[k], want_acc[k], rtol=1e-9, atol=1e-12)
+        assert not acc["infprobs"][:, ped.chromstarts[c]:ped.chromstarts[c + 1]].any()
+        moved += int(np.abs(gh - ped.hw[1:]).max() > 1e-6)
+    assert moved > 0
+    ctx.close()
+
+
+def test_iterations_move_parameters_and_round_trip_through_deserialize(libs, tmp_path):
+    """--count 3 semantics through the engine: two haplotyping iterations change haplotype weights and certainties,
+    the dump of the state re-loads into a fresh run (deserialize, cnF2freq.cpp:7757-7832) to the printed precision, and
+    a further iteration from the re-loaded state equals one from the original state to that precision."""
+    capi, host = libs
+    ped = synth.make_outbred3(3, 3, 12, 2, seed=12, missing=0.2)
+    run = host.Run(ped)
+    run.postmarkerdata()
+    s0 = run.state()
+    run.iteration(tmp_path / "rows1.txt")
+    s1 = run.state()
+    run.iteration(tmp_path / "rows2.txt")
+    s2 = run.state()
+    free = (s0["hw"] > 0) & (s0["hw"] < 1) & (ped.empty[:, None] == 0)
+    assert np.abs(s1["hw"] - s0["hw"])[free].max() > 1e-4, "haplotype weights did not move"
+    assert np.abs(s2["hw"] - s1["hw"])[free].max() > 1e-6
+    assert np.abs(s1["sure"] - s0["sure"]).max() > 1e-6, "certainties did not move"
+    assert np.array_equal(s1["hw"][~free & (ped.empty[:, None] == 0)], s0["hw"][~free & (ped.empty[:, None] == 0)]), \
+        "locked weights must stay"
+    assert s1["scalefactor"] != 0.013
+    text = open(tmp_path / "rows1.txt").read()
+    assert "FIRST PASS: 1\n" in text and "SKEWNESS PASS: 1\n" in text
+    run.dump(tmp_path / "dump.txt")
+    again = host.Run(ped)
+    again.postmarkerdata()
+    again.deserialize(tmp_path / "dump.txt")
+    s3 = again.state()
+    assert np.array_equal(s3["allele"], s2["allele"])
+    np.testing.assert_allclose(s3["hw"], s2["hw"], atol=5.1e-7)          # "%f"
+    np.testing.assert_allclose(s3["sure"], s2["sure"], atol=5.1e-7)      # "%lf"
+    run.close()
+    again.close()
+
+
+def test_demo_files_of_the_reference(libs, tmp_path):
+    """The reference's only fixture (demo.sh:37 on demoplantimpute.{map,ped,gen}; CRLF files, a read-count token, an
+    implicit F1 generation, a gen-1 individual as parent): block headers C:1, D:1, F:1 with 18 rows each in --output.
+    `demooutput` is stale (older fork: 4 columns, C and D only, normalised rows): its differences from our
+    normalised rows are recorded, not asserted."""
+    demo = os.path.join(ROOT, "tests", "golden", "demo")
+    exe = os.path.join(ROOT, "cnf2freq_amd", "cnF2freq")
+    out = tmp_path / "demo_out.txt"
+    r = subprocess.run([exe, "--mapfile", os.path.join(demo, "demoplantimpute.map"), "--pedfile",
+                        os.path.join(demo, "demoplantimpute.ped"), "--genfile", os.path.join(demo, "demoplantimpute.gen"),
+                        "--output", str(out), "--count", "10", "--normalise"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(out).read().split("\n")
+    blocks = {}
+    i = 0
+    while i < len(lines):
+        if lines[i] in ("C:1", "D:1", "F:1"):
+            rows = []
+            j = i + 1
+            while lines[j] != "":
+                rows.append([float(x) for x in lines[j].split("\t")])
+                j += 1
+            blocks[lines[i]] = np.array(rows)
+            i = j
+        i += 1
+    assert sorted(blocks) == ["C:1", "D:1", "F:1"]
+    for k, b in blocks.items():
+        assert b.shape == (18, 3), k
+        assert np.allclose(b.sum(axis=1), 1.0, atol=2e-5)
+    # 10 dumps of 11 individuals (A B C C_aux_realf C_aux_realm D D_aux_realf D_aux_realm E F H + haplo = 12) x 18 markers
+    assert sum(1 for x in lines if x == "1 A") == 10
+    assert sum(1 for x in lines if x.startswith("FIRST PASS: ")) > 0
+    # record the differences from the stale demooutput (first three columns of blocks C and D)
+    stale = open(os.path.join(demo, "demooutput")).read().replace("\r", "").split("\n")
+    diffs = {}
+    for name in ("C:1", "D:1"):
+        k = stale.index(name)
+        ref = np.array([[float(x) for x in stale[k + 1 + t].split("\t")[:3]] for t in range(18)])
+        diffs[name] = float(np.abs(ref - blocks[name]).max())
+    record = os.path.join(ROOT, "gpurun_out", "demo_vs_stale_demooutput.txt")
+    os.makedirs(os.path.dirname(record), exist_ok=True)
+    with open(record, "w") as f:
+        for name, d in diffs.items():
+            f.write("%s max |row - demooutput row| = %.5f\n" % (name, d))
+        f.write("argmax class agrees on %d of 36 rows\n" % sum(
+            int(np.argmax(blocks[n][t]) == np.argmax([float(x) for x in stale[stale.index(n) + 1 + t].split("\t")[:3]]))
+            for n in ("C:1", "D:1") for t in range(18)))
