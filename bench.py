@@ -410,6 +410,7 @@ def main():
             merge_info = {"value": float(n) * M / (ms_m[-1] * 1e-3), "unit": "individual*marker/s",
                           "kernel_ms": ms_m[-1], "kernel": "cnf2::fb_packed_kernel",
                           "loglik_bit_identical": bool(torch.equal(loglik, ll_h)),
+                          "loglik_max_rel_diff": float(((loglik - ll_h).abs() / ll_h.abs()).max().item()),
                           "rows_max_abs_diff": float((dosage[:ns] - rows_h).abs().max().item()),
                           "note": "CNF2_MERGE_MODES: modes differing only in the shift bits of parents that are "
                                   "homozygous everywhere are swept once; all 8 modes are output"}

@@ -69,6 +69,7 @@ void Engine::pull_rows()
         std::copy(sure.begin() + (size_t)r * M * 2, sure.begin() + (size_t)(r + 1) * M * 2, I.sure.begin());
         std::copy(hw.begin() + (size_t)r * M, hw.begin() + (size_t)(r + 1) * M, I.hw.begin());
     }
+    rows_stale_ = false;
 }
 
 // dosureval (cnF2freq.cpp:3084-3097): certainty from the number of supporting relatives and the product of their odds
@@ -248,6 +249,7 @@ bool Engine::deserialize(const char* path)
 {
     FILE* f = fopen(path, "rt");
     if (!f) return false;
+    sync_rows();
     printf("deserialize started.\n");
     std::vector<char> buf(1 << 16);
     auto getline = [&](std::string& line) -> bool {
@@ -317,13 +319,17 @@ void Engine::iteration(FILE* out)
     std::vector<int32_t> desc(descendants_.begin(), descendants_.end());
     for (auto& d : desc)
         if (d == 0) d = 1;     // postmarkerdata leaves no zero; a run without it counts every individual once
-    std::vector<double> factors((size_t)N * C * 8), loglik((size_t)N * C), dosage((size_t)N * M * 3);
+    std::vector<double> factors((size_t)N * C * 8), loglik((size_t)N * C), dosage(opt.print_rows ? (size_t)N * M * 3 : 0);
     const uint32_t rowflag = opt.normalise ? 0 : CNF2_RAW_DOSAGE;
     if (N > 0) {
         if (opt.update)
-            check(cnf2_sweep_accumulate(ctx, 0, N, desc.data(), factors.data(), loglik.data(), dosage.data(), nullptr, nullptr,
-                                        nullptr, nullptr, rowflag),
+            check(cnf2_sweep_accumulate(ctx, 0, N, desc.data(), factors.data(), loglik.data(),
+                                        opt.print_rows ? dosage.data() : nullptr, nullptr, nullptr, nullptr, nullptr, rowflag),
                   "cnf2_sweep_accumulate");
+        else if (!opt.print_rows)
+            check(cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), nullptr,
+                             (opt.merge_modes ? CNF2_MERGE_MODES : 0) | CNF2_NO_DOSAGE),
+                  "cnf2_sweep");
         else
             check(cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(),
                              (opt.merge_modes ? CNF2_MERGE_MODES : 0) | rowflag),
@@ -339,7 +345,7 @@ void Engine::iteration(FILE* out)
                 printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
                        P.inds[T.dous[j]].gen < 2 ? 2 : 8);
             }
-        for (int j = 0; j < N; j++) {            // cnF2freq.cpp:6183-6188
+        for (int j = 0; j < N && opt.print_rows; j++) {            // cnF2freq.cpp:6183-6188
             fprintf(out, "%s:%d\n", P.inds[T.dous[j]].name.c_str(), c + 1);
             const double ll = loglik[(size_t)j * C + c];
             const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
@@ -353,12 +359,14 @@ void Engine::iteration(FILE* out)
         fflush(out);
         if (!opt.update || N == 0) continue;
         // cnF2freq.cpp:6232-6392: the update pass after this chromosome
-        for (int r = 0; r < R; r++) fprintf(out, "FIRST PASS: %d\n", P.inds[r].n);
+        if (opt.print_rows)
+            for (int r = 0; r < R; r++) fprintf(out, "FIRST PASS: %d\n", P.inds[r].n);
         int hits = 0;
         check(cnf2_update_pass(ctx, c, children_.data(), desc.data(), nullptr, nullptr, nullptr, scalefactor_, entropyfactor_,
                                &hits, 0),
               "cnf2_update_pass");
-        for (int r = 0; r < R; r++) fprintf(out, "SKEWNESS PASS: %d\n", P.inds[r].n);
+        if (opt.print_rows)
+            for (int r = 0; r < R; r++) fprintf(out, "SKEWNESS PASS: %d\n", P.inds[r].n);
         const int  mx = std::max(oldhits_, oldhits2_), mn = std::min(oldhits_, oldhits2_);
         const bool bad = hits > mx;
         if (bad) scalefactor_ /= 1.1;
@@ -370,11 +378,12 @@ void Engine::iteration(FILE* out)
         last_hits_ = hits;
         fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
     }
-    if (opt.update && N > 0) pull_rows();
+    if (opt.update && N > 0) rows_stale_ = true;
 }
 
 void Engine::dump(FILE* out, int limit)
 {
+    sync_rows();
     for (size_t r = 0; r < P.inds.size(); r++) {
         const Individual& I = P.inds[r];
         if (I.n > limit) continue;

@@ -28,6 +28,7 @@ struct EngineOptions {
     bool normalise = false;     // rows divided by their sum (older reporter); default: raw class sums (cnF2freq.cpp:3523)
     bool update = true;         // false: iterations only sweep and print (parity aid, not a reference mode)
     bool dump_all = true;       // false: only the last iteration dumps (large runs; the reference always dumps)
+    bool print_rows = true;     // false: rows of this iteration are not formatted at all (large runs, non-final iterations)
 };
 
 class Engine {
@@ -46,6 +47,8 @@ public:
     void dump(FILE* out, int limit);
 
     void   set_update(bool u) { opt.update = u; }
+    void   set_print_rows(bool p) { opt.print_rows = p; }
+    void   sync_rows() { if (rows_stale_) pull_rows(); }   // host copies of the individuals' rows up to date
     double scalefactor() const { return scalefactor_; }
     int    last_hits() const { return last_hits_; }
     const std::vector<int>& descendants() const { return descendants_; }
@@ -67,6 +70,7 @@ private:
     std::vector<int>    lockstart_;          // [inds][C]
     double scalefactor_ = 0.013, entropyfactor_ = 1.0;   // cnF2freq.cpp:3573-3574
     int    oldhits_ = 0, oldhits2_ = 0, last_hits_ = 0;
+    bool   rows_stale_ = false;   // the device rows were updated since they were last copied to the host
 };
 
 }  // namespace cnf2host

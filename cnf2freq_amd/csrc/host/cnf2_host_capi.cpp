@@ -93,6 +93,7 @@ int cnf2h_iteration(cnf2h_run* run, const char* rows_path, int update)
         return -2;
     }
     run->E->set_update(update != 0);
+    run->E->set_print_rows(rows_path != nullptr);
     run->E->iteration(f);
     fclose(f);
     return 0;
@@ -118,6 +119,7 @@ int cnf2h_get_state(cnf2h_run* run, uint8_t* allele, double* sure, double* hw, i
                     double* variances, double* scalefactor, int32_t* last_hits)
 {
     if (!run) return -2;
+    run->E->sync_rows();
     const Pedigree& P = run->P;
     const size_t    M = P.pos.size();
     for (size_t r = 0; r < P.inds.size(); r++) {

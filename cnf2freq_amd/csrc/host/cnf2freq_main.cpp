@@ -39,6 +39,7 @@ struct Options {
     bool        preprocess = true;    // --no-preprocess: skip postmarkerdata      } parity aids, not reference modes:
     bool        update = true;        // --no-update: sweeps without the updates    } every round repeats the same sweep
     bool        dump_all = true;      // --dump-last-only: large runs
+    bool        rows_all = true;      // --rows-last-only: large runs (rows of non-final rounds are not formatted)
     bool        parse_only = false;   // print the parsed tables and stop (no GPU needed; used by tests)
 };
 
@@ -76,6 +77,7 @@ static bool parse(int argc, char** argv, Options& o)
         else if (a == "--no-preprocess") o.preprocess = false;
         else if (a == "--no-update") o.update = false;
         else if (a == "--dump-last-only") o.dump_all = false;
+        else if (a == "--rows-last-only") o.rows_all = false;
         else if (a == "--parse-only") o.parse_only = true;
         else {
             fprintf(stderr, "unsupported option %s (this build covers the PlantImpute path only)\n", a.c_str());
@@ -160,7 +162,10 @@ int main(int argc, char** argv)
 
     for (int it = 0; it < opt.count; it++) {
         const bool early = it < 1;                       // cnF2freq.cpp:8131
-        if (!early) E.iteration((it == opt.count - 1) ? out : stdout);
+        if (!early) {
+            E.set_print_rows(opt.rows_all || it == opt.count - 1);
+            E.iteration((it == opt.count - 1) ? out : stdout);
+        }
         fflush(stdout);
         fflush(out);
         if (opt.dump_all || it == opt.count - 1) E.dump(out, opt.limit);

@@ -93,6 +93,20 @@ class TiledGather:
         return t
 
 
+def allreduce_accumulators(infprobs, haplobase, haplocount):
+    """The one collective of a haplotyping iteration: ranks own disjoint blocks of analysed individuals but share
+    ancestors, whose per-record accumulators (infprobs [R, M, 2, 2], haplobase / haplocount [R, M]; what
+    moveinfprobs / movehaplos add up, cnF2freq.cpp:3577-3616) every rank holds a partial sum of.  One
+    all-reduce(sum) of the three slabs (the reference's dead MPI code reduces them per individual,
+    cnF2freq.cpp:6245-6254); every rank then runs the same update pass on the same numbers.  In place; tensors may
+    live on the GPU (nccl = RCCL) or on the host (gloo)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in (infprobs, haplobase, haplocount)]
+    for w in works:
+        w.wait()
+
+
 def gather_ragged_to_root(a, dst=0):
     """Gather numpy arrays whose first dimension differs per rank (block partition);
     returns the concatenation on `dst`, None elsewhere."""

@@ -28,7 +28,7 @@ const char *cnf2h_last_error(void);
 
 /* postmarkerdata(indcount) as main() calls it (cnF2freq.cpp:8083-8085) */
 int cnf2h_postmarkerdata(cnf2h_run *run, int indcount);
-/* one doit<false, genotypereporter> (cnF2freq.cpp:8132): rows and pass lines to rows_path (NULL: discarded);
+/* one doit<false, genotypereporter> (cnF2freq.cpp:8132): rows and pass lines appended to rows_path (NULL: not formatted at all);
  * update = 0 sweeps without the parameter updates */
 int cnf2h_iteration(cnf2h_run *run, const char *rows_path, int update);
 /* the dump of cnF2freq.cpp:8157-8192 to a file (append), and deserialize (cnF2freq.cpp:7757-7832) from one */

@@ -65,13 +65,28 @@ def main():
 
     src = dosage.cpu() if staged else dosage
     tg.run(src, consume)
+    # a haplotyping sweep with its accumulators: every rank adds its individuals' share to per-record slabs on its
+    # own GPU (family members of other ranks' individuals included), one all-reduce sums them
+    desc = ctx.descendants()
+    R = ped.n_rec
+    inf = torch.zeros((R, M, 2, 2), dtype=torch.float64, device=dev)
+    hb = torch.zeros((R, M), dtype=torch.float64, device=dev)
+    hc = torch.zeros((R, M), dtype=torch.float64, device=dev)
+    hz = torch.zeros((nb, M, 2), dtype=torch.float64, device=dev)
+    if i1 > i0:
+        ctx.sweep_accumulate_device(desc, i0, i1, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(), inf.data_ptr(),
+                                    hb.data_ptr(), hc.data_ptr(), hz.data_ptr())
+    ctx.sync()
+    acc = [t.cpu() if staged else t for t in (inf, hb, hc)]
+    cdist.allreduce_accumulators(*acc)
     if rank == 0:
         sizes = [cdist.shard_range(n, r, world) for r in range(world)]
         dos = np.concatenate([full[r, :b - a] for r, (a, b) in enumerate(sizes)])
         ll = np.concatenate([p.cpu().numpy()[:b - a] for p, (a, b) in zip(ll_parts, sizes)])
         fa = np.concatenate([p.cpu().numpy()[:b - a] for p, (a, b) in zip(f_parts, sizes)])
         np.savez(out, dosage=dos, loglik=ll, factors=fa, tiles=np.array(seen), root_bytes=tg.root_bytes(),
-                 tile_bytes=nb * tile * 3 * 8, world=world)
+                 tile_bytes=nb * tile * 3 * 8, world=world, acc_infprobs=acc[0].cpu().numpy(),
+                 acc_haplobase=acc[1].cpu().numpy(), acc_haplocount=acc[2].cpu().numpy())
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()

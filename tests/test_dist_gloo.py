@@ -116,3 +116,40 @@ def test_marker_tiled_gather_single_process():
     out = torch.zeros_like(src)
     tg.run(src, lambda m0, m1, parts: out[:, m0:m1].copy_(parts[0]))
     assert torch.equal(out, src) and tg.root_bytes() == 0
+
+
+def _acc_worker(rank, world, port, q):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, M = 4, 5
+    g = torch.Generator().manual_seed(100 + rank)
+    parts = [torch.rand((R, M, 2, 2), generator=g, dtype=torch.float64), torch.rand((R, M), generator=g, dtype=torch.float64),
+             torch.rand((R, M), generator=g, dtype=torch.float64)]
+    mine = [p.clone() for p in parts]
+    cdist.allreduce_accumulators(*parts)
+    # every rank must hold the sum of all ranks' partial accumulators
+    want = [torch.zeros_like(p) for p in parts]
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        for w, shape in zip(want, [(R, M, 2, 2), (R, M), (R, M)]):
+            w += torch.rand(shape, generator=gr, dtype=torch.float64)
+    ok = all(torch.allclose(a, b, rtol=1e-14, atol=0) for a, b in zip(parts, want)) and not torch.equal(parts[0], mine[0])
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulator_allreduce_two_ranks():
+    """The collective of a haplotyping iteration (shared-ancestor accumulator slabs, cnF2freq.cpp:6245-6254)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_acc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True and q.get(timeout=5) is True

@@ -42,11 +42,17 @@ def test_two_rank_hip_sweep_equals_single_rank(tmp_path, tile):
     ctx = capi.Context(0)
     ctx.upload(ped)
     one = ctx.sweep()
+    acc = ctx.sweep_accumulate(ctx.descendants())
     ctx.close()
     # bit-equality with the single-rank sweep: sharding and tiling must not change a single value
     assert np.array_equal(z["dosage"], one["dosage"])
     assert np.array_equal(z["loglik"], one["loglik"])
     assert np.array_equal(z["factors"], one["factors"])
+    # the accumulators of a haplotyping sweep: per-rank partial sums + one all-reduce = the single-rank sums (the F2
+    # founders are ancestors of every individual on both ranks); equal to rounding, the order of the additions differs
+    for k in ("infprobs", "haplobase", "haplocount"):
+        np.testing.assert_allclose(z["acc_" + k], acc[k], rtol=1e-11, atol=1e-13, equal_nan=True, err_msg=k)
+    assert np.abs(acc["infprobs"][0]).max() > 0, "founder A should collect evidence from every F2"
     # the tiles cover the marker axis exactly once, in order
     tiles = z["tiles"]
     assert tiles[0, 0] == 0 and tiles[-1, 1] == ped.n_markers and np.all(tiles[1:, 0] == tiles[:-1, 1])

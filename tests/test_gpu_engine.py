@@ -44,8 +44,16 @@ def test_postmarkerdata_matches_reference(libs, case):
     assert np.array_equal(st["allele"], z["pm_allele"])
     np.testing.assert_allclose(st["sure"], z["pm_sure"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(st["variances"], z["pm_variances"], rtol=1e-9, atol=1e-14)
-    assert np.array_equal(st["hw"], z["pm_hw"]), "lockhaplos picked other markers"
-    assert (st["hw"] != ped.dense()[2]).any(), "the fixture should lock some haplotype weights"
+    # lockhaplos locks the marker of largest variance per chromosome (cnF2freq.cpp:3058-3065): identical unless two
+    # markers tie to rounding (our variances agree with the reference's to 1e-9, not to the bit)
+    h0 = ped.dense()[2]
+    for r in range(ped.n_rec):
+        got_m, want_m = np.flatnonzero(st["hw"][r] != h0[r]), np.flatnonzero(z["pm_hw"][r] != h0[r])
+        if not np.array_equal(got_m, want_m):
+            v = z["pm_variances"][r]
+            assert len(got_m) == len(want_m) == 1 and abs(v[got_m[0]] - v[want_m[0]]) <= 1e-9 * v[want_m[0]], r
+        assert np.array_equal(st["hw"][r][got_m], np.where(h0[r][got_m] <= 0.5, 0.0, 1.0))
+    assert (st["hw"] != h0).any(), "the fixture should lock some haplotype weights"
     run.close()
 
 
