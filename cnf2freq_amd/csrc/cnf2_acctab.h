@@ -86,8 +86,10 @@ CNF2_HD void line_accumulate_h(const LineCfg& c, const LineTerms& T, const LineT
 
 // The AK_COUNT values of table entry `entry` = P<<5 | f<<4 | sp<<3 | k (cnf2_lane.h) for tie combination `combo`.
 // slot[k]: data of window slot k at the marker (blank for missing slots).  ar = acc_root() of the entry's f.
-CNF2_HD void acc_entry(const Window& w, const Slot slot[7], int entry, int combo, bool no_ties, const AccRoot& ar,
-                       double out[AK_COUNT])
+// This form walks the (up to) 8 paths of the line like the reference does; acc_entry() below is the factored form
+// the kernel uses, checked against this one on the host.
+CNF2_HD void acc_entry_paths(const Window& w, const Slot slot[7], int entry, int combo, bool no_ties, const AccRoot& ar,
+                             double out[AK_COUNT])
 {
     for (int k = 0; k < AK_COUNT; k++) out[k] = 0.0;
     const int  P = entry >> 5;
@@ -134,6 +136,115 @@ CNF2_HD void acc_entry(const Window& w, const Slot slot[7], int entry, int combo
             out[AK_WGP + (c.firstpar * 2 + x) * 2 + i] = H.A.wgp[x][i];
         }
         out[AK_HZ + i] = P ? H.A.h[i] : H.A.wh[i];
+    }
+}
+
+// Factored form of acc_entry_paths.  A path (fp, fgt, fgo) of the line has the emission term
+// base[fp] * ot[fp][fgo] * tr[fp][fgt]; its GENOS weight w_i = R_i lp_i / (R_0 lp_0 + R_1 lp_1) does not depend on the
+// other grandparent (the probe's "other" factor is the emission's own and cancels), so every sum over paths splits
+// into a sum over the other grandparent's alleles times a 2 x 2 sum over (fp, fgt).  Where a weight is 0 / 0 (no probe
+// is possible on a path the emission allows) the reference adds NaN to the HOMOZYGOUS sums but nothing to infprobs
+// (its "non-zero product" tests fail there): kept.
+CNF2_HD void acc_entry(const Window& w, const Slot slot[7], int entry, int combo, bool no_ties, const AccRoot& ar,
+                       double out[AK_COUNT])
+{
+    for (int k = 0; k < AK_COUNT; k++) out[k] = 0.0;
+    const int  P = entry >> 5;
+    const bool root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    LaneJob    L;
+    make_lane(w, entry, &L);
+    const LineCfg& c = L.cfg;
+    const int   sp = 1 + 3 * P;
+    const Slot &par = slot[sp], &tr = slot[sp + 1 + c.firstpar], &ot = slot[sp + 1 + (c.firstpar ^ 1)];
+    LineTerms   TP[2];
+    for (int i = 0; i < 2; i++) line_terms(c, par, tr, ot, i + 1, 0.0, false, &TP[i]);
+    if (root_attop) {
+        out[AK_R] = 1.0;
+        const double den = ar.Rs[0][0] + ar.Rs[0][1];
+        for (int i = 0; i < 2; i++) {
+            const double lp = line_path_term(TP[i], 0, 0, 0);
+            out[AK_HZ + i] = P ? lp : (ar.Rs[0][i] * ar.Xo[i]) * lp / den;
+        }
+        return;
+    }
+    LineTerms T;
+    line_terms(c, par, tr, ot, P ? ar.R.inmv1 : ar.R.inmv0, P ? ar.R.sv1 : ar.R.sv0, P == 0 && ar.R.inmv0 == 2, &T);
+    const int  force_par = no_ties ? -1 : tie_force(L.tie_par, combo), force_tr = no_ties ? -1 : tie_force(L.tie_tr, combo),
+               force_ot = no_ties ? -1 : tie_force(L.tie_ot, combo);
+    const bool par_present = (c.par & SLOT_PRESENT) != 0, par_founder = (c.par & SLOT_FOUNDER) != 0;
+    const bool par_is_line = !par_present || par_founder;
+    const bool tr_real = !par_is_line && (c.tr & SLOT_PRESENT), ot_real = !par_is_line && (c.ot & SLOT_PRESENT);
+    bool okp[2], okt[2], oko[2];
+    for (int a = 0; a < 2; a++) {
+        okp[a] = !par_present || allele_ok(c.par, a, c.firstpar, force_par);
+        okt[a] = tr_real ? allele_ok(c.tr, a, c.bit_tr, force_tr) : (a == 0);
+        oko[a] = ot_real ? allele_ok(c.ot, a, c.bit_ot, force_ot) : (a == 0);
+    }
+    const double* R = ar.Rs[P];
+    double rtot = 0.0, wh[2] = {0, 0}, wroot[2] = {0, 0}, wpar[2][2] = {{0, 0}, {0, 0}}, wgp[2][2] = {{0, 0}, {0, 0}};
+    double h[2] = {0, 0}, rpar[2] = {0, 0}, rtr[2] = {0, 0}, rot[2] = {0, 0};
+    for (int fp = 0; fp < 2; fp++) {
+        if (!okp[fp]) continue;
+        double O = 0.0, Oh[2] = {0, 0};
+        for (int fg = 0; fg < 2; fg++)
+            if (oko[fg]) {
+                O += T.ot[fp][fg];
+                if (T.ot[fp][fg] != 0.0) {
+                    Oh[0] += TP[0].ot[fp][fg];
+                    Oh[1] += TP[1].ot[fp][fg];
+                }
+            }
+        const double bo = T.base[fp] * O;
+        double       trsum = 0.0, th[2] = {0, 0};
+        for (int fg = 0; fg < 2; fg++) {
+            if (!okt[fg]) continue;
+            const double t = T.tr[fp][fg];
+            trsum += t;
+            if (t != 0.0) {
+                th[0] += TP[0].tr[fp][fg];
+                th[1] += TP[1].tr[fp][fg];
+            }
+            const double term = bo * t;                    // sum over the other grandparent's admissible alleles
+            rtr[(fg ^ c.bit_tr) & 1] += term;
+            if (term == 0.0) continue;                     // no path with a positive val here: never evaluated
+            const double l0 = TP[0].base[fp] * TP[0].tr[fp][fg], l1 = TP[1].base[fp] * TP[1].tr[fp][fg];
+            const double den = R[0] * l0 + R[1] * l1;
+            for (int i = 0; i < 2; i++) {
+                const double wi = (R[i] * (i ? l1 : l0)) / den;
+                const double tw = term * wi;
+                wh[i] += tw;
+                if (den != 0.0) {
+                    wroot[i] += tw;
+                    if (par_present) wpar[fp][i] += tw;
+                    if (tr_real) wgp[fg][i] += tw;
+                }
+            }
+        }
+        rtot += bo * trsum;
+        rpar[(fp ^ c.firstpar) & 1] += bo * trsum;
+        for (int fg = 0; fg < 2; fg++)
+            if (oko[fg]) rot[(fg ^ c.bit_ot) & 1] += (T.base[fp] * T.ot[fp][fg]) * trsum;
+        if (T.base[fp] != 0.0)
+            for (int i = 0; i < 2; i++) h[i] += TP[i].base[fp] * Oh[i] * th[i];
+    }
+    out[AK_R] = rtot;
+    if (par_present) {
+        for (int ph = 0; ph < 2; ph++) out[AK_HAP + 0 * 2 + ph] = rpar[ph ^ c.sp];
+        if (!par_founder) {
+            const int gt = c.firstpar, go = c.firstpar ^ 1;
+            if (c.tr & SLOT_PRESENT)
+                for (int ph = 0; ph < 2; ph++) out[AK_HAP + (1 + gt) * 2 + ph] = rtr[ph];
+            if (c.ot & SLOT_PRESENT)
+                for (int ph = 0; ph < 2; ph++) out[AK_HAP + (1 + go) * 2 + ph] = rot[ph];
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        out[AK_WROOT + i] = wroot[i];
+        for (int x = 0; x < 2; x++) {
+            out[AK_WPAR + x * 2 + i] = wpar[x][i];
+            out[AK_WGP + (c.firstpar * 2 + x) * 2 + i] = wgp[x][i];
+        }
+        out[AK_HZ + i] = P ? h[i] : wh[i];
     }
 }
 

@@ -257,6 +257,30 @@ int shim_acc_contract(int n_rec, const int32_t* par, const uint8_t* empty, const
     return w.n_groups;
 }
 
+// every table entry of one (individual, marker): the factored form against the path-walking form.  out_*[64][AK_COUNT]
+int shim_acc_entries(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const int32_t* row_of,
+                     const uint8_t* allele, const double* sure, const double* hw, int n_markers, int rec, int marker,
+                     int combo, double* out_fast, double* out_paths)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    Slot slot[7];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot[k] = unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    }
+    const bool attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    for (int e = 0; e < 64; e++) {
+        AccRoot ar;
+        acc_root(slot[0], attop, (e >> 4) & 1, &ar);
+        acc_entry(w, slot, e, combo, false, ar, out_fast + e * AK_COUNT);
+        acc_entry_paths(w, slot, e, combo, false, ar, out_paths + e * AK_COUNT);
+    }
+    return w.n_groups;
+}
+
 // ---- per-iteration updates (cnf2_update.h) ----
 double shim_cap_step(double intended, double orig, double epsilon, int* hits, int breakathalf)
 {

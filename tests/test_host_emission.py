@@ -270,3 +270,33 @@ def test_table_form_of_all_accumulators_matches_fanout(shim, maker):
             checked += 1
             tied += int(ng > 0)
     assert checked > 0
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_factored_table_entries_equal_the_path_walk(shim, seed):
+    """acc_entry (sums over paths factored into 2 x 2 sums; what the kernel evaluates) against acc_entry_paths (the
+    8-path walk pinned on the oracle above), every entry and tie combination, random windows with exact zeros
+    (impossible paths, 0 / 0 weights: NaN must appear in the same places)."""
+    ped = synth.make_random_windows(40, 3, seed=seed)
+    ped.sure = ped.sure.copy()
+    ped.sure[ped.sure < 0.02] = 0.0
+    # the sex-marker sentinel (cnF2freq.cpp:226) with sure 0 matches neither probe value: 0 / 0 weights
+    rs = np.random.RandomState(seed)
+    hit = rs.rand(*ped.allele.shape[:2]) < 0.1
+    hit[0] = False
+    ped.allele = ped.allele.copy()
+    ped.allele[hit, 1] = 9
+    ped.sure[hit, 1] = 0.0
+    nan_seen = 0
+    for ind in ped.dous:
+        for m in range(ped.n_markers):
+            a, b = np.zeros((64, 23)), np.zeros((64, 23))
+            ng = shim.shim_acc_entries(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, int(ind), m,
+                                       0, _p(a), _p(b))
+            for combo in range(1 << ng):
+                shim.shim_acc_entries(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, int(ind), m,
+                                      combo, _p(a), _p(b))
+                assert np.array_equal(np.isnan(a), np.isnan(b))
+                np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300, equal_nan=True)
+                nan_seen += int(np.isnan(b).any())
+    assert nan_seen > 0 or seed != 31
