@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_fixparents_scan", "cnf2_variances",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
@@ -74,6 +74,7 @@ def load():
         L.cnf2_descendants.argtypes = [vp, vp]
         L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_sweep_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
+        L.cnf2_sweep_turn_scan.argtypes = [vp, i32, i32, vp, vp, C.c_uint32]
         L.cnf2_fixparents_scan.argtypes = [vp, vp, i32, vp]
         L.cnf2_variances.argtypes = [vp, vp, i32, i32, vp]
         L.cnf2_snapshot_priors.argtypes = [vp, vp]
@@ -302,6 +303,16 @@ class Context:
                                                C.c_void_p(d_loglik), C.c_void_p(d_dosage), C.c_void_p(d_inf),
                                                C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
                                                flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
+
+    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True):
+        """Batched turn scan: rawervals [n][M][128][8] and / or their log-sum-exp over the admissible modes [n][M][128]."""
+        ind_end = self.n_ind if ind_end is None else ind_end
+        n = ind_end - ind_begin
+        raw = np.zeros((n, self.n_markers, 128, 8)) if full else None
+        ls = np.zeros((n, self.n_markers, 128)) if lse else None
+        self._chk(self.L.cnf2_sweep_turn_scan(self.h, ind_begin, ind_end, _p(raw) if full else None, _p(ls) if lse else None,
+                                              0 if ties else NO_TIES), "cnf2_sweep_turn_scan")
+        return raw, ls
 
     def fixparents_scan(self, recs):
         recs = np.ascontiguousarray(recs, np.int32)

@@ -1092,6 +1092,122 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
     return CNF2_OK;
 }
 
+// Batched turn scan (HOT LOOP 3, cnF2freq.cpp:5686-5752) for the analysed individuals [ind_begin, ind_end): the sweep
+// kernels run in their turn-scan instantiation (alpha after emission and beta of every marker, with scales, into a
+// batch buffer), turn_rows_kernel forms rawervals[turn][s] for all 128 turns and 8 shift modes of every marker.
+int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawervals_out, double* turn_lse_out,
+                         uint32_t flags)
+{
+    int rc = ready(ctx);
+    if (rc) return rc;
+    const int n_all = (int)ctx->windows.size();
+    if ((!rawervals_out && !turn_lse_out) || ind_begin < 0 || ind_end > n_all || ind_begin > ind_end)
+        return fail(ctx, CNF2_ERR_ARG, "bad turn scan arguments");
+    const bool out_dev = (flags & CNF2_OUT_DEVICE) != 0;
+    const int    n = ind_end - ind_begin;
+    const size_t M = (size_t)ctx->n_markers;
+    if (n == 0) return CNF2_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nf = (size_t)n * ctx->n_chrom * 8, nl = (size_t)n * ctx->n_chrom, nd = (size_t)n * M * 3;
+    if ((rc = ensure(ctx, &ctx->d_factors, &ctx->factors_cap, nf))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_loglik, &ctx->loglik_cap, nl))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_dosage, &ctx->dosage_cap, nd))) return rc;
+    double *d_full = rawervals_out, *d_lse = turn_lse_out;
+    if (!out_dev) {
+        // staging for the whole range: 9 KB per individual x marker -- callers with large ranges use device buffers
+        d_full = d_lse = nullptr;
+        const size_t need = (rawervals_out ? (size_t)n * M * 1024 : 0) + (turn_lse_out ? (size_t)n * M * 128 : 0);
+        if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, need))) return rc;
+        double* q0 = ctx->d_scratch;
+        if (rawervals_out) {
+            d_full = q0;
+            q0 += (size_t)n * M * 1024;
+        }
+        if (turn_lse_out) d_lse = q0;
+    }
+    std::vector<Job> jobs;
+    size_t           n_fast = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int c = 0; c < ctx->n_chrom; c++)
+            for (int j = 0; j < n; j++) {
+                const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
+                if (tied != (pass == 1)) continue;
+                Job jb;
+                jb.ind = j;
+                jb.first = ctx->chromstarts[c];
+                jb.last = ctx->chromstarts[c + 1] - 1;
+                jb.chrom = c;
+                jobs.push_back(jb);
+            }
+        if (pass == 0) n_fast = jobs.size();
+    }
+    if ((rc = ensure(ctx, &ctx->d_jobs, &ctx->jobs_cap, jobs.size() + 1))) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice));
+    const int    mlen = max_chrom_len(ctx);
+    const size_t stride = (size_t)mlen * 528;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->spill_bytes + ctx->wbuf_cap * sizeof(double);
+    int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu;
+    const size_t per_blk = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
+    if ((size_t)grid_cap * per_blk > free_b / 4) grid_cap = (int)(free_b / 4 / per_blk);
+    if (grid_cap < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the spill of one block");
+    {
+        size_t capd = ctx->spill_bytes / sizeof(double);
+        rc = ensure(ctx, &ctx->d_spill, &capd, (size_t)grid_cap * CNF2_WAVES_PER_BLOCK * stride);
+        ctx->spill_bytes = capd * sizeof(double);
+        if (rc) return rc;
+    }
+    const size_t per_job = (size_t)mlen * 1040;
+    size_t       batch = (free_b - (size_t)grid_cap * per_blk) / 2 / (per_job * sizeof(double));
+    if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the alpha/beta rows of one job");
+    if (batch > jobs.size()) batch = jobs.size();
+    if (batch > 1000000) batch = 1000000;
+    if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
+    KernelParams p;
+    base_params(ctx, &p);
+    p.windows      = ctx->d_windows + ind_begin;
+    p.spill        = ctx->d_spill;
+    p.spill_stride = stride;
+    p.factors      = ctx->d_factors;
+    p.loglik       = ctx->d_loglik;
+    p.dosage       = ctx->d_dosage;
+    p.flags        = (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0;
+    p.wbuf         = ctx->d_wbuf;
+    p.wstride      = (size_t)mlen;
+    TurnParams q;
+    memset(&q, 0, sizeof(q));
+    q.max_len   = mlen;
+    q.rawervals = d_full;
+    q.turn_lse  = d_lse;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int pass = 0; pass < 2; pass++) {
+        const size_t lo = pass ? n_fast : 0, hi = pass ? jobs.size() : n_fast;
+        for (size_t b0 = lo; b0 < hi; b0 += batch) {
+            const size_t nb = (hi - b0 < batch) ? hi - b0 : batch;
+            p.jobs   = ctx->d_jobs + b0;
+            p.n_jobs = (int)nb;
+            int grid = (int)((nb + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+            if (grid > grid_cap) grid = grid_cap;
+            if (pass == 0) launch_fb_fast_ab(p, grid, ctx->stream);
+            else launch_fb_ab(p, grid, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+            q.kp     = p;
+            q.n_jobs = (int)nb;
+            launch_turn_rows(q, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    if (!out_dev) {
+        if (rawervals_out) HIP_TRY(ctx, hipMemcpyAsync(rawervals_out, d_full, (size_t)n * M * 1024 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (turn_lse_out) HIP_TRY(ctx, hipMemcpyAsync(turn_lse_out, d_lse, (size_t)n * M * 128 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CNF2_OK;
+}
+
 // The accumulators alone, into host arrays (zeroed first): the form the parity tests use.
 int cnf2_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32_t* descendants, double* infprobs_out,
                     double* haplobase_out, double* haplocount_out, double* homozyg_out, uint32_t flags)

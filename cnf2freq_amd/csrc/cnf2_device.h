@@ -118,6 +118,16 @@ void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
+void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream);
+void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream);
+// Inputs of the batched turn scan (turn_rows_kernel): what a turn-scan sweep (STOREW == 2) left in kp.wbuf
+struct TurnParams {
+    KernelParams kp;
+    int          n_jobs, max_len;
+    double*      rawervals;   // [n_ind][n_markers][128][8] or NULL
+    double*      turn_lse;    // [n_ind][n_markers][128] or NULL
+};
+void launch_turn_rows(const TurnParams& q, hipStream_t stream);
 
 // Inputs of the stage-2 parity kernels: the reference-layout store of ONE individual x chromosome.
 struct Stage2Params {

@@ -333,7 +333,9 @@ __device__ __forceinline__ double chain_normaliser(const double (&v)[8], double*
     return inv;
 }
 
-template <bool DEBUG_STORE, bool STOREW = false>
+// STOREW: 0 = plain sweep; 1 = accumulate mode (posterior weights of every marker into p.wbuf); 2 = turn-scan mode
+// (alpha after emission and beta of every marker with their log2 scales into p.wbuf, 1040 doubles per marker)
+template <bool DEBUG_STORE, int STOREW = 0>
 __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 {
     __shared__ double lds_tab[CNF2_WAVES_PER_BLOCK][64];
@@ -493,7 +495,20 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
                     }
                 }
                 D     = chain_sum(D);
-                if (STOREW) {
+                if (STOREW == 2) {
+                    // turn-scan mode: A = alphaminus e, B = beta (both as the normalised vectors held here) and their
+                    // log2 scales: log2 P(data, mode) = fs / ln 2 = lgA + lgB + log2 D
+                    double* wp = p.wbuf + ((size_t)job * p.wstride + (m - first)) * 1040;
+                    const double lgB = log2(bmant) + (double)bexpo;
+                    const double lgA = fs * 1.4426950408889634074 - log2(D) - lgB;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        *(double2*)(wp + k * 128 + lane * 2) = make_double2(sp[(2 * k) * 64] * e[2 * k], sp[(2 * k + 1) * 64] * e[2 * k + 1]);
+                        *(double2*)(wp + 512 + k * 128 + lane * 2) = make_double2(b[2 * k], b[2 * k + 1]);
+                    }
+                    if (c.lo == 0) *(double2*)(wp + 1024 + 2 * s) = make_double2(lgA, lgB);
+                }
+                if (STOREW == 1) {
                     // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta = wj * ws / D
                     const double sw = (D > 0.0) ? ws / D : 0.0;
                     double*      wp = p.wbuf + ((size_t)job * p.wstride + (m - first)) * 512;
@@ -746,7 +761,7 @@ struct BwdState {
 // HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
 // spill traffic for ~15 % more arithmetic.
-template <bool HALF, bool STOREW = false>
+template <bool HALF, int STOREW = 0>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
     // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
@@ -926,6 +941,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             constexpr bool ODD = decltype(odd_tag)::value;
             const int      ml  = m - first;
             double         wj[8];
+            double         aw[STOREW == 2 ? 8 : 1];                 // turn-scan mode: alpha-minus of this marker, unscaled
             const double2 r_m = *(const double2*)(row + TAB_T);     // gap m-1 -> m
             double        inv_m;
             if (ODD) {
@@ -938,10 +954,18 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 // the normaliser inv(m-1) is a per-chain scalar and everything below is linear in wj:
                 // it is applied to the three class sums (`scale`) instead of to the eight states
                 transition_scaled(wj, r_m.x, r_m.y);
+                if (STOREW == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) aw[j] = wj[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) wj[j] *= S.b[j];
                 inv_m = S.inv_odd;
             } else {
+                if (STOREW == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) aw[j] = S.am[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) wj[j] = S.am[j] * S.b[j];
                 inv_m = S.inv_even;
@@ -983,7 +1007,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
-            if (STOREW) {
+            if (STOREW == 1) {
                 // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta for the batched HOT LOOP 2 kernel
                 double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
 #pragma unroll
@@ -996,6 +1020,23 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // that it does not occupy registers across them
             double e[8];
             emission_from_row(row, c, e);
+            if (STOREW == 2) {
+                // turn-scan mode: A = alphaminus e and B = beta as held here, with the log2 of the scales that make them
+                // absolute (alphaminus: Fpre, and the stored normaliser of the even neighbour for a rebuilt odd marker)
+                double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 1040;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const d2v va = {aw[2 * k] * e[2 * k], aw[2 * k + 1] * e[2 * k + 1]};
+                    const d2v vb = {S.b[2 * k], S.b[2 * k + 1]};
+                    __builtin_nontemporal_store(va, (d2v*)(wp + k * 128 + lane * 2));
+                    __builtin_nontemporal_store(vb, (d2v*)(wp + 512 + k * 128 + lane * 2));
+                }
+                if (c.lo == 0) {
+                    const double lgA = log2((ODD ? S.inv_even : 1.0) * S.fmant) + (double)S.fexpo;
+                    const double lgB = log2(S.bmant) + (double)S.bexpo;
+                    *(double2*)(wp + 1024 + 2 * s) = make_double2(lgA, lgB);
+                }
+            }
             // every lane parks its three class partials in this marker's row (all of it is dead by now:
             // tables, root weights and gap factors have been read); the tile epilogue sums them
             wave_lds_fence();
@@ -2379,11 +2420,115 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
 
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fb_fast_kernel<true, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL((fb_fast_kernel<true, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fb_kernel<false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL((fb_kernel<false, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_fast_kernel<true, 2>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_kernel<false, 2>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+
+// =====================================================================================
+// Batched turn scan (HOT LOOP 3, cnF2freq.cpp:5686-5752): rawervals[turn][s] =
+// doanalyze<aroundturner>(turn, classicstop(q, -1)) - factor for every marker of every job of a turn-scan sweep,
+// one wavefront per (job, marker).  aroundturner(turn) XORs the states with turn & 54 and the shift mode with
+// (turn >> 6) | (turn & 1 ? 2 : 0) | (turn & 8 ? 4 : 0) (cnF2freq.cpp:506-511), so
+//     rawervals[turn][s] = log sum_k A_s(k ^ (turn & 54)) B_{s ^ shiftx}(k) + scales - factor:
+// 8 shift flips (B fetched from the partner chain: lane moves), 4 flips of state bits 1-2 (lanes inside a chain: DPP)
+// and 4 of state bits 4-5 (registers: free), an 8-term dot product and a chain sum each.  One logarithm per 8 turns
+// and lane (lane lo keeps the sum of the turn whose index is lo mod 8).  Outputs: the full table and / or its
+// log-sum-exp over the admissible shift modes per turn (what the clause weights of cnF2freq.cpp:5800-5817 are made of).
+// =====================================================================================
+__global__ __launch_bounds__(CNF2_BLOCK) void turn_rows_kernel(TurnParams q)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job  = blockIdx.x;
+    const int ml   = blockIdx.y * CNF2_WAVES_PER_BLOCK + wib;
+    const KernelParams& p = q.kp;
+    const Job jb = p.jobs[job];
+    if (ml >= jb.last - jb.first + 1) return;
+    const int    m = jb.first + ml;
+    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
+    const Window w = p.windows[jb.ind];
+    const int s = lane >> 3, lo = state_lo(lane);
+    const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 1040;
+    double A[4][8], B[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double2 va = *(const double2*)(wp + k * 128 + lane * 2);
+        const double2 vb = *(const double2*)(wp + 512 + k * 128 + lane * 2);
+        A[0][2 * k] = va.x;
+        A[0][2 * k + 1] = va.y;
+        B[2 * k] = vb.x;
+        B[2 * k + 1] = vb.y;
+    }
+    const double2 sc = *(const double2*)(wp + 1024 + 2 * s);          // log2 scales of this lane's chain
+    // the four flips of state bits 1, 2 (lane bits through the GF(2) map of the sweep: flip_b1, flip_b2)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        A[1][j] = lane_flip_b1(A[0][j]);
+        A[2][j] = lane_flip_b2(A[0][j]);
+        A[3][j] = lane_flip_b2(A[1][j]);
+    }
+    double* full = q.rawervals ? q.rawervals + ((size_t)jb.ind * p.n_markers + m) * 1024 : nullptr;
+    double* lse  = q.turn_lse ? q.turn_lse + ((size_t)jb.ind * p.n_markers + m) * 128 : nullptr;
+    const bool s_ok = !(s & w.shiftignore) && s < w.shiftend;
+#pragma unroll 1
+    for (int sx = 0; sx < 8; sx++) {
+        // B and its scale from the chain this one turns into
+        double Bs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) Bs[j] = __shfl_xor(B[j], sx << 3);
+        const double lgBs = __shfl_xor(sc.y, sx << 3);
+        const double base = (sc.x + lgBs) * 0.69314718055994530942 - factor;
+        // 16 state flips in two groups of 8 turns; turn bits: 0 <- sx bit 1, 3 <- sx bit 2, 6 <- sx bit 0
+        const int tshift = ((sx >> 1) & 1) | (((sx >> 2) & 1) << 3) | ((sx & 1) << 6);
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            double keep = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int x = grp * 8 + t;                     // x bit 0 -> state bit 1, 1 -> bit 2, 2 -> bit 4, 3 -> bit 5
+                const int xl = x & 3, xj = (x >> 2) << 1;      // lane flips (b1, b2), register xor on j bits 1, 2
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) v = fma(A[xl][j ^ xj], Bs[j], v);
+                v = chain_sum(v);
+                if (lo == t) keep = v;
+            }
+            // this lane's turn of the group
+            const int x = grp * 8 + lo;
+            const int turn = tshift | ((x & 1) << 1) | (((x >> 1) & 1) << 2) | (((x >> 2) & 1) << 4) | (((x >> 3) & 1) << 5);
+            const double r = (keep > 0.0) ? base + log(keep) : (double)CNF2_MINFACTOR_F - factor;
+            if (full) full[turn * 8 + s] = r;
+            if (lse) {
+                // log-sum-exp over the admissible shift modes (cnF2freq.cpp:5802-5812), lanes of equal lo across chains
+                const double rv = s_ok ? r : -INFINITY;
+                double mx = fmax(rv, __shfl_xor(rv, 8));
+                mx = fmax(mx, __shfl_xor(mx, 16));
+                mx = fmax(mx, __shfl_xor(mx, 32));
+                mx = fmax(mx, (double)CNF2_MINFACTOR_F);
+                double ex = s_ok ? exp(r - mx) : 0.0;
+                ex += __shfl_xor(ex, 8);
+                ex += __shfl_xor(ex, 16);
+                ex += __shfl_xor(ex, 32);
+                if (s == 0) lse[turn] = mx + log(ex);
+            }
+        }
+    }
+}
+void launch_turn_rows(const TurnParams& q, hipStream_t stream)
+{
+    dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(turn_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 
 int fb_fast_blocks_per_cu()

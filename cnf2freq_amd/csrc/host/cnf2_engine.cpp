@@ -88,6 +88,8 @@ void Engine::postmarkerdata(int indcount)
     std::vector<int32_t> recs;
     for (int r = 0; r < R; r++)
         if (in_scope(r)) recs.push_back(r);
+    T = Tables();     // the upload tables are not needed any more (large runs)
+    T.dous.assign(P.dous.begin(), P.dous.end());
     const unsigned char UNKNOWN = 0, SEXMARKER = 9;
     typedef std::map<int, std::pair<int, double>> ValMap;     // allele value -> (supporting count, product of odds)
     int any, anyrem;
@@ -135,77 +137,102 @@ void Engine::postmarkerdata(int indcount)
         push_rows();
         std::vector<uint8_t> ok(recs.size() * (size_t)M * 2);
         if (!recs.empty()) check(cnf2_fixparents_scan(ctx, recs.data(), (int)recs.size(), ok.data()), "cnf2_fixparents_scan");
-        std::vector<std::vector<ValMap>> vals(R);
-        for (int r : recs) vals[r].resize(M);
+        // what fixparents does to the individual itself: no admissible interpretation at all clears the genotype
+        std::vector<size_t> qof(R, (size_t)-1);               // record -> position in recs
+        for (size_t q = 0; q < recs.size(); q++) qof[recs[q]] = q;
         for (size_t q = 0; q < recs.size(); q++) {
-            const int r = recs[q];
-            Individual& I = P.inds[r];
-            for (int k = 0; k < 2; k++)
-                if (I.pars[k] >= 0 && vals[I.pars[k]].empty()) vals[I.pars[k]].resize(M);
-            for (int g = 0; g < M; g++) {
-                const bool ok0 = ok[(q * M + g) * 2] != 0, ok1 = ok[(q * M + g) * 2 + 1] != 0;
-                if (!ok0 && !ok1) {
+            Individual& I = P.inds[recs[q]];
+            for (int g = 0; g < M; g++)
+                if (!ok[(q * M + g) * 2] && !ok[(q * M + g) * 2 + 1]) {
                     fprintf(stderr, "Clearing %d:%d (was %d,%d)\n", I.n, g, I.allele[g * 2], I.allele[g * 2 + 1]);
                     I.allele[g * 2] = I.allele[g * 2 + 1] = UNKNOWN;
                     I.sure[g * 2] = I.sure[g * 2 + 1] = 0.0;
                 }
+        }
+        // ... and to its parents: an interpretation that stands alone hands the allele on that side to the parent's
+        // markervals (value -> count, product of the children's error odds).  Gathered per parent from its children in
+        // ascending order -- the order in which the reference's loop visits them -- and only where it is consumed
+        // (markers at which the parent lacks an allele), so nothing of size individuals x markers is held.
+        std::vector<std::vector<std::pair<int, int>>> kids(R);      // (child record, which parent slot of the child)
+        for (int r : recs)
+            for (int k = 0; k < 2; k++)
+                if (P.inds[r].pars[k] >= 0) kids[P.inds[r].pars[k]].push_back(std::make_pair(r, k));
+        auto gather = [&](int r, int g, ValMap& vm) {
+            for (auto& ck : kids[r]) {
+                const Individual& K = P.inds[ck.first];
+                const size_t      q = qof[ck.first];
+                const bool ok0 = ok[(q * M + g) * 2] != 0, ok1 = ok[(q * M + g) * 2 + 1] != 0;
                 if (ok0 == ok1) continue;                      // only an interpretation that stands alone is passed on
                 const int flag2 = ok1 ? 1 : 0;
-                for (int k = 0; k < 2; k++) {
-                    if (I.pars[k] < 0) continue;
-                    const int u = (k ^ flag2) & 1;
-                    const int value = I.allele[g * 2 + u];
-                    if (value == UNKNOWN) continue;
-                    ValMap& vm = vals[I.pars[k]][g];
-                    int     oldcount = 0;
-                    double  oldodds = 1;
-                    auto it = vm.find(value);
-                    if (it != vm.end()) {
-                        oldcount = it->second.first;
-                        oldodds  = it->second.second;
-                    }
-                    double probit = I.sure[g * 2] + I.sure[g * 2 + 1];
-                    probit /= (1 - probit);
-                    vm[value] = std::make_pair(oldcount + 1, oldodds * probit);
+                const int u = (ck.second ^ flag2) & 1;
+                const int value = K.allele[g * 2 + u];
+                if (value == UNKNOWN) continue;
+                int    oldcount = 0;
+                double oldodds = 1;
+                auto it = vm.find(value);
+                if (it != vm.end()) {
+                    oldcount = it->second.first;
+                    oldodds  = it->second.second;
                 }
+                double probit = K.sure[g * 2] + K.sure[g * 2 + 1];
+                probit /= (1 - probit);
+                vm[value] = std::make_pair(oldcount + 1, oldodds * probit);
             }
-        }
-        // corrections (cnF2freq.cpp:3281-3366, latephase is never set)
+        };
+        // corrections (cnF2freq.cpp:3281-3366, latephase is never set).  The contributions were all made before this
+        // loop starts in the reference; a correction below changes a child's alleles only after its parents (lower or
+        // higher numbers alike) have been given the old ones, so the children's state is frozen first.
         any = 0;
         anyrem = 0;
+        struct Fix { int r, g; uint8_t a0, a1; double s0, s1; };
+        std::vector<Fix> fixes;
         for (int r : recs) {
             Individual& I = P.inds[r];
-            if (vals[r].empty()) continue;
             for (int g = 0; g < M; g++) {
-                ValMap&   vm = vals[r][g];
                 const int known = (I.allele[g * 2] != UNKNOWN) + (I.allele[g * 2 + 1] != UNKNOWN);
-                const int oldany = any;
                 if (known == 2) continue;
+                ValMap vm;
+                gather(r, g, vm);
                 vm.erase(UNKNOWN);
                 if (I.allele[g * 2] != UNKNOWN) vm.insert(std::make_pair((int)I.allele[g * 2], std::make_pair(children_[r], I.sure[g * 2])));
                 if (I.allele[g * 2 + 1] != UNKNOWN)
                     vm.insert(std::make_pair((int)I.allele[g * 2 + 1], std::make_pair(children_[r], I.sure[g * 2 + 1])));
                 if (vm.size() >= 3) fprintf(stderr, "Error, too many matches: %d\t%d\n", I.n, g);
+                Fix fx = {r, g, I.allele[g * 2], I.allele[g * 2 + 1], I.sure[g * 2], I.sure[g * 2 + 1]};
+                bool changed = false;
                 if (vm.size() == 2) {
                     auto a = vm.begin(), b = ++vm.begin();
                     const int knowncount = a->second.first + b->second.first;
-                    I.allele[g * 2]     = (uint8_t)a->first;
-                    I.allele[g * 2 + 1] = (uint8_t)b->first;
-                    I.sure[g * 2]       = sureval_from(knowncount, a->second.first, a->second.second);
-                    I.sure[g * 2 + 1]   = sureval_from(knowncount, b->second.first, b->second.second);
-                    any++;
+                    fx.a0 = (uint8_t)a->first;
+                    fx.a1 = (uint8_t)b->first;
+                    fx.s0 = sureval_from(knowncount, a->second.first, a->second.second);
+                    fx.s1 = sureval_from(knowncount, b->second.first, b->second.second);
+                    changed = true;
                 } else if (vm.size() == 1 && known == 0) {
-                    any++;
                     auto a = vm.begin();
-                    I.allele[g * 2]     = (uint8_t)a->first;
-                    I.allele[g * 2 + 1] = UNKNOWN;
-                    I.sure[g * 2]       = sureval_from(a->second.first, a->second.first, a->second.second);
-                    I.sure[g * 2 + 1]   = 0.0;
+                    fx.a0 = (uint8_t)a->first;
+                    fx.a1 = UNKNOWN;
+                    fx.s0 = sureval_from(a->second.first, a->second.first, a->second.second);
+                    fx.s1 = 0.0;
+                    changed = true;
                 }
-                if (any != oldany && !opt.quiet)
-                    printf("Correction at %d, marker %d (%d;%d) (%lf;%lf)\n", I.n, g, I.allele[g * 2], I.allele[g * 2 + 1],
-                           I.sure[g * 2], I.sure[g * 2 + 1]);
+                if (changed) {
+                    any++;
+                    fixes.push_back(fx);
+                    if (!opt.quiet)
+                        printf("Correction at %d, marker %d (%d;%d) (%lf;%lf)\n", I.n, g, fx.a0, fx.a1, fx.s0, fx.s1);
+                }
             }
+        }
+        for (const Fix& fx : fixes) {
+            Individual& I = P.inds[fx.r];
+            I.allele[fx.g * 2] = fx.a0;
+            I.allele[fx.g * 2 + 1] = fx.a1;
+            I.sure[fx.g * 2] = fx.s0;
+            I.sure[fx.g * 2 + 1] = fx.s1;
+        }
+        for (int r : recs) {
+            Individual& I = P.inds[r];
             for (int g = 0; g < M; g++)
                 if (I.allele[g * 2] == SEXMARKER) std::swap(I.allele[g * 2], I.allele[g * 2 + 1]);
         }

@@ -191,6 +191,19 @@ int cnf2_sweep_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32
                           double *loglik_out, double *dosage_out, double *infprobs, double *haplobase,
                           double *haplocount, double *homozyg, uint32_t flags);
 
+/* Batched turn scan (HOT LOOP 3; cnF2freq.cpp:5686-5752 with aroundturner 498-554): for every
+ * analysed individual in [ind_begin, ind_end) and every marker,
+ *   rawervals_out [n][M][128][8]  doanalyze<aroundturner>(turn, classicstop(q, -1)) - factor for every turn and shift mode,
+ *                                 unmasked like cnf2_turn_scan (the caller applies flag2ignore / shiftignore), and / or
+ *   turn_lse_out  [n][M][128]     per turn the log-sum-exp of those values over the admissible shift modes: the quantity
+ *                                 the clause weights are made of (computew, cnF2freq.cpp:5800-5817: weight(turn) =
+ *                                 (lse[turn] - lse[0] * descendants) * descendants).
+ * Either pointer may be NULL.  Host buffers are staged through one device buffer of the full size (9 KB per
+ * individual x marker); with CNF2_OUT_DEVICE they are device pointers and only the batch buffer is allocated.
+ * The sweep kernels run in their turn-scan instantiation; all individuals and chromosomes in batched launches. */
+int cnf2_sweep_turn_scan(cnf2_ctx *ctx, int ind_begin, int ind_end, double *rawervals_out, double *turn_lse_out,
+                         uint32_t flags);
+
 /* Pre-processing user of the emission (parity level): individ::addvariance
  * (cnF2freq.cpp:1489-1558, called by postmarkerdata for every marker, cnF2freq.cpp:3373-3389) for one analysed
  * individual and chromosome: var_out[mc] = variances[marker], NaN where the reference leaves the entry alone

@@ -771,3 +771,55 @@ def test_batched_accumulate_rows_equal_the_per_individual_hooks(capi):
         np.testing.assert_allclose(got["infprobs"][r], inf[:, k] / self0[:, None, None], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(got["homozyg"][0], hz / self0[:, None], rtol=1e-9, atol=1e-13)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_batched_turn_scan_matches_reference(capi, case):
+    """cnf2_sweep_turn_scan (every individual and marker in batched launches, alpha / beta straight from the sweep's
+    registers) against the reference's rawervals (goldens G5) and, at every marker, against the per-individual hook
+    that reads the reference-layout store."""
+    ped, z = load_golden(case)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    raw, lse = ctx.sweep_turn_scan()
+    for j in range(len(ped.dous)):
+        if not z["ok"][j]:
+            continue
+        for ti, m in enumerate(z["turn_markers"]):
+            want = z["rawervals"][j, ti]
+            live = ~np.isnan(want)
+            np.testing.assert_allclose(raw[j, int(m)][live], want[live], rtol=1e-9, atol=1e-8)
+        rows = ctx.turn_scan_rows(j, 0)
+        fin = np.abs(rows) < 1e14
+        np.testing.assert_allclose(raw[j][fin], rows[fin], rtol=1e-9, atol=1e-8)
+        # the reduced form: log-sum-exp over the admissible modes, as computew forms it (cnF2freq.cpp:5800-5812)
+        w = ctx.window_info(j)
+        s_ok = np.array([not (s & w["shiftignore"]) and s < (8 if ped.gen[ped.dous[j]] >= 2 else 2) for s in range(8)])
+        r = np.where(s_ok[None, None, :], raw[j], -np.inf)
+        mx = np.maximum(r.max(axis=2), capi.MINFACTOR)
+        want_lse = mx + np.log(np.exp(r - mx[:, :, None]).sum(axis=2))
+        np.testing.assert_allclose(lse[j], want_lse, rtol=1e-10, atol=1e-9)
+    ctx.close()
+
+
+def test_batched_turn_scan_on_tied_windows_and_chromosomes(capi):
+    """Same on an advanced intercross (tied windows: general kernel) over two chromosomes, against the oracle."""
+    ped = synth.make_ail(4, 6, 3, 7, 2, seed=5, chrom_cm=20.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    raw, _ = ctx.sweep_turn_scan(lse=False)
+    o = oracle_ped(ped)
+    checked = 0
+    for j, ind in enumerate(ped.dous):
+        gen = int(ped.gen[ind])
+        for c in range(2):
+            first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+            if not o.sweep_ind(int(ind), gen, first=first, last=last, mode=2)["ok"]:
+                continue
+            for m in (first, last):
+                want = o.turn_scan(int(ind), m, gen, first=first, last=last)
+                live = ~np.isnan(want)
+                np.testing.assert_allclose(raw[j, m][live], want[live], rtol=1e-9, atol=1e-8)
+                checked += 1
+    assert checked > 10
+    ctx.close()
