@@ -1194,6 +1194,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
             HIP_TRY(ctx, hipGetLastError());
             q.kp     = p;
             q.n_jobs = (int)nb;
+            q.scaled_transitions = (pass == 0);
             launch_turn_rows(q, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
         }

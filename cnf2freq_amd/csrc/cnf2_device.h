@@ -124,6 +124,7 @@ void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream);
 struct TurnParams {
     KernelParams kp;
     int          n_jobs, max_len;
+    int          scaled_transitions;   // the batch came from the fast kernel (log-likelihoods include chrom_logk)
     double*      rawervals;   // [n_ind][n_markers][128][8] or NULL
     double*      turn_lse;    // [n_ind][n_markers][128] or NULL
 };

@@ -2456,7 +2456,9 @@ __global__ __launch_bounds__(CNF2_BLOCK) void turn_rows_kernel(TurnParams q)
     const Job jb = p.jobs[job];
     if (ml >= jb.last - jb.first + 1) return;
     const int    m = jb.first + ml;
-    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
+    // the fast kernel's butterflies drop a constant per gap: its reported log-likelihood carries the chromosome's sum of
+    // their logarithms, the stored alpha / beta do not
+    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] - (q.scaled_transitions ? p.chrom_logk[jb.chrom] : 0.0);
     const Window w = p.windows[jb.ind];
     const int s = lane >> 3, lo = state_lo(lane);
     const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 1040;

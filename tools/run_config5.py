@@ -44,7 +44,7 @@ s1 = run.state()
 t_pull = time.time() - t
 free = (s0["hw"] > 0) & (s0["hw"] < 1)
 out = {
-    "config": "BASELINE config 5: outbred 3-generation, 20% missing, %d analysed of %d individuals, %d markers, %d iterations, 1 GPU"
+    "config": "BASELINE config 5: outbred 3-generation, 20%% missing, %d analysed of %d individuals, %d markers, %d iterations, 1 GPU"
               % (n, R, M, iters),
     "units_per_iteration": n * M,
     "upload_s": t_up, "postmarkerdata_s": t_pm, "iteration_s_mean": float(np.mean(t_it)), "iteration_s_first": t_it[0],
