@@ -53,6 +53,17 @@ ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr())
 ctx.sync()
 t_sweep = time.time() - t
 print("sweep              %.3f s  %.3g units/s" % (t_sweep, units / t_sweep), flush=True)
+# batched turn scan (HOT LOOP 3) on the first individuals: per-turn log-sum-exp to a device buffer (1 KB per unit)
+nt = min(n, 1000)
+lse = torch.empty((nt, M, 128), dtype=f64, device=dev)
+for rep in range(2):
+    t = time.time()
+    ctx._chk(ctx.L.cnf2_sweep_turn_scan(ctx.h, 0, nt, None, C.c_void_p(lse.data_ptr()), capi.OUT_DEVICE), "cnf2_sweep_turn_scan")
+    ctx.sync()
+    t_turn = time.time() - t
+print("turn scan          %.3f s for %d individuals  %.3g units/s (%.1f x sweep per unit)   lse[0,0,0]=%.6f"
+      % (t_turn, nt, nt * M / t_turn, (t_turn / (nt * M)) / (t_sweep / units), float(lse[0, 0, 0].item())), flush=True)
+del lse
 sf = 0.013
 for it in range(iters):
     t = time.time()
