@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CNF2HIP_LIB: another build of the same library (kernel A/B timing); still the HIP path, never a fallback
 LIB_PATH = os.environ.get("CNF2HIP_LIB") or os.path.join(_HERE, "libcnf2hip.so")
 
-OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP = 1, 2, 4, 8, 16, 32, 64, 128
+OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP, XPOSE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -174,14 +174,14 @@ class Context:
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
-              merge_modes=False):
+              merge_modes=False, xpose=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
         loglik = np.zeros((n, self.n_chrom))
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
         flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
-                 | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0))
+                 | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
         return dict(factors=factors, loglik=loglik, dosage=dos)

@@ -674,7 +674,8 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     }
     if (n_fast > 0) {
         int gf = (int)((n_fast + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-        launch_fb_fast(p, gf < grid_fast ? gf : grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
+        if ((flags & CNF2_XPOSE) && !(flags & CNF2_FULL_SPILL)) launch_fb_fast_xpose(p, gf < grid_fast ? gf : grid_fast, ctx->stream);
+        else launch_fb_fast(p, gf < grid_fast ? gf : grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_general > 0) {

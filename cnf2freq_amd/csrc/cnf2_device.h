@@ -149,6 +149,7 @@ void launch_infprobs_rows(const Stage2Params& q, uint32_t flags, double* out, hi
 void launch_addvariance(const KernelParams& p, int first, int len, double* out, hipStream_t stream);
 void launch_fb(const KernelParams& p, int grid, bool debug_store, hipStream_t stream);
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream);
+void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream);
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
                       hipStream_t stream);

@@ -197,6 +197,55 @@ __device__ __forceinline__ void transition_scaled(double (&a)[8], double t0, dou
     }
 }
 
+// The three butterflies on the state bits that currently sit in the registers (bit 0 of the triple belongs to a
+// parent's meiosis: genrec[1], the other two to grandparental ones: genrec[0]; settings.h:23).
+__device__ __forceinline__ void register_stages(double (&a)[8], double t0, double t1)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const double x = a[j], y = a[j + 1];
+        a[j]     = fma(t1, y, x);
+        a[j + 1] = fma(t1, x, y);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j & 2) continue;
+        const double x = a[j], y = a[j + 2];
+        a[j]     = fma(t0, y, x);
+        a[j + 2] = fma(t0, x, y);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double x = a[j], y = a[j + 4];
+        a[j]     = fma(t0, y, x);
+        a[j + 4] = fma(t0, x, y);
+    }
+}
+
+// Transposing form of transition_scaled (CNF2_XPOSE variant of the fast kernel): instead of exchanging the three
+// lane-held state bits by DPP (48 v_mov_dpp per transition, a quarter of the kernel's VALU work), the wave swaps
+// which triple of state bits sits in the lanes: register stages on the triple held in registers, an 8 x 8 transpose
+// of every chain's (lane, register) block through LDS (8 ds_write_b64 + 8 ds_read_b64, no VALU slot), register
+// stages on the other triple.  The layout therefore alternates from marker to marker: even local markers keep state
+// bits 0-2 in the lanes (as the spill rows and the table reads of the DPP variant assume), odd ones bits 3-5.
+// xb: this wave's 64 x XPOSE_RS doubles.  Row stride 9 spreads the eight chains over the LDS banks.
+#define XPOSE_RS 9
+__device__ __forceinline__ void transition_xpose(double (&a)[8], double t0, double t1, double* xb, int lane)
+{
+    register_stages(a, t0, t1);
+    const int s8 = lane & 56, l = lane & 7;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // earlier reads of xb are done
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; j++) xb[(s8 + j) * XPOSE_RS + l] = a[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = xb[(s8 + l) * XPOSE_RS + j];
+    register_stages(a, t0, t1);
+}
+
 // ------------------------------------------------------------------ per-job lane state
 struct LaneCtx {
     LaneJob L;            // producer role
@@ -746,6 +795,18 @@ __device__ __forceinline__ void emission_from_row(const double* row, const FastC
     for (int j = 0; j < 8; j++) e[j] = cA0 * B0[j] + cA1 * B1[j];
 }
 
+// The same in the transposed layout of an odd marker (XPOSE variant): the lane holds state bits 3-5 (its low lane bits
+// index the B half of the table), the registers state bits 0-2 (the A half).
+__device__ __forceinline__ void emission_from_row_t(const double* row, const FastCtx& c, double (&e)[8], double k = 1.0)
+{
+    const double cB0 = row[TAB_C + 0 + c.s0] * row[(1 << 5) | (0 << 4) | (c.s2 << 3) | c.lo] * k;
+    const double cB1 = row[TAB_C + 2 + c.s0] * row[(1 << 5) | (1 << 4) | (c.s2 << 3) | c.lo] * k;
+    const double* A0 = row + ((0 << 5) | (0 << 4) | (c.s1 << 3));
+    const double* A1 = row + ((0 << 5) | (1 << 4) | (c.s1 << 3));
+#pragma unroll
+    for (int j = 0; j < 8; j++) e[j] = cB0 * A0[j] + cB1 * A1[j];
+}
+
 // Running state of the backward pass of one lane (kept in one struct so that the per-marker body can be
 // instantiated for even and odd markers without a merge of differently-defined values between them).
 struct BwdState {
@@ -761,20 +822,23 @@ struct BwdState {
 // HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
 // spill traffic for ~15 % more arithmetic.
-template <bool HALF, int STOREW = 0>
+template <bool HALF, int STOREW = 0, bool XPOSE = false>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
+    static_assert(!XPOSE || (HALF && STOREW == 0), "the transposing variant exists for the plain half-spill sweep");
     // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
     // per lane and k), then [chain][2] = reciprocal normaliser of the (even) marker and, HALF only, of
     // an odd last marker.
     constexpr int ROW = 528;
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
+    __shared__ __attribute__((aligned(16))) double xlds[XPOSE ? CNF2_WAVES_PER_BLOCK : 1][XPOSE ? 64 * XPOSE_RS : 2];
 
     const int lane  = threadIdx.x & 63;
     const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
     const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
     double*   tab   = lds[wib];
+    double*   xb    = xlds[XPOSE ? wib : 0];
     double*   spill = p.spill + (size_t)wave * p.spill_stride;
 
     for (int job = wave; job < p.n_jobs; job += nwave) {
@@ -800,7 +864,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
         c.s2 = (s >> 2) & 1;
-        c.lo = state_lo(lane);
+        c.lo = XPOSE ? (lane & 7) : state_lo(lane);   // no DPP butterflies in the transposing variant: plain order
         c.active = !(s & w.shiftignore) && s < w.shiftend;
         const int first = jb.first, last = jb.last;
         const int ntile = (last - first + 8) >> 3;
@@ -823,7 +887,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         auto fwd_step = [&](auto odd_tag, const double* row, int m) {
             constexpr bool ODD = decltype(odd_tag)::value;
             double         e[8];
-            emission_from_row(row, c, e, pend);
+            if (XPOSE && ODD) emission_from_row_t(row, c, e, pend);
+            else emission_from_row(row, c, e, pend);
             const double2 r  = *(const double2*)(row + TAB_T);
             const int     ml = m - first;
             double*       sp = spill + (size_t)(HALF ? (ml >> 1) : ml) * ROW;
@@ -853,7 +918,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
                 if (c.lo == 0) sp[512 + 2 * s + (ODD ? 1 : 0)] = inv;
             }
-            if (m < last) transition_scaled(a, r.x, r.y);
+            if (m < last) {
+                if (XPOSE) transition_xpose(a, r.x, r.y, xb, lane);
+                else transition_scaled(a, r.x, r.y);
+            }
         };
         RawSlots raw;
         load_raw<0>(p, c, first, first, last, &raw);
@@ -953,7 +1021,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 for (int j = 0; j < 8; j++) wj[j] = S.am[j] * ep[j];
                 // the normaliser inv(m-1) is a per-chain scalar and everything below is linear in wj:
                 // it is applied to the three class sums (`scale`) instead of to the eight states
-                transition_scaled(wj, r_m.x, r_m.y);
+                if (XPOSE) transition_xpose(wj, r_m.x, r_m.y, xb, lane);
+                else transition_scaled(wj, r_m.x, r_m.y);
                 if (STOREW == 2) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) aw[j] = wj[j];
@@ -986,9 +1055,13 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
 #pragma unroll
             for (int f = 0; f < 2; f++) {
-                const int     ia = (0 << 5) | (f << 4) | (c.s1 << 3) | c.lo;
-                const double* Br = row + TAB_R + ((1 << 5) | (f << 4) | (c.s2 << 3));
-                const double* B1 = row + TAB_2 + ((1 << 5) | (f << 4) | (c.s2 << 3));
+                // the lane's own line (its low bits index that half of the tables) and the line held in the registers:
+                // A / B as printed, B / A in the transposed layout of an odd marker (n_a1 and n_b1 then swap roles,
+                // which the class sums below do not notice: they use n_a1 + n_b1)
+                constexpr bool T = XPOSE && ODD;
+                const int     ia = ((T ? 1 : 0) << 5) | (f << 4) | ((T ? c.s2 : c.s1) << 3) | c.lo;
+                const double* Br = row + TAB_R + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
+                const double* B1 = row + TAB_2 + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
                 const double  cf = row[TAB_C + f * 2 + c.s0];
                 const double  av = cf * row[TAB_R + ia], a1 = cf * row[TAB_2 + ia];
                 double        sb = 0.0, sb1 = 0.0;
@@ -1019,7 +1092,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // this marker's own emission is only needed for the beta step: formed here, after the sums, so
             // that it does not occupy registers across them
             double e[8];
-            emission_from_row(row, c, e);
+            if (XPOSE && ODD) emission_from_row_t(row, c, e);
+            else emission_from_row(row, c, e);
             if (STOREW == 2) {
                 // turn-scan mode: A = alphaminus e and B = beta as held here, with the log2 of the scales that make them
                 // absolute (alphaminus: Fpre, and the stored normaliser of the even neighbour for a rebuilt odd marker)
@@ -1049,7 +1123,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // (deferring this normaliser like the forward one was measured slower here: the row scale and the
             // emission of the next step would both wait for the reciprocal)
             if (!HALF || !ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
-            transition_scaled(S.b, r_m.x, r_m.y);
+            if (XPOSE) transition_xpose(S.b, r_m.x, r_m.y, xb, lane);
+            else transition_scaled(S.b, r_m.x, r_m.y);
         };
         load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
@@ -2406,6 +2481,10 @@ void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
     hipLaunchKernelGGL(fb_packed_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
+void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_fast_kernel<true, 0, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream)
 {
     if (half_spill) hipLaunchKernelGGL(fb_fast_kernel<true>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);

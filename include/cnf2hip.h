@@ -60,7 +60,10 @@ enum {
                                     Ignored together with CNF2_FULL_SPILL. */
     CNF2_ACC_DEVICE   = 1u << 6, /* cnf2_sweep_accumulate: the four accumulator pointers are device pointers owned by the
                                     caller (a multi-GPU driver all-reduces them in place) */
-    CNF2_ACC_KEEP     = 1u << 7  /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
+    CNF2_ACC_KEEP     = 1u << 7, /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
+    CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
+                                    registers by a transpose through LDS instead of being exchanged by DPP moves (same
+                                    results to rounding; A/B switch while the variant is evaluated) */
 };
 
 typedef struct cnf2_ctx cnf2_ctx;

@@ -823,3 +823,34 @@ def test_batched_turn_scan_on_tied_windows_and_chromosomes(capi):
                 checked += 1
     assert checked > 10
     ctx.close()
+
+
+def test_transposing_sweep_variant_equals_the_dpp_variant(capi):
+    """CNF2_XPOSE: the fast kernel with its three lane-held state bits brought into registers by a transpose through
+    LDS instead of DPP exchanges (the layout alternates from marker to marker).  Same arithmetic in another order of
+    lanes: results equal to rounding.  F2 (single-allele producer shortcuts), outbred with missing data and random
+    weights, ragged chromosomes (lengths 1, even, odd), and against the oracle."""
+    f2 = synth.make_f2(9, 21, 1, seed=9, chrom_cm=30.0, missing=0.15)
+    f2.chromstarts = np.array([0, 1, 9, 22], np.int32)
+    f2.pos = np.concatenate([[0.0], np.arange(8) * 0.9, np.arange(13) * 1.7])
+    out = synth.make_outbred3(3, 3, 33, 2, seed=12, missing=0.2, random_hw=True, random_sure=True)
+    for ped in (f2, out, synth.make_random_windows(40, 7, seed=91)):
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        for raw in (False, True):
+            a = ctx.sweep(raw=raw)
+            b = ctx.sweep(raw=raw, xpose=True)
+            np.testing.assert_allclose(b["factors"], a["factors"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(b["loglik"], a["loglik"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(b["dosage"], a["dosage"], rtol=1e-9, atol=1e-13)
+        ctx.close()
+    ctx = capi.Context(0)
+    ctx.upload(out)
+    got = ctx.sweep(xpose=True)
+    o = oracle_ped(out)
+    for c in range(2):
+        first, last = int(out.chromstarts[c]), int(out.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(out.dous, out.gen[out.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
