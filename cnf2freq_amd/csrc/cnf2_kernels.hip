@@ -617,6 +617,11 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 // LDS per wave: 8 markers x TAB_STRIDE doubles: [0,64) tot, [64,68) root weights c[f][s0],
 // and for the backward pass [72,136) restricted totals, [136,200) class-2 parts.
 // =====================================================================================
+#ifndef CNF2_RESCALE_MASK
+#define CNF2_RESCALE_MASK 7   /* half-spill sweep: rescale alpha / beta at markers whose local index has these bits clear
+                                 (7 = once per tile of 8 markers; measured +3.3 % over rescaling at every second marker) */
+#endif
+#define CNF2_RESCALE_GUARD 1e150 /* a normaliser below 1 / this makes the wave rescale at every second marker from there on */
 #define TAB_STRIDE 202   /* doubles per marker row: 16-B aligned rows, conflict-free producer stores */
 #define TAB_C 64
 #define TAB_T 68     /* double2: r/(1-r) of the gap carried by this row */
@@ -880,6 +885,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         int    expo = 0;
         bool   dead = false;
         double pend = 1.0;     // reciprocal normaliser not yet applied to a[] (folded into the next emission)
+        int    rmask = CNF2_RESCALE_MASK, bmask = CNF2_RESCALE_MASK;   // rescaling pattern of the forward / backward pass
         // One marker of the forward pass.  ODD (HALF only): nothing is spilled and, except at the last
         // marker of the chromosome, nothing is rescaled: two emission products in a row cannot underflow a
         // double.  A skipped step has normaliser 1 (the reference rescales at every marker,
@@ -906,17 +912,24 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #pragma unroll
             for (int j = 0; j < 8; j++) a[j] *= e[j];
             pend = 1.0;
-            if (!ODD || m == last) {
+            // HALF: the vectors are rescaled at every CNF2_RESCALE-th marker only (and at the last one): a few emission
+            // products in a row cannot underflow a double, and a skipped step simply has normaliser 1
+            const bool norm_here = !HALF || m == last || (!ODD && (ml & rmask) == 0);
+            if (norm_here) {
                 // reciprocal of this step's normaliser, per chain: stored so that the backward pass can
                 // rebuild the forward scale before each marker without a reduction (and redo the forward step)
                 double inv;
                 if (HALF) {
                     inv  = chain_normaliser(a, &mant, &expo, &dead);
                     pend = inv;
+                    // data that loses > 150 decades in one stretch: keep the vectors in range by rescaling densely
+                    if (__ballot(inv > CNF2_RESCALE_GUARD)) rmask = 1;
                 } else {
                     scale_chain(a, &mant, &expo, &dead, &inv);     // full spill: the stored rows are normalised at once
                 }
                 if (c.lo == 0) sp[512 + 2 * s + (ODD ? 1 : 0)] = inv;
+            } else if (!ODD) {
+                if (c.lo == 0) sp[512 + 2 * s] = 1.0;
             }
             if (m < last) {
                 if (XPOSE) transition_xpose(a, r.x, r.y, xb, lane);
@@ -1122,7 +1135,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             for (int j = 0; j < 8; j++) S.b[j] *= e[j];
             // (deferring this normaliser like the forward one was measured slower here: the row scale and the
             // emission of the next step would both wait for the reciprocal)
-            if (!HALF || !ODD) scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
+            if (!HALF || (!ODD && (ml & bmask) == 0)) {
+                const double bsum = scale_chain(S.b, &S.bmant, &S.bexpo, &S.bdead);
+                if (HALF && __ballot(bsum > 0.0 && bsum * CNF2_RESCALE_GUARD < 1.0)) bmask = 1;
+            }
             if (XPOSE) transition_xpose(S.b, r_m.x, r_m.y, xb, lane);
             else transition_scaled(S.b, r_m.x, r_m.y);
         };

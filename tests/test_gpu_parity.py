@@ -854,3 +854,27 @@ def test_transposing_sweep_variant_equals_the_dpp_variant(capi):
         np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
+
+
+def test_sparse_rescaling_guard_on_data_that_loses_many_decades(capi):
+    """The half-spill sweep rescales its vectors once per tile of 8 markers; a stretch of data that loses more than
+    150 decades between two rescalings switches the wave to dense rescaling.  Genotypes that contradict the pedigree
+    with tiny certainties (every marker costs ~1e-24) against the oracle, which rescales at every marker like the
+    reference (cnF2freq.cpp:1664-1668)."""
+    ped = synth.make_outbred3(2, 2, 60, 1, seed=5, missing=0.0)
+    ped.allele = ped.allele.copy()
+    ped.sure = ped.sure.copy()
+    kid = int(ped.dous[0])
+    p0, p1 = int(ped.par[kid, 0]), int(ped.par[kid, 1])
+    for r, al in ((kid, (2, 2)), (p0, (1, 1)), (p1, (1, 1))):
+        ped.allele[ped.row_of[r], 10:50] = al
+        ped.sure[ped.row_of[r], 10:50] = 1e-6
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    want = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    assert want["factor"][0] < -400, "the fixture should lose hundreds of log units"
+    np.testing.assert_allclose(got["loglik"][:, 0], want["factor"], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-6, atol=1e-10)
+    ctx.close()
