@@ -19,6 +19,7 @@ fams = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
 snps = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 chroms = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+budget = float(sys.argv[5]) if len(sys.argv) > 5 else 1e9      # wall-clock seconds after which no further iteration starts
 t0 = time.time()
 ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 n, M, R = len(ped.dous), ped.n_markers, ped.n_rec
@@ -34,6 +35,9 @@ s0 = run.state()
 locked = int(((s0["hw"] == 0) | (s0["hw"] == 1)).sum())
 t_it = []
 for it in range(iters):
+    if time.time() - t0 > budget:
+        print("wall-clock budget reached after %d iterations" % it, flush=True)
+        break
     t = time.time()
     run.iteration(None)
     t_it.append(time.time() - t)
@@ -45,8 +49,8 @@ t_pull = time.time() - t
 free = (s0["hw"] > 0) & (s0["hw"] < 1)
 out = {
     "config": "BASELINE config 5: outbred 3-generation, 20%% missing, %d analysed of %d individuals, %d markers, %d iterations, 1 GPU"
-              % (n, R, M, iters),
-    "units_per_iteration": n * M,
+              % (n, R, M, len(t_it)),
+    "iterations_requested": iters, "iterations_done": len(t_it), "units_per_iteration": n * M,
     "upload_s": t_up, "postmarkerdata_s": t_pm, "iteration_s_mean": float(np.mean(t_it)), "iteration_s_first": t_it[0],
     "iterations_total_s": float(np.sum(t_it)), "state_download_s": t_pull,
     "units_per_s_per_iteration": n * M / float(np.mean(t_it)),
