@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CNF2HIP_LIB: another build of the same library (kernel A/B timing); still the HIP path, never a fallback
 LIB_PATH = os.environ.get("CNF2HIP_LIB") or os.path.join(_HERE, "libcnf2hip.so")
 
-OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP, XPOSE = 1, 2, 4, 8, 16, 32, 64, 128, 256
+OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP, XPOSE, LOG_PATHS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -26,7 +26,7 @@ SYMBOLS = [
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
-    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_workspace_bytes", "cnf2_stream",
+    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
 
@@ -84,6 +84,7 @@ def load():
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
         L.cnf2_last_kernel_ms.argtypes = [vp, vp, i32]
+        L.cnf2_last_paths.argtypes = [vp, vp, i32]
         L.cnf2_workspace_bytes.argtypes = [vp]
         L.cnf2_workspace_bytes.restype = C.c_size_t
         L.cnf2_set_grid_reserve.argtypes = [vp, i32]
@@ -174,17 +175,23 @@ class Context:
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
-              merge_modes=False, xpose=False):
+              merge_modes=False, xpose=False, log_paths=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
         loglik = np.zeros((n, self.n_chrom))
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
         flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
-                 | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0))
+                 | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0)
+                 | (LOG_PATHS if log_paths else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
-        return dict(factors=factors, loglik=loglik, dosage=dos)
+        out = dict(factors=factors, loglik=loglik, dosage=dos)
+        if log_paths:
+            paths = np.zeros((n, self.n_chrom), np.int32)
+            self._chk(self.L.cnf2_last_paths(self.h, _p(paths), paths.size), "cnf2_last_paths")
+            out["paths"] = paths
+        return out
 
     def sweep_device(self, ind_begin, ind_end, d_factors, d_loglik, d_dosage, flags=0):
         """Device-pointer form (ints or None); only enqueues on the context's stream."""

@@ -89,6 +89,9 @@ struct cnf2_ctx {
     double * d_fw = nullptr, *d_ratio = nullptr;
     size_t   fw_cap = 0, ratio_cap = 0;
     int*     d_hits = nullptr;
+    int32_t* d_pathlog = nullptr;
+    size_t   pathlog_cap = 0;
+    int      pathlog_n = 0;
     Window*  d_scanwin = nullptr;
     size_t   scanwin_cap = 0;
     uint8_t* d_okout = nullptr;
@@ -211,6 +214,7 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_ratio);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_scanwin);
+    (void)hipFree(ctx->d_pathlog);
     (void)hipFree(ctx->d_okout);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -663,6 +667,12 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     p.dosage       = d_d;
     p.flags        = (want_dosage ? 0 : KP_NO_DOSAGE) | ((flags & CNF2_RAW_DOSAGE) ? KP_RAW_DOSAGE : 0) |
               ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
+    if (flags & CNF2_LOG_PATHS) {
+        if ((rc = ensure(ctx, &ctx->d_pathlog, &ctx->pathlog_cap, nl))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_pathlog, 0xff, nl * sizeof(int32_t), ctx->stream));
+        p.path_log     = ctx->d_pathlog;
+        ctx->pathlog_n = (int)nl;
+    }
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (n_packed > 0) {
@@ -699,6 +709,16 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
             HIP_TRY(ctx, hipMemcpyAsync(dosage_out, d_d, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return CNF2_OK;
+}
+
+int cnf2_last_paths(cnf2_ctx* ctx, int32_t* paths_out, int n)
+{
+    if (!ctx || !paths_out || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad path arguments");
+    if (!ctx->d_pathlog || n > ctx->pathlog_n) return fail(ctx, CNF2_ERR_STATE, "no sweep with CNF2_LOG_PATHS covers %d jobs", n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(paths_out, ctx->d_pathlog, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return CNF2_OK;
 }
 

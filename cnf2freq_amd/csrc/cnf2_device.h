@@ -65,7 +65,11 @@ struct KernelParams {
     // lane / register layout (lane = chain << 3 | l, registers 2k, 2k+1)
     double*        wbuf;
     size_t         wstride;      // markers per job slot
+    // which kernel / producer specialisation swept a job (tests): [n_ind][n_chrom], 0-3 = fast kernel with that `hom`
+    // class, 32 | homleaf = packed kernel, 64 = general kernel; NULL = not recorded
+    int32_t*       path_log;
 };
+enum { PATH_PACKED = 32, PATH_GENERAL = 64 };
 
 // Inputs of the batched HOT LOOP 2 kernel (acc_rows_kernel): the weights a STOREW sweep left for `n_jobs` jobs and
 // where the per-record accumulators live.  After every locus the reference scales homozyg, then moveinfprobs /

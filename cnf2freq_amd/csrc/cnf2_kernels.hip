@@ -403,6 +403,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
     for (int job = wave; job < p.n_jobs; job += nwave) {
         const Job    jb = p.jobs[job];
         const Window w  = p.windows[jb.ind];
+        if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = PATH_GENERAL;
         LaneCtx      c;
         make_lane(w, lane, &c.L);
         c.row_root   = w.row[0];
@@ -867,6 +868,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         }
         if (hom == 0 && w.flag2ignore == 0) hom = 3;
         hom = __builtin_amdgcn_readfirstlane(hom);
+        if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = hom;
         const int s = lane >> 3;
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
@@ -1268,6 +1270,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
         c.active = true;                                     // eligibility: shiftignore == 0, shiftend == 8
         const int first = pj.first, last = pj.last;
         const int ntile = (last - first + 2) >> 1;
+        if (p.path_log && (lane & 15) == 0) p.path_log[(size_t)ind * p.n_chrom + pj.chrom] = PATH_PACKED | pj.homleaf;
         double*   myrow0 = tab + cjob * TAB_STRIDE;          // this lane's job, marker 0 of the tile
         double*   myrow1 = myrow0 + 4 * TAB_STRIDE;
 

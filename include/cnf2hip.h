@@ -61,6 +61,7 @@ enum {
     CNF2_ACC_DEVICE   = 1u << 6, /* cnf2_sweep_accumulate: the four accumulator pointers are device pointers owned by the
                                     caller (a multi-GPU driver all-reduces them in place) */
     CNF2_ACC_KEEP     = 1u << 7, /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
+    CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same
                                     results to rounding; A/B switch while the variant is evaluated) */
@@ -259,6 +260,11 @@ int cnf2_selftest_lane_xor(cnf2_ctx *ctx, double *out384);
  * measured with hipEvents on the context's stream (kernel_ms[0] = forward-backward kernel),
  * and workspace bytes currently allocated on the device. */
 int    cnf2_last_kernel_ms(cnf2_ctx *ctx, float *kernel_ms, int n);
+/* After a cnf2_sweep with CNF2_LOG_PATHS: paths_out[n] (n = individuals of that sweep x chromosomes, [ind][chrom]) = which
+ * code swept the job: 0-3 the fast kernel with producer class 0 general / 1 both parents homozygous everywhere / 2 and the
+ * grandparents too / 3 complete window (restricted table = unrestricted); 32 | homleaf the merged-modes kernel; 64 the
+ * general kernel (tied windows).  Test support: the specialisations are exact shortcuts and must all be exercised. */
+int    cnf2_last_paths(cnf2_ctx *ctx, int32_t *paths_out, int n);
 size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
 void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
 /* The sweep kernels are persistent (one resident wave per job in flight) and normally fill every

@@ -878,3 +878,70 @@ def test_sparse_rescaling_guard_on_data_that_loses_many_decades(capi):
     np.testing.assert_allclose(got["loglik"][:, 0], want["factor"], rtol=1e-9, atol=1e-8)
     np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-6, atol=1e-10)
     ctx.close()
+
+
+def _four_founder_pedigree(n_kids, M, seed, empty_f1=True, empty_gp=False):
+    """n_kids analysed children of two F1 parents with four distinct, heterozygous grandparents (no ancestor in two
+    slots: no tie group).  empty_f1: the parents have no data (homozygous-everywhere blank rows); empty_gp: one
+    grandparent has no data either (its slot is restricted: flag2ignore != 0)."""
+    rs = np.random.RandomState(seed)
+    R = 6 + n_kids
+    par = np.full((R, 2), -1, np.int32)
+    gen = np.zeros(R, np.int32)
+    empty = np.zeros(R, np.uint8)
+    par[4], par[5] = (0, 1), (2, 3)
+    gen[4] = gen[5] = 1
+    for k in range(n_kids):
+        par[6 + k] = (4, 5)
+        gen[6 + k] = 2
+    allele = np.zeros((R + 1, M, 2), np.uint8)
+    allele[1:] = rs.choice([1, 2], size=(R, M, 2))
+    allele[1:5][:, :, 0], allele[1:5][:, :, 1] = 1, 2            # grandparents heterozygous everywhere
+    sure = np.where(allele != 0, 0.02, 0.0)
+    hw = np.full((R + 1, M), 0.5)
+    hw[1:] = 0.2 + 0.6 * rs.rand(R, M)
+    row_of = np.arange(1, R + 1, dtype=np.int32)
+    if empty_f1:
+        empty[4] = empty[5] = 1
+        row_of[4] = row_of[5] = 0
+    if empty_gp:
+        empty[3] = 1
+        row_of[3] = 0
+    pos = np.arange(M) * 1.5
+    ped = synth.Pedigree(["r%d" % i for i in range(R)], par, gen, empty, row_of, allele, sure, hw, pos,
+                         np.array([0, M], np.int32), np.arange(6, R, dtype=np.int32))
+    ped.founder_flags()
+    return ped
+
+
+def test_every_producer_specialisation_runs_and_is_exact(capi):
+    """The sweep picks, per job, a kernel and a table-producer specialisation from the data (exact shortcuts): each one
+    must be reached by some fixture (cnf2_last_paths says which code swept a job) and agree with the oracle."""
+    cases = [
+        ("fast kernel, general producer (hom 0): a restricted slot, parents with data",
+         _four_founder_pedigree(3, 9, 1, empty_f1=False, empty_gp=True), False, {0}),
+        ("fast kernel, parents homozygous everywhere (hom 1)", _four_founder_pedigree(3, 9, 2), False, {1}),
+        ("fast kernel, parents and grandparents homozygous everywhere (hom 2): the F2",
+         synth.make_f2(5, 9, 1, seed=3, chrom_cm=20.0, missing=0.1), False, {2}),
+        ("fast kernel, complete window (hom 3)", synth.make_outbred3(1, 3, 9, 1, seed=4, missing=0.0, random_hw=True), False, {3}),
+        ("merged-modes kernel, grandparents not homozygous (homleaf 0)", _four_founder_pedigree(5, 9, 5), True, {32, 1}),
+        ("merged-modes kernel, grandparents homozygous (homleaf 1)",
+         synth.make_f2(6, 9, 1, seed=6, chrom_cm=20.0, missing=0.1), True, {33, 2}),
+        ("general kernel: tied windows", synth.make_ail(4, 6, 3, 9, 1, seed=5, chrom_cm=20.0), False, {64, 3, 0}),
+    ]
+    for what, ped, merge, allowed in cases:
+        ctx = capi.Context(0)
+        ctx.upload(ped)
+        got = ctx.sweep(merge_modes=merge, log_paths=True)
+        paths = set(int(x) for x in got["paths"].ravel())
+        assert paths <= allowed and min(allowed) in paths or max(allowed) in paths, (what, paths)
+        if merge:
+            assert any(p >= 32 and p < 64 for p in paths), (what, paths)
+        elif 64 in allowed:
+            assert 64 in paths, (what, paths)
+        else:
+            assert paths == allowed, (what, paths)
+        want = oracle_ped(ped).sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+        np.testing.assert_allclose(got["factors"][:, 0], want["factors"], rtol=RTOL, atol=1e-8, err_msg=what)
+        np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-7, atol=1e-11, err_msg=what)
+        ctx.close()
