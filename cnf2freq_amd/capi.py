@@ -327,10 +327,11 @@ class Context:
         self._chk(self.L.cnf2_fixparents_scan(self.h, _p(recs), len(recs), _p(ok)), "cnf2_fixparents_scan")
         return ok
 
-    def variances(self, recs, ordered=True):
+    def variances(self, recs, ordered=True, brute=False):
         recs = np.ascontiguousarray(recs, np.int32)
         v = np.zeros((len(recs), self.n_markers))
-        self._chk(self.L.cnf2_variances(self.h, _p(recs), len(recs), 1 if ordered else 0, _p(v)), "cnf2_variances")
+        self._chk(self.L.cnf2_variances(self.h, _p(recs), len(recs), (1 if ordered else 0) | (2 if brute else 0), _p(v)),
+                  "cnf2_variances")
         return v
 
     def snapshot_priors(self, has_prior):

@@ -1444,6 +1444,8 @@ int cnf2_fixparents_scan(cnf2_ctx* ctx, const int32_t* recs, int n, uint8_t* ok_
     return CNF2_OK;
 }
 
+// ordered: bit 0 = founder flags as fixtrees has assigned them in ascending order; bit 1 = evaluate by brute force
+// (the 65 536 emission calls of the reference's loops) instead of the closed form -- cross-check only
 int cnf2_variances(cnf2_ctx* ctx, const int32_t* recs, int n, int ordered, double* var_out)
 {
     if (!ctx || !recs || !var_out || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad scan arguments");
@@ -1451,8 +1453,9 @@ int cnf2_variances(cnf2_ctx* ctx, const int32_t* recs, int n, int ordered, doubl
     if (n == 0) return CNF2_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t M = ctx->n_markers;
-    // in slabs: one block per (record, marker)
-    const int slab = 4096;
+    const bool brute = (ordered & 2) != 0;
+    ordered &= 1;
+    const int slab = brute ? 4096 : 65535;       // grid.y
     int rc;
     if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)(n < slab ? n : slab) * M))) return rc;
     for (int i0 = 0; i0 < n; i0 += slab) {
@@ -1461,7 +1464,8 @@ int cnf2_variances(cnf2_ctx* ctx, const int32_t* recs, int n, int ordered, doubl
         KernelParams p;
         base_params(ctx, &p);
         p.windows = ctx->d_scanwin;
-        launch_addvariance_batch(p, k, ctx->d_scratch, ctx->stream);
+        if (brute) launch_addvariance_batch(p, k, ctx->d_scratch, ctx->stream);
+        else launch_variance_closed(p, k, ctx->d_scratch, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(var_out + (size_t)i0 * M, ctx->d_scratch, (size_t)k * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

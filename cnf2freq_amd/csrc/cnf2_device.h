@@ -120,6 +120,7 @@ struct UpdateParams {
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
+void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream);

@@ -29,6 +29,7 @@
 #include "cnf2_accum.h"
 #include "cnf2_acctab.h"
 #include "cnf2_update.h"
+#include "cnf2_variance.h"
 
 namespace cnf2 {
 
@@ -2076,6 +2077,25 @@ void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(addvariance_kernel, dim3(p.n_markers, n_windows), dim3(256), 0, stream, p, 0, out);
+}
+
+// addvariance for window y of p.windows at every marker through its closed form (cnf2_variance.h): one thread per
+// (window, marker) instead of 65 536 emission calls.  out[y][m], NaN where the reference leaves the entry alone.
+__global__ __launch_bounds__(256) void variance_closed_kernel(KernelParams p, double* out)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= p.n_markers) return;
+    const Window w = p.windows[blockIdx.y];
+    Slot slot[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) slot[k] = load_slot(p, w.row[k] < 0 ? 0 : w.row[k], m);
+    bool         valid;
+    const double v = variance_closed(w, slot, &valid);
+    out[(size_t)blockIdx.y * p.n_markers + m] = valid ? v : nan("");
+}
+void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(variance_closed_kernel, dim3((p.n_markers + 255) / 256, n_windows), dim3(256), 0, stream, p, out);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -219,9 +219,11 @@ int cnf2_addvariance(cnf2_ctx *ctx, int ind, int chrom, double *var_out);
  *  cnf2_fixparents_scan  ok_out[n][M][2]: fixparents' admissibility test (cnF2freq.cpp:1411-1431): is any (state, path of
  *                        parity b) possible at the marker under shift mode 0 with CORRECTIONINFERENCE set, no founder flag
  *                        assigned yet (main() calls postmarkerdata before any fixtrees, cnF2freq.cpp:8083-8085)
- *  cnf2_variances        var_out[n][M] as cnf2_addvariance; ordered != 0: founder flags as fixtrees has assigned them when
- *                        the records are visited in ascending order (an ancestor's flag counts if its record index is not
- *                        above the record's own), else every flag. */
+ *  cnf2_variances        var_out[n][M] as cnf2_addvariance, through the closed form of cnf2_variance.h (the sums over states and
+ *                        paths factorise per line; one thread per record x marker).  ordered bit 0: founder flags as fixtrees
+ *                        has assigned them when the records are visited in ascending order (an ancestor's flag counts if its
+ *                        record index is not above the record's own), else every flag; bit 1: brute force like
+ *                        cnf2_addvariance (cross-check). */
 int cnf2_fixparents_scan(cnf2_ctx *ctx, const int32_t *recs, int n, uint8_t *ok_out);
 int cnf2_variances(cnf2_ctx *ctx, const int32_t *recs, int n, int ordered, double *var_out);
 

@@ -25,6 +25,7 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
 }
 
 #include "cnf2_update.h"
+#include "cnf2_variance.h"
 
 extern "C" {
 
@@ -279,6 +280,25 @@ int shim_acc_entries(int n_rec, const int32_t* par, const uint8_t* empty, const 
         acc_entry_paths(w, slot, e, combo, false, ar, out_paths + e * AK_COUNT);
     }
     return w.n_groups;
+}
+
+// closed form of addvariance (cnf2_variance.h) for record `rec` at `marker`; returns 0 when the entry is left alone
+int shim_variance(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const int32_t* row_of,
+                  const uint8_t* allele, const double* sure, const double* hw, int n_markers, int rec, int marker,
+                  double* out)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    Slot slot[7];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot[k] = unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    }
+    bool valid;
+    *out = variance_closed(w, slot, &valid);
+    return valid ? 1 : 0;
 }
 
 // ---- per-iteration updates (cnf2_update.h) ----

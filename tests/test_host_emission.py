@@ -300,3 +300,37 @@ def test_factored_table_entries_equal_the_path_walk(shim, seed):
                 np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300, equal_nan=True)
                 nan_seen += int(np.isnan(b).any())
     assert nan_seen > 0 or seed != 31
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.make_random_windows(40, 4, seed=61),
+    lambda: synth.make_outbred3(2, 2, 7, 1, seed=8, missing=0.25, random_hw=True, random_sure=True),
+    lambda: synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2),
+])
+def test_closed_form_variance_matches_addvariance(shim, maker):
+    """cnf2_variance.h (addvariance as a product of two per-line sums) against the oracle's restatement of the
+    reference's 65 536-call loops (cnF2freq.cpp:1489-1558), for EVERY record of the pedigree (postmarkerdata calls it
+    for everybody), incl. founders, empty individuals, missing parents and the sex-marker sentinel."""
+    ped = maker()
+    rs = np.random.RandomState(7)
+    hit = rs.rand(*ped.allele.shape[:2]) < 0.05
+    hit[0] = False
+    ped.allele = ped.allele.copy()
+    ped.allele[hit, 1] = 9
+    o = oracle_ped(ped)
+    seen_none = seen_val = 0
+    for rec in range(ped.n_rec):
+        f2i = o.fixtrees(rec).flag2ignore
+        for m in range(ped.n_markers):
+            want = o.addvariance(rec, m, f2i)
+            got = np.zeros(1)
+            ok = shim.shim_variance(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, rec, m, _p(got))
+            if want is None:
+                assert ok == 0
+                seen_none += 1
+            else:
+                assert ok == 1
+                # the value is a squared difference of two nearly equal sums: cancellation amplifies rounding
+                assert abs(got[0] - want) <= 1e-8 * abs(want) + 1e-18, (rec, m, got[0], want)
+                seen_val += 1
+    assert seen_val > 50
