@@ -139,32 +139,88 @@ CNF2_HD void acc_entry_paths(const Window& w, const Slot slot[7], int entry, int
     }
 }
 
+// What a probe of the line needs (line_terms() for a KNOWN incoming allele with zero error odds, the GENOSPROBE /
+// HOMOZYGOUS calls of cnF2freq.cpp:5519-5537): with zero odds every match term is just its base value, so the line's
+// base[fp] and tr[fp][fg] come out of a few products.  The "other grandparent" factors of a probe are the emission's
+// own (they do not see the incoming allele) and are not formed here.
+struct ProbeTerms {
+    double base[2];
+    double tr[2][2];
+};
+CNF2_HD void probe_terms(const LineCfg& c, const Slot& par, const Slot& tr, int value, ProbeTerms* T)
+{
+    T->base[0] = T->base[1] = 0.0;
+    T->tr[0][0] = T->tr[0][1] = T->tr[1][0] = T->tr[1][1] = 0.0;
+    if (!(c.par & SLOT_PRESENT)) {                           // 1 + secondval with secondval = 0
+        T->base[0]  = 1.0;
+        T->tr[0][0] = 1.0;
+        return;
+    }
+    if (c.par & SLOT_FOUNDER) {                              // the parent is the top of its line
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            T->base[f]  = 1.0;
+            T->tr[f][0] = probe_base(value, f ? par.a1 : par.a0, f ? par.s1 : par.s0) * phase_weight(par, f ^ c.firstpar ^ c.sp);
+        }
+        return;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        const double so = f ? par.s0 : par.s1;
+        double b = probe_base(value, f ? par.a1 : par.a0, f ? par.s1 : par.s0) * phase_weight(par, f ^ c.firstpar ^ c.sp);
+        if (so != 0.0) b *= (1.0 - so);
+        if (!(b != 0.0)) continue;                           // cnF2freq.cpp:1271: nothing below a zero base
+        T->base[f] = b;
+        if (c.tr & SLOT_PRESENT) {
+#pragma unroll
+            for (int fg = 0; fg < 2; fg++)
+                T->tr[f][fg] = probe_base(value, fg ? tr.a1 : tr.a0, fg ? tr.s1 : tr.s0) * phase_weight(tr, fg ^ c.bit_tr);
+        } else {
+            T->tr[f][0] = 1.0;
+        }
+    }
+}
+
 // Factored form of acc_entry_paths.  A path (fp, fgt, fgo) of the line has the emission term
 // base[fp] * ot[fp][fgo] * tr[fp][fgt]; its GENOS weight w_i = R_i lp_i / (R_0 lp_0 + R_1 lp_1) does not depend on the
 // other grandparent (the probe's "other" factor is the emission's own and cancels), so every sum over paths splits
 // into a sum over the other grandparent's alleles times a 2 x 2 sum over (fp, fgt).  Where a weight is 0 / 0 (no probe
 // is possible on a path the emission allows) the reference adds NaN to the HOMOZYGOUS sums but nothing to infprobs
-// (its "non-zero product" tests fail there): kept.
+// (its "non-zero product" tests fail there): kept.  Written without run-time array indices (everything is selected),
+// so that the device version keeps its state in registers.
 CNF2_HD void acc_entry(const Window& w, const Slot slot[7], int entry, int combo, bool no_ties, const AccRoot& ar,
                        double out[AK_COUNT])
 {
+#pragma unroll
     for (int k = 0; k < AK_COUNT; k++) out[k] = 0.0;
     const int  P = entry >> 5;
     const bool root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
     LaneJob    L;
     make_lane(w, entry, &L);
     const LineCfg& c = L.cfg;
-    const int   sp = 1 + 3 * P;
-    const Slot &par = slot[sp], &tr = slot[sp + 1 + c.firstpar], &ot = slot[sp + 1 + (c.firstpar ^ 1)];
-    LineTerms   TP[2];
-    for (int i = 0; i < 2; i++) line_terms(c, par, tr, ot, i + 1, 0.0, false, &TP[i]);
+    const Slot  par = P ? slot[4] : slot[1], gpa = P ? slot[5] : slot[2], gpb = P ? slot[6] : slot[3];
+    const Slot  tr = c.firstpar ? gpb : gpa, ot = c.firstpar ? gpa : gpb;
+    ProbeTerms  TP0, TP1;
+    probe_terms(c, par, tr, 1, &TP0);
+    probe_terms(c, par, tr, 2, &TP1);
     if (root_attop) {
         out[AK_R] = 1.0;
         const double den = ar.Rs[0][0] + ar.Rs[0][1];
-        for (int i = 0; i < 2; i++) {
-            const double lp = line_path_term(TP[i], 0, 0, 0);
-            out[AK_HZ + i] = P ? lp : (ar.Rs[0][i] * ar.Xo[i]) * lp / den;
+        // the all-zero path of a probe: base * other grandparent * traced grandparent.  The other grandparent's term
+        // (allele index 0 of both) does not depend on the incoming allele: formed once, as line_terms() forms it
+        double o00 = 1.0;
+        if ((c.par & SLOT_PRESENT) && !(c.par & SLOT_FOUNDER)) {
+            const double so = par.s1;
+            const double ssv = (so != 0.0) ? so / (1.0 - so) : 0.0;
+            if (c.ot & SLOT_PRESENT) {
+                double o[2], two[2];
+                top_terms(ot, par.a1, ssv, c.bit_ot, o, two);
+                o00 = o[0];
+            } else o00 = 1.0 + ssv;
         }
+        const double lp0 = (TP0.base[0] * o00) * TP0.tr[0][0], lp1 = (TP1.base[0] * o00) * TP1.tr[0][0];
+        out[AK_HZ + 0] = P ? lp0 : (ar.Rs[0][0] * ar.Xo[0]) * lp0 / den;
+        out[AK_HZ + 1] = P ? lp1 : (ar.Rs[0][1] * ar.Xo[1]) * lp1 / den;
         return;
     }
     LineTerms T;
@@ -174,78 +230,96 @@ CNF2_HD void acc_entry(const Window& w, const Slot slot[7], int entry, int combo
     const bool par_present = (c.par & SLOT_PRESENT) != 0, par_founder = (c.par & SLOT_FOUNDER) != 0;
     const bool par_is_line = !par_present || par_founder;
     const bool tr_real = !par_is_line && (c.tr & SLOT_PRESENT), ot_real = !par_is_line && (c.ot & SLOT_PRESENT);
-    bool okp[2], okt[2], oko[2];
-    for (int a = 0; a < 2; a++) {
-        okp[a] = !par_present || allele_ok(c.par, a, c.firstpar, force_par);
-        okt[a] = tr_real ? allele_ok(c.tr, a, c.bit_tr, force_tr) : (a == 0);
-        oko[a] = ot_real ? allele_ok(c.ot, a, c.bit_ot, force_ot) : (a == 0);
-    }
-    const double* R = ar.Rs[P];
-    double rtot = 0.0, wh[2] = {0, 0}, wroot[2] = {0, 0}, wpar[2][2] = {{0, 0}, {0, 0}}, wgp[2][2] = {{0, 0}, {0, 0}};
-    double h[2] = {0, 0}, rpar[2] = {0, 0}, rtr[2] = {0, 0}, rot[2] = {0, 0};
+    const double R0 = P ? ar.Rs[1][0] : ar.Rs[0][0], R1 = P ? ar.Rs[1][1] : ar.Rs[0][1];
+    double rtot = 0.0, wh0 = 0.0, wh1 = 0.0, wroot0 = 0.0, wroot1 = 0.0, h0 = 0.0, h1 = 0.0;
+    double wpar[2][2] = {{0, 0}, {0, 0}}, wgp[2][2] = {{0, 0}, {0, 0}};        // [allele index][i]
+    double rpar0 = 0.0, rpar1 = 0.0, rtr0 = 0.0, rtr1 = 0.0, rot0 = 0.0, rot1 = 0.0;   // by forced phase psi
+#pragma unroll
     for (int fp = 0; fp < 2; fp++) {
-        if (!okp[fp]) continue;
-        double O = 0.0, Oh[2] = {0, 0};
-        for (int fg = 0; fg < 2; fg++)
-            if (oko[fg]) {
-                O += T.ot[fp][fg];
-                if (T.ot[fp][fg] != 0.0) {
-                    Oh[0] += TP[0].ot[fp][fg];
-                    Oh[1] += TP[1].ot[fp][fg];
-                }
-            }
+        const bool okp = !par_present || allele_ok(c.par, fp, c.firstpar, force_par);
+        if (!okp) continue;
+        const bool oko0 = ot_real ? allele_ok(c.ot, 0, c.bit_ot, force_ot) : true;
+        const bool oko1 = ot_real ? allele_ok(c.ot, 1, c.bit_ot, force_ot) : false;
+        const double O = (oko0 ? T.ot[fp][0] : 0.0) + (oko1 ? T.ot[fp][1] : 0.0);
         const double bo = T.base[fp] * O;
-        double       trsum = 0.0, th[2] = {0, 0};
+        double       trsum = 0.0, th0 = 0.0, th1 = 0.0;
+#pragma unroll
         for (int fg = 0; fg < 2; fg++) {
-            if (!okt[fg]) continue;
+            const bool okt = tr_real ? allele_ok(c.tr, fg, c.bit_tr, force_tr) : (fg == 0);
+            if (!okt) continue;
             const double t = T.tr[fp][fg];
             trsum += t;
             if (t != 0.0) {
-                th[0] += TP[0].tr[fp][fg];
-                th[1] += TP[1].tr[fp][fg];
+                th0 += TP0.tr[fp][fg];
+                th1 += TP1.tr[fp][fg];
             }
-            const double term = bo * t;                    // sum over the other grandparent's admissible alleles
-            rtr[(fg ^ c.bit_tr) & 1] += term;
+            const double term = bo * t;                    // summed over the other grandparent's admissible alleles
+            if (((fg ^ c.bit_tr) & 1) == 0) rtr0 += term;
+            else rtr1 += term;
             if (term == 0.0) continue;                     // no path with a positive val here: never evaluated
-            const double l0 = TP[0].base[fp] * TP[0].tr[fp][fg], l1 = TP[1].base[fp] * TP[1].tr[fp][fg];
-            const double den = R[0] * l0 + R[1] * l1;
-            for (int i = 0; i < 2; i++) {
-                const double wi = (R[i] * (i ? l1 : l0)) / den;
-                const double tw = term * wi;
-                wh[i] += tw;
-                if (den != 0.0) {
-                    wroot[i] += tw;
-                    if (par_present) wpar[fp][i] += tw;
-                    if (tr_real) wgp[fg][i] += tw;
+            const double l0 = TP0.base[fp] * TP0.tr[fp][fg], l1 = TP1.base[fp] * TP1.tr[fp][fg];
+            const double den = R0 * l0 + R1 * l1;
+            const double tw0 = term * ((R0 * l0) / den), tw1 = term * ((R1 * l1) / den);
+            wh0 += tw0;
+            wh1 += tw1;
+            if (den != 0.0) {
+                wroot0 += tw0;
+                wroot1 += tw1;
+                if (par_present) {
+                    wpar[fp][0] += tw0;
+                    wpar[fp][1] += tw1;
+                }
+                if (tr_real) {
+                    wgp[fg][0] += tw0;
+                    wgp[fg][1] += tw1;
                 }
             }
         }
         rtot += bo * trsum;
-        rpar[(fp ^ c.firstpar) & 1] += bo * trsum;
-        for (int fg = 0; fg < 2; fg++)
-            if (oko[fg]) rot[(fg ^ c.bit_ot) & 1] += (T.base[fp] * T.ot[fp][fg]) * trsum;
-        if (T.base[fp] != 0.0)
-            for (int i = 0; i < 2; i++) h[i] += TP[i].base[fp] * Oh[i] * th[i];
+        if (((fp ^ c.firstpar) & 1) == 0) rpar0 += bo * trsum;
+        else rpar1 += bo * trsum;
+        const double bt = T.base[fp] * trsum;
+        if (oko0) {
+            if ((c.bit_ot & 1) == 0) rot0 += bt * T.ot[fp][0];
+            else rot1 += bt * T.ot[fp][0];
+        }
+        if (oko1) {
+            if ((c.bit_ot & 1) == 1) rot0 += bt * T.ot[fp][1];
+            else rot1 += bt * T.ot[fp][1];
+        }
+        if (T.base[fp] != 0.0) {
+            // probe sums over the paths the emission allows: the other grandparent's factor is the emission's own
+            h0 += TP0.base[fp] * (TP0.base[fp] != 0.0 ? O : 0.0) * th0;
+            h1 += TP1.base[fp] * (TP1.base[fp] != 0.0 ? O : 0.0) * th1;
+        }
     }
     out[AK_R] = rtot;
     if (par_present) {
-        for (int ph = 0; ph < 2; ph++) out[AK_HAP + 0 * 2 + ph] = rpar[ph ^ c.sp];
+        out[AK_HAP + 0] = c.sp ? rpar1 : rpar0;            // phase = psi ^ the parent's localshift
+        out[AK_HAP + 1] = c.sp ? rpar0 : rpar1;
         if (!par_founder) {
-            const int gt = c.firstpar, go = c.firstpar ^ 1;
-            if (c.tr & SLOT_PRESENT)
-                for (int ph = 0; ph < 2; ph++) out[AK_HAP + (1 + gt) * 2 + ph] = rtr[ph];
-            if (c.ot & SLOT_PRESENT)
-                for (int ph = 0; ph < 2; ph++) out[AK_HAP + (1 + go) * 2 + ph] = rot[ph];
+            // traced / other grandparent -> grandparent index by the parent's firstpar bit
+            const bool trp = (c.tr & SLOT_PRESENT) != 0, otp = (c.ot & SLOT_PRESENT) != 0;
+            const double a0 = c.firstpar ? (otp ? rot0 : 0.0) : (trp ? rtr0 : 0.0), a1 = c.firstpar ? (otp ? rot1 : 0.0) : (trp ? rtr1 : 0.0);
+            const double b0 = c.firstpar ? (trp ? rtr0 : 0.0) : (otp ? rot0 : 0.0), b1 = c.firstpar ? (trp ? rtr1 : 0.0) : (otp ? rot1 : 0.0);
+            out[AK_HAP + 2] = a0;
+            out[AK_HAP + 3] = a1;
+            out[AK_HAP + 4] = b0;
+            out[AK_HAP + 5] = b1;
         }
     }
-    for (int i = 0; i < 2; i++) {
-        out[AK_WROOT + i] = wroot[i];
-        for (int x = 0; x < 2; x++) {
+    out[AK_WROOT + 0] = wroot0;
+    out[AK_WROOT + 1] = wroot1;
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
             out[AK_WPAR + x * 2 + i] = wpar[x][i];
-            out[AK_WGP + (c.firstpar * 2 + x) * 2 + i] = wgp[x][i];
+            out[AK_WGP + (0 * 2 + x) * 2 + i] = c.firstpar ? 0.0 : wgp[x][i];
+            out[AK_WGP + (1 * 2 + x) * 2 + i] = c.firstpar ? wgp[x][i] : 0.0;
         }
-        out[AK_HZ + i] = P ? h[i] : wh[i];
-    }
+    out[AK_HZ + 0] = P ? h0 : wh0;
+    out[AK_HZ + 1] = P ? h1 : wh1;
 }
 
 // a * b where b carries the weight: a term whose weight is zero is never evaluated by the reference

@@ -2251,7 +2251,10 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 // =====================================================================================
 #define ACC_TAB (64 * AK_COUNT)
 #define ACC_LDS (ACC_TAB + 64 + 32 + 64 + 48)
-__global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
+#ifndef CNF2_ACC_MINBLOCKS
+#define CNF2_ACC_MINBLOCKS 1
+#endif
+__global__ __launch_bounds__(CNF2_BLOCK, CNF2_ACC_MINBLOCKS) void acc_rows_kernel(AccParams q)
 {
     __shared__ double lds[CNF2_WAVES_PER_BLOCK][ACC_LDS];
     const int lane = threadIdx.x & 63;
@@ -2290,9 +2293,10 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
     const bool root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
     const int  n_combo    = (no_ties || root_attop) ? 1 : (1 << w.n_groups);
     const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
-    AccRoot ar[2];
-    acc_root(slot[0], root_attop, 0, &ar[0]);
-    acc_root(slot[0], root_attop, 1, &ar[1]);
+    // per root allele f (no run-time indexed arrays: everything the later steps need is selected from ar0 / ar1)
+    AccRoot ar0, ar1;
+    acc_root(slot[0], root_attop, 0, &ar0);
+    acc_root(slot[0], root_attop, 1, &ar1);
     if (lane < 44) out[lane] = 0.0;
 
     for (int combo = 0; combo < n_combo; combo++) {
@@ -2300,17 +2304,23 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
         wave_lds_fence();
         {
             double e[AK_COUNT];
-            const int f_e = (lane >> 4) & 1;
-            if (ar[f_e].live) acc_entry(w, slot, lane, combo, no_ties, ar[f_e], e);
-            else
+            const bool f_e = ((lane >> 4) & 1) != 0;
+            if (f_e ? ar1.live : ar0.live) {
+                if (f_e) acc_entry(w, slot, lane, combo, no_ties, ar1, e);
+                else acc_entry(w, slot, lane, combo, no_ties, ar0, e);
+            } else {
+#pragma unroll
                 for (int k = 0; k < AK_COUNT; k++) e[k] = 0.0;
+            }
+#pragma unroll
             for (int k = 0; k < AK_COUNT; k++) tab[lane * AK_COUNT + k] = e[k];
         }
         wave_lds_fence();
         // ---- 2. partial contractions
 #pragma unroll
         for (int f = 0; f < 2; f++) {
-            const double cf = ar[f].live ? ar[f].cf[s0] : 0.0;
+            const AccRoot& af = f ? ar1 : ar0;
+            const double cf = af.live ? (s0 ? af.cf[1] : af.cf[0]) : 0.0;
             const double* t1 = tab + (size_t)((1 << 5) | (f << 4) | (s2 << 3)) * AK_COUNT;    // line 1 entries of this chain
             double tr = 0.0, th0 = 0.0, th1 = 0.0;
 #pragma unroll
@@ -2353,13 +2363,16 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
             if (lane < 28) {                                   // inf[slot][allele index][i]
                 const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
                 if (slotk == 0) {
+#pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        if (!ar[f].live) continue;
+                        const AccRoot& af = f ? ar1 : ar0;
+                        if (!af.live) continue;
                         if (root_attop) {
-                            const int side = (f == ax) ? 0 : 1;
-                            double    vsum = 0.0;
+                            const bool side = (f != ax);
+                            double     vsum = 0.0;
                             for (int e = 0; e < 16; e++) vsum += vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
-                            acc += vsum * (ar[f].Rs[side][i] / (ar[f].Rs[side][0] + ar[f].Rs[side][1]));
+                            const double r0 = side ? af.Rs[1][0] : af.Rs[0][0], r1 = side ? af.Rs[1][1] : af.Rs[0][1];
+                            acc += vsum * ((i ? r1 : r0) / (r0 + r1));
                         } else {
                             const int P = (f == ax) ? 0 : 1;                                   // fr = P ? f ^ 1 : f
                             for (int e = 0; e < 16; e++) {
@@ -2371,8 +2384,9 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
                 } else if (!root_attop) {
                     const int P = slotk >= 4, rel = slotk - (1 + 3 * P);                       // 0 parent, 1 / 2 grandparents
                     const int kind = rel == 0 ? AK_WPAR + ax * 2 + i : AK_WGP + ((rel - 1) * 2 + ax) * 2 + i;
+#pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        if (!ar[f].live) continue;
+                        if (!(f ? ar1.live : ar0.live)) continue;
                         for (int e = 0; e < 16; e++) {
                             const double wt = P ? ut[f * 16 + e] : vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
                             acc += mul0(tab[(size_t)((P << 5) | (f << 4) | e) * AK_COUNT + kind], wt);
@@ -2381,26 +2395,30 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
                 }
             } else if (lane < 30) {                            // homozyg[i]
                 const int i = lane - 28;
+#pragma unroll
                 for (int f = 0; f < 2; f++) {
-                    if (!ar[f].live) continue;
+                    const AccRoot& af = f ? ar1 : ar0;
+                    if (!af.live) continue;
                     double t = 0.0;
                     for (int e = 0; e < 16; e++)
                         t += mul0(tab[(size_t)((0 << 5) | (f << 4) | e) * AK_COUNT + AK_HZ + i], zt[(f * 2 + i) * 16 + e]);
-                    acc += ar[f].hzscale[i] * t;
+                    acc += (i ? af.hzscale[1] : af.hzscale[0]) * t;
                 }
             } else {                                           // haplos[slot][phase]
                 const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
                 if (slotk == 0) {
+#pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        if (!ar[f].live) continue;
+                        if (!(f ? ar1.live : ar0.live)) continue;
                         const int s0v = f ^ ph;                                                // phase = f ^ s0
                         for (int e = 0; e < 16; e++)
                             acc += mul0(tab[(size_t)((0 << 5) | (f << 4) | e) * AK_COUNT + AK_R], vt[(f * 2 + s0v) * 16 + e]);
                     }
                 } else if (!root_attop) {
                     const int P = slotk >= 4, rel = slotk - (1 + 3 * P);
+#pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        if (!ar[f].live) continue;
+                        if (!(f ? ar1.live : ar0.live)) continue;
                         for (int e = 0; e < 16; e++) {
                             const double wt = P ? ut[f * 16 + e] : vt[(f * 2 + 0) * 16 + e] + vt[(f * 2 + 1) * 16 + e];
                             acc += mul0(tab[(size_t)((P << 5) | (f << 4) | e) * AK_COUNT + AK_HAP + rel * 2 + ph], wt);
@@ -2414,12 +2432,15 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
     wave_lds_fence();
     // ---- 4. per-locus reductions (cnF2freq.cpp:5876-5902)
     const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
+    // this lane's own window member (lanes 0-6), read with the lane as index straight from memory
+    const Window* wg = p.windows + jb.ind;
+    const int     kk = lane < 7 ? lane : 0;
+    const int     myrow = wg->row[kk];
+    const Slot    mine = load_slot(p, myrow < 0 ? 0 : myrow, m);
     if (lane < 7) {
-        const int k = lane, r = srec[k];
         // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
-        const bool upd = (w.flags[k] & SLOT_PRESENT) && !(slot[k].a0 == slot[k].a1 && slot[k].s0 == slot[k].s1);
-        if (!upd) out[30 + k * 2] = out[30 + k * 2 + 1] = 0.0;
-        (void)r;
+        const bool upd = (wg->flags[kk] & SLOT_PRESENT) && !(mine.a0 == mine.a1 && mine.s0 == mine.s1);
+        if (!upd) out[30 + kk * 2] = out[30 + kk * 2 + 1] = 0.0;
     }
     wave_lds_fence();
     double self0 = 0.0;
@@ -2449,7 +2470,7 @@ __global__ __launch_bounds__(CNF2_BLOCK) void acc_rows_kernel(AccParams q)
             double* dst = q.acc_inf + ((size_t)r * p.n_markers + m) * 4;
             for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
             if (h0 != 0.0 || h1 != 0.0) {                                                      // cnF2freq.cpp:3601-3616
-                if (fabs(slot[k].hw - 0.5) < 0.5 - 1e-12) {
+                if (fabs(mine.hw - 0.5) < 0.5 - 1e-12) {
                     const double md = (double)0.000005f;
                     const double b1 = h0 + exp(-400.0) * md * md * 0.5;
                     const double b2 = h1 + exp(-400.0) * md * md * 0.5;
