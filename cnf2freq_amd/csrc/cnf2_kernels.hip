@@ -869,9 +869,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         }
         if (hom == 0 && w.flag2ignore == 0) hom = 3;
         hom = __builtin_amdgcn_readfirstlane(hom);
-#ifndef CNF2_NO_PATHLOG
         if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = hom;
-#endif
         const int s = lane >> 3;
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
