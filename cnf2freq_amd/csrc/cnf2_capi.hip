@@ -1068,7 +1068,9 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         p.wstride      = (size_t)mlen;
         AccParams q;
         memset(&q, 0, sizeof(q));
-        q.flags     = (flags & CNF2_NO_TIES) ? KP_NO_TIES : 0;
+        q.flags     = ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0) | ((flags & CNF2_ACC_TABLE) ? KP_ACC_TABLE : 0);
+        for (int j = 0; j < n; j++)
+            if (ctx->windows[ind_begin + j].flags[0] & SLOT_FOUNDER) q.flags |= KP_ACC_ATTOP;
         q.slot_rec  = ctx->d_slot_rec + (size_t)ind_begin * 7;
         q.desc      = ctx->d_desc;
         q.rec_empty = ctx->d_rec_empty;

@@ -15,7 +15,9 @@ namespace cnf2 {
 #define CNF2_MINFACTOR_F (-1e15f)  /* settings.h:29 */
 #define CNF2_IGNORED_D (-1e30)     /* cnF2freq.cpp:5378 */
 
-enum { KP_NO_DOSAGE = 1, KP_RAW_DOSAGE = 2, KP_NO_TIES = 4 };
+enum { KP_NO_DOSAGE = 1, KP_RAW_DOSAGE = 2, KP_NO_TIES = 4,
+       KP_ACC_TABLE = 8,    // accumulate: the table-form kernel does every window
+       KP_ACC_ATTOP = 16 }; // accumulate: the batch holds windows whose root is the top of its lines (table form)
 
 // One unit of sequential work: an analysed individual on one chromosome
 // (the body of the loops at cnF2freq.cpp:5283 and 5294).
@@ -79,7 +81,7 @@ struct AccParams {
     KernelParams   kp;           // windows (offset to ind_begin), jobs (offset to the batch), rows, wbuf, loglik, factors
     int            n_jobs;       // jobs in this batch
     int            max_len;      // longest chromosome of the batch (grid.y)
-    uint32_t       flags;        // KP_NO_TIES
+    uint32_t       flags;        // KP_NO_TIES, KP_ACC_TABLE, KP_ACC_ATTOP
     const int32_t* slot_rec;     // [n_ind][7] record per window slot, -1 none (offset like windows)
     const int32_t* desc;         // [n_rec] individ::descendants
     const uint8_t* rec_empty;    // [n_rec]

@@ -28,6 +28,7 @@
 #include "cnf2_emtab.h"
 #include "cnf2_accum.h"
 #include "cnf2_acctab.h"
+#include "cnf2_accpath.h"
 #include "cnf2_update.h"
 #include "cnf2_variance.h"
 
@@ -2249,6 +2250,62 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 //      3577-3616) with f64 atomics into the per-record arrays.
 // Not tuned beyond the algebra (the table entries are evaluated by the plain host/device code of cnf2_accum.h).
 // =====================================================================================
+// The per-locus reductions of doit for one (job, marker) (cnF2freq.cpp:5876-5902, 3577-3616): out[44] = inf[7][2][2],
+// homozyg[2], haplos[7][2] of the window's slots -> homozyg scale, moveinfprobs, movehaplos with f64 atomics.
+__device__ __forceinline__ void acc_reduce_locus(const AccParams& q, const Job& jb, int m, int lane, double* out)
+{
+    const KernelParams& p = q.kp;
+    const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
+    // this lane's own window member (lanes 0-6), read with the lane as index straight from memory
+    const Window* wg = p.windows + jb.ind;
+    const int     kk = lane < 7 ? lane : 0;
+    const int     myrow = wg->row[kk];
+    const Slot    mine = load_slot(p, myrow < 0 ? 0 : myrow, m);
+    if (lane < 7) {
+        // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
+        const bool upd = (wg->flags[kk] & SLOT_PRESENT) && !(mine.a0 == mine.a1 && mine.s0 == mine.s1);
+        if (!upd) out[30 + kk * 2] = out[30 + kk * 2 + 1] = 0.0;
+    }
+    wave_lds_fence();
+    double self0 = 0.0;
+    for (int k = 0; k < 7; k++)
+        if (srec[k] == srec[0]) self0 += out[(k * 2 + 0) * 2 + 0] + out[(k * 2 + 0) * 2 + 1];
+    const double sum = 1.0 / self0;                                                            // cnF2freq.cpp:5880-5885
+    if (lane < 2) q.acc_hz[((size_t)jb.ind * p.n_markers + m) * 2 + lane] = out[28 + lane] * sum;
+    if (lane < 7) {
+        const int k = lane, r = srec[k];
+        bool first = r >= 0;
+        for (int k2 = 0; k2 < k; k2++) first = first && (srec[k2] != r);                      // reltree: unique members
+        if (first) {
+            double inf[4] = {0, 0, 0, 0}, h0 = 0.0, h1 = 0.0;
+            int    occ = 0;
+            for (int k2 = k; k2 < 7; k2++) {
+                if (srec[k2] != r) continue;
+                for (int t = 0; t < 4; t++) inf[t] += out[k2 * 4 + t];
+                h0 += out[30 + k2 * 2];
+                h1 += out[30 + k2 * 2 + 1];
+                // reltreeordered: the individual itself always, ancestors only when non-empty (cnF2freq.cpp:3111-3152)
+                if (k2 == 0 || !q.rec_empty[r]) occ++;
+            }
+            const double descf = (double)q.desc[srec[0]];
+            double       norm = sum * 2;                                                       // cnF2freq.cpp:3582-3587
+            for (int t = 0; t < occ; t++) norm /= 2;
+            norm *= descf;
+            double* dst = q.acc_inf + ((size_t)r * p.n_markers + m) * 4;
+            for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
+            if (h0 != 0.0 || h1 != 0.0) {                                                      // cnF2freq.cpp:3601-3616
+                if (fabs(mine.hw - 0.5) < 0.5 - 1e-12) {
+                    const double md = (double)0.000005f;
+                    const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+                    const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+                    atomicAdd(q.acc_hb + (size_t)r * p.n_markers + m, b1 / (b1 + b2) * descf);
+                    atomicAdd(q.acc_hc + (size_t)r * p.n_markers + m, descf);
+                }
+            }
+        }
+    }
+}
+
 #define ACC_TAB (64 * AK_COUNT)
 #define ACC_LDS (ACC_TAB + 64 + 32 + 64 + 48)
 #ifndef CNF2_ACC_MINBLOCKS
@@ -2269,6 +2326,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_ACC_MINBLOCKS) void acc_rows_kerne
     const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
     if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                     // cnF2freq.cpp:5403
     const Window w = p.windows[jb.ind];
+    if (!(q.flags & KP_ACC_TABLE) && !(w.flags[0] & SLOT_FOUNDER)) return;               // acc_paths_kernel's
     double* tab = lds[wib];                    // [64 entries][AK_COUNT]
     double* vt  = tab + ACC_TAB;               // [f][s0][16]
     double* ut  = vt + 64;                     // [f][16]
@@ -2430,62 +2488,266 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_ACC_MINBLOCKS) void acc_rows_kerne
         }
     }
     wave_lds_fence();
-    // ---- 4. per-locus reductions (cnF2freq.cpp:5876-5902)
-    const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
-    // this lane's own window member (lanes 0-6), read with the lane as index straight from memory
-    const Window* wg = p.windows + jb.ind;
-    const int     kk = lane < 7 ? lane : 0;
-    const int     myrow = wg->row[kk];
-    const Slot    mine = load_slot(p, myrow < 0 ? 0 : myrow, m);
-    if (lane < 7) {
-        // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
-        const bool upd = (wg->flags[kk] & SLOT_PRESENT) && !(mine.a0 == mine.a1 && mine.s0 == mine.s1);
-        if (!upd) out[30 + kk * 2] = out[30 + kk * 2 + 1] = 0.0;
-    }
-    wave_lds_fence();
-    double self0 = 0.0;
-    for (int k = 0; k < 7; k++)
-        if (srec[k] == srec[0]) self0 += out[(k * 2 + 0) * 2 + 0] + out[(k * 2 + 0) * 2 + 1];
-    const double sum = 1.0 / self0;                                                            // cnF2freq.cpp:5880-5885
-    if (lane < 2) q.acc_hz[((size_t)jb.ind * p.n_markers + m) * 2 + lane] = out[28 + lane] * sum;
-    if (lane < 7) {
-        const int k = lane, r = srec[k];
-        bool first = r >= 0;
-        for (int k2 = 0; k2 < k; k2++) first = first && (srec[k2] != r);                      // reltree: unique members
-        if (first) {
-            double inf[4] = {0, 0, 0, 0}, h0 = 0.0, h1 = 0.0;
-            int    occ = 0;
-            for (int k2 = k; k2 < 7; k2++) {
-                if (srec[k2] != r) continue;
-                for (int t = 0; t < 4; t++) inf[t] += out[k2 * 4 + t];
-                h0 += out[30 + k2 * 2];
-                h1 += out[30 + k2 * 2 + 1];
-                // reltreeordered: the individual itself always, ancestors only when non-empty (cnF2freq.cpp:3111-3152)
-                if (k2 == 0 || !q.rec_empty[r]) occ++;
-            }
-            const double descf = (double)q.desc[srec[0]];
-            double       norm = sum * 2;                                                       // cnF2freq.cpp:3582-3587
-            for (int t = 0; t < occ; t++) norm /= 2;
-            norm *= descf;
-            double* dst = q.acc_inf + ((size_t)r * p.n_markers + m) * 4;
-            for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
-            if (h0 != 0.0 || h1 != 0.0) {                                                      // cnF2freq.cpp:3601-3616
-                if (fabs(mine.hw - 0.5) < 0.5 - 1e-12) {
-                    const double md = (double)0.000005f;
-                    const double b1 = h0 + exp(-400.0) * md * md * 0.5;
-                    const double b2 = h1 + exp(-400.0) * md * md * 0.5;
-                    atomicAdd(q.acc_hb + (size_t)r * p.n_markers + m, b1 / (b1 + b2) * descf);
-                    atomicAdd(q.acc_hc + (size_t)r * p.n_markers + m, descf);
-                }
-            }
+    acc_reduce_locus(q, jb, m, lane, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same accumulators in the path form of cnf2_accpath.h, for every window whose root is not the top of its own
+// lines (the others stay with acc_rows_kernel).  One wavefront per (job, marker):
+//   1. lane = path (P, f, fp, t, g1, g0): the line's three match terms, its GENOS weights and probe products -- once;
+//   2. three butterfly stages (DPP on lane bits 0, 1, 3) turn paths into the 64 restricted totals and the
+//      HOMOZYGOUS probe sums of line 1; into LDS in the emission-table numbering;
+//   3. lane = (shift mode, low state bits): partial contractions v, u, z of the posterior weights (as acc_rows_kernel);
+//   4. lane = entry: its weight from v / u / z; the transposed butterflies give every path the sum Omega of the
+//      weights of the entries it belongs to, with the last stage kept split for each slot (HAPLOS phases);
+//   5. lane = path: products, 8-lane sums, and a last gather by the 44 accumulators through LDS;
+//   6. the per-locus reductions of doit (as acc_rows_kernel).
+// ---------------------------------------------------------------------------------------------------
+#define APL_RT   0                 /* [64] restricted totals, emission-table numbering */
+#define APL_HT   64                /* [i][32] HOMOZYGOUS probe sums of the entries of line 1 */
+#define APL_VT   128               /* [f][s0][16] */
+#define APL_UT   192               /* [f][16] */
+#define APL_ZT   224               /* [f][i][16] */
+#define APL_RED  288               /* [12 kinds][8 groups] */
+#define APL_TW   384               /* [i][64] GENOS terms per path lane */
+#define APL_OUT  512               /* [44] */
+#define APL_LDS  560
+
+template <int BIT>
+__device__ __forceinline__ double path_xchg(double v)
+{
+    if (BIT == 0) return lane_xor1(v);
+    if (BIT == 1) return lane_xor2(v);
+    return lane_xor8(v);
+}
+template <int BIT>
+__device__ __forceinline__ double path_stage(double v, double own, double other)
+{
+    return own * v + other * path_xchg<BIT>(v);
+}
+
+__global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
+{
+    __shared__ double lds[CNF2_WAVES_PER_BLOCK][APL_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job  = blockIdx.x;
+    const int ml   = blockIdx.y * CNF2_WAVES_PER_BLOCK + wib;
+    const KernelParams& p = q.kp;
+    const Job jb = p.jobs[job];
+    const int len = jb.last - jb.first + 1;
+    if (ml >= len) return;
+    const int    m  = jb.first + ml;
+    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
+    if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                     // cnF2freq.cpp:5403
+    const Window w = p.windows[jb.ind];
+    if (w.flags[0] & SLOT_FOUNDER) return;                                              // acc_rows_kernel's
+    double* L = lds[wib];
+
+    double x[8];
+    {
+        const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double2 v2 = *(const double2*)(wp + k * 128 + lane * 2);
+            x[2 * k]     = v2.x;
+            x[2 * k + 1] = v2.y;
         }
     }
+    Slot slot[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) slot[k] = load_slot(p, w.row[k] < 0 ? 0 : w.row[k], m);
+    const bool no_ties = (q.flags & KP_NO_TIES) != 0;
+    const int  n_combo = no_ties ? 1 : (1 << w.n_groups);
+    // consumer role of this lane (steps 3): shift mode bits and low state bits
+    const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
+    // path / entry role (steps 1, 2, 4, 5)
+    const int  P = lane >> 5, f = (lane >> 4) & 1, fp = (lane >> 3) & 1, t = (lane >> 2) & 1;
+    const int  eidx = path_entry_index(lane), e4 = eidx & 15;
+    double     cf0, cf1, hzs0, hzs1;            // c_f(s0 of the consumer role) for f = 0, 1; HOMOZYGOUS scale of this lane's f
+    bool       live0, live1;
+    PathTerms  T;
+    {
+        AccRoot ar0, ar1;
+        acc_root(slot[0], false, 0, &ar0);
+        acc_root(slot[0], false, 1, &ar1);
+        live0 = ar0.live;
+        live1 = ar1.live;
+        cf0   = live0 ? (s0 ? ar0.cf[1] : ar0.cf[0]) : 0.0;
+        cf1   = live1 ? (s0 ? ar1.cf[1] : ar1.cf[0]) : 0.0;
+        hzs0  = f ? ar1.hzscale[0] : ar0.hzscale[0];
+        hzs1  = f ? ar1.hzscale[1] : ar0.hzscale[1];
+        if (f) path_terms(w, slot, lane, ar1, &T);
+        else path_terms(w, slot, lane, ar0, &T);
+    }
+    const bool live = f ? live1 : live0;
+    if (!live) T.term0 = T.k0 = T.k1 = 0.0;
+    if (lane < 44) L[APL_OUT + lane] = 0.0;
+
+    for (int combo = 0; combo < n_combo; combo++) {
+        PathCoef C;
+        path_coef(w, slot, lane, combo, no_ties, &C);
+        // ---- 2. paths -> entries
+        wave_lds_fence();
+        {
+            double R = T.term0, H0 = T.k0, H1 = T.k1;
+            R  = path_stage<0>(R, C.g0_s, C.g0_f);
+            H0 = path_stage<0>(H0, C.g0_s, C.g0_f);
+            H1 = path_stage<0>(H1, C.g0_s, C.g0_f);
+            R  = path_stage<1>(R, C.g1_s, C.g1_f);
+            H0 = path_stage<1>(H0, C.g1_s, C.g1_f);
+            H1 = path_stage<1>(H1, C.g1_s, C.g1_f);
+            R  = path_stage<3>(R, C.par_s, C.par_f);
+            H0 = path_stage<3>(H0, C.par_s, C.par_f);
+            H1 = path_stage<3>(H1, C.par_s, C.par_f);
+            L[APL_RT + eidx] = R;
+            if (P) {
+                L[APL_HT + (eidx & 31)]      = H0;
+                L[APL_HT + 32 + (eidx & 31)] = H1;
+            }
+        }
+        wave_lds_fence();
+        const double Rmine = L[APL_RT + eidx];
+        // ---- 3. partial contractions (lane = shift mode and low state bits, registers = high state bits)
+#pragma unroll
+        for (int ff = 0; ff < 2; ff++) {
+            const double  cf = ff ? cf1 : cf0;
+            const double* t1 = L + APL_RT + ((1 << 5) | (ff << 4) | (s2 << 3));          // line 1 entries of this chain
+            const double* h0 = L + APL_HT + ((ff << 4) | (s2 << 3));
+            const double* h1 = h0 + 32;
+            double tr = 0.0, th0 = 0.0, th1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double cx = cf * x[j];
+                if (cx != 0.0) {
+                    tr += cx * t1[j];
+                    th0 += cx * h0[j];
+                    th1 += cx * h1[j];
+                }
+            }
+            tr += lane_xor32(tr);
+            th0 += lane_xor32(th0);
+            th1 += lane_xor32(th1);
+            th0 += lane_xor8(th0);
+            th1 += lane_xor8(th1);
+            const int e0 = (s1 << 3) | lo;
+            if (s2 == 0) L[APL_VT + (ff * 2 + s0) * 16 + e0] = tr;
+            if (s2 == 0 && s0 == 0) {
+                L[APL_ZT + (ff * 2 + 0) * 16 + e0] = th0;
+                L[APL_ZT + (ff * 2 + 1) * 16 + e0] = th1;
+            }
+            const double r0 = L[APL_RT + ((0 << 5) | (ff << 4) | (s1 << 3) | lo)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double cx = cf * x[j];
+                double       pj = (cx != 0.0) ? cx * r0 : 0.0;
+                pj = chain_sum(pj);
+                pj += lane_xor8(pj);
+                pj += lane_xor16(pj);
+                if ((lane & 31) == 0) L[APL_UT + ff * 16 + (s2 << 3) + j] = pj;
+            }
+        }
+        wave_lds_fence();
+        // ---- 4. lane = entry: weights, then entries -> paths
+        const double v0 = L[APL_VT + (f * 2 + 0) * 16 + e4], v1 = L[APL_VT + (f * 2 + 1) * 16 + e4];
+        const double wt = P ? L[APL_UT + f * 16 + e4] : v0 + v1;
+        double z0 = P ? 0.0 : L[APL_ZT + (f * 2 + 0) * 16 + e4], z1 = P ? 0.0 : L[APL_ZT + (f * 2 + 1) * 16 + e4];
+        // HAPLOS of the root straight from the entries: phase f ^ s0 (cnF2freq.cpp:1227)
+        double hr0 = 0.0, hr1 = 0.0;
+        if (P == 0 && live) {
+            const double a = mul0(Rmine, v0), b = mul0(Rmine, v1);
+            hr0 = f ? b : a;
+            hr1 = f ? a : b;
+        }
+        const double X1  = path_stage<1>(wt, C.g1_s, C.g1_r);
+        const double X01 = path_stage<0>(X1, C.g0_s, C.g0_r);
+        const double Y   = path_stage<3>(X1, C.par_s, C.par_r);
+        const double X0  = path_stage<0>(wt, C.g0_s, C.g0_r);
+        const double Z   = path_stage<3>(X0, C.par_s, C.par_r);
+        z0 = path_stage<1>(z0, C.g1_s, C.g1_r);
+        z1 = path_stage<1>(z1, C.g1_s, C.g1_r);
+        z0 = path_stage<0>(z0, C.g0_s, C.g0_r);
+        z1 = path_stage<0>(z1, C.g0_s, C.g0_r);
+        z0 = path_stage<3>(z0, C.par_s, C.par_r);
+        z1 = path_stage<3>(z1, C.par_s, C.par_r);
+        const double o_par_self = C.par_s * X01, o_par_part = C.par_r * path_xchg<3>(X01);      // phase t / !t
+        const double o_g0_self = C.g0_s * Y, o_g0_part = C.g0_r * path_xchg<0>(Y);              // phase 0 / 1
+        const double o_g1_self = C.g1_s * Z, o_g1_part = C.g1_r * path_xchg<1>(Z);
+        // ---- 5. lane = path
+        double val[12];
+        {
+            const double c = (o_par_self + o_par_part) * T.term0;
+            const bool   ok = c != 0.0 && T.den_ok;
+            val[0] = ok ? c * T.w0 : 0.0;                               // GENOS terms
+            val[1] = ok ? c * T.w1 : 0.0;
+            const double c0 = z0 * T.term0, c1 = z1 * T.term0;          // HOMOZYGOUS (line 0)
+            val[2] = (P == 0 && c0 != 0.0) ? hzs0 * (c0 * T.w0) : 0.0;
+            val[3] = (P == 0 && c1 != 0.0) ? hzs1 * (c1 * T.w1) : 0.0;
+            val[4] = hr0;
+            val[5] = hr1;
+            const double ps = (T.out & PO_PAR) ? mul0(T.term0, o_par_self) : 0.0, pp = (T.out & PO_PAR) ? mul0(T.term0, o_par_part) : 0.0;
+            val[6] = t ? pp : ps;
+            val[7] = t ? ps : pp;
+            val[8]  = (T.out & PO_G0) ? mul0(T.term0, o_g0_self) : 0.0;
+            val[9]  = (T.out & PO_G0) ? mul0(T.term0, o_g0_part) : 0.0;
+            val[10] = (T.out & PO_G1) ? mul0(T.term0, o_g1_self) : 0.0;
+            val[11] = (T.out & PO_G1) ? mul0(T.term0, o_g1_part) : 0.0;
+        }
+        L[APL_TW + lane]      = (T.out & PO_TR) ? val[0] : 0.0;
+        L[APL_TW + 64 + lane] = (T.out & PO_TR) ? val[1] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            // sum over lane bits 0-2 (g0, g1, t): xor1, xor2, then the pairing i <-> 7 - i finishes it
+            double v = val[k];
+            v += lane_xor1(v);
+            v += lane_xor2(v);
+            v += dpp_mov_all<0x141>(v);
+            if ((lane & 7) == 0) L[APL_RED + k * 8 + (lane >> 3)] = v;
+        }
+        wave_lds_fence();
+        if (lane < 44) {
+            double acc = 0.0;
+            const double* red = L + APL_RED;                              // group = P<<2 | f<<1 | fp
+            if (lane < 28) {
+                const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
+                if (slotk == 0) {                                         // root: allele index f ^ P
+                    acc = red[i * 8 + (0 << 2 | ax << 1)] + red[i * 8 + (0 << 2 | ax << 1 | 1)] +
+                          red[i * 8 + (1 << 2 | (ax ^ 1) << 1)] + red[i * 8 + (1 << 2 | (ax ^ 1) << 1 | 1)];
+                } else {
+                    const int PP = slotk >= 4, rel = slotk - (1 + 3 * PP);
+                    if (rel == 0) {                                       // parent: allele index fp
+                        if (w.flags[slotk] & SLOT_PRESENT) acc = red[i * 8 + (PP << 2 | 0 << 1 | ax)] + red[i * 8 + (PP << 2 | 1 << 1 | ax)];
+                    } else {                                              // grandparent rel - 1 as the traced one: allele index g
+                        const int tt = rel - 1;
+                        const double* tw = L + APL_TW + i * 64;
+                        for (int k = 0; k < 8; k++) {                     // over f, fp and the other grandparent's allele
+                            const int ff = k & 1, pp = (k >> 1) & 1, go = k >> 2;
+                            const int gg0 = tt ? go : ax, gg1 = tt ? ax : go;
+                            acc += tw[PP << 5 | ff << 4 | pp << 3 | tt << 2 | gg1 << 1 | gg0];
+                        }
+                    }
+                }
+            } else if (lane < 30) {
+                const int i = lane - 28;
+                acc = red[(2 + i) * 8 + 0] + red[(2 + i) * 8 + 1] + red[(2 + i) * 8 + 2] + red[(2 + i) * 8 + 3];
+            } else {
+                const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
+                const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
+                const int kind = 4 + (rel + 1) * 2 + ph;                  // root, parent, grandparent 0, grandparent 1
+                acc = red[kind * 8 + PP * 4 + 0] + red[kind * 8 + PP * 4 + 1] + red[kind * 8 + PP * 4 + 2] + red[kind * 8 + PP * 4 + 3];
+            }
+            L[APL_OUT + lane] += acc;
+        }
+    }
+    wave_lds_fence();
+    acc_reduce_locus(q, jb, m, lane, L + APL_OUT);
 }
 
 void launch_acc_rows(const AccParams& q, hipStream_t stream)
 {
     dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(acc_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
+    if (!(q.flags & KP_ACC_TABLE)) hipLaunchKernelGGL(acc_paths_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
+    if (q.flags & (KP_ACC_TABLE | KP_ACC_ATTOP)) hipLaunchKernelGGL(acc_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 
 void launch_addvariance(const KernelParams& p, int first, int len, double* out, hipStream_t stream)

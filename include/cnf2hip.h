@@ -61,6 +61,10 @@ enum {
     CNF2_ACC_DEVICE   = 1u << 6, /* cnf2_sweep_accumulate: the four accumulator pointers are device pointers owned by the
                                     caller (a multi-GPU driver all-reduces them in place) */
     CNF2_ACC_KEEP     = 1u << 7, /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
+    CNF2_ACC_TABLE    = 1u << 10, /* cnf2_sweep_accumulate: evaluate every window in the table form (one lane per emission-table
+                                    entry) instead of the path form (one lane per allele path of a line); same sums, the
+                                    slower kernel -- kept as the cross-check of the fast one and for windows whose root
+                                    is the top of its own lines, which always take it */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same

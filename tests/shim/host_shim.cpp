@@ -8,6 +8,7 @@
 #include "cnf2_emtab.h"
 #include "cnf2_accum.h"
 #include "cnf2_acctab.h"
+#include "cnf2_accpath.h"
 
 using namespace cnf2;
 
@@ -251,6 +252,34 @@ int shim_acc_contract(int n_rec, const int32_t* par, const uint8_t* empty, const
     hz_out[0] = hz_out[1] = 0;
     acc_contract_scalar(w, slot, wg, no_ties != 0, inf_out, hz_out, hap_out);
     // doupdatehaplo (cnF2freq.cpp:1224-1239): a slot that is homozygous with equal sure at the marker, or absent, adds nothing
+    for (int k = 0; k < 7; k++) {
+        const bool upd = (w.flags[k] & SLOT_PRESENT) && !(slot[k].a0 == slot[k].a1 && slot[k].s0 == slot[k].s1);
+        if (!upd) hap_out[k * 2] = hap_out[k * 2 + 1] = 0;
+    }
+    return w.n_groups;
+}
+
+// Path form of the same accumulators (cnf2_accpath.h: what the fast accumulate kernel evaluates).  Returns -1 for an
+// individual that is the top of its own lines (the kernel leaves those to the table form).
+int shim_acc_contract_paths(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                            const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+                            int n_markers, int rec, int marker, const double* wg, int no_ties, double* inf_out,
+                            double* hz_out, double* hap_out)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    if (w.flags[0] & SLOT_FOUNDER) return -1;
+    Slot slot[7];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot[k] = unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    }
+    for (int k = 0; k < 28; k++) inf_out[k] = 0;
+    for (int k = 0; k < 14; k++) hap_out[k] = 0;
+    hz_out[0] = hz_out[1] = 0;
+    acc_contract_paths(w, slot, wg, no_ties != 0, inf_out, hz_out, hap_out);
     for (int k = 0; k < 7; k++) {
         const bool upd = (w.flags[k] & SLOT_PRESENT) && !(slot[k].a0 == slot[k].a1 && slot[k].s0 == slot[k].s1);
         if (!upd) hap_out[k * 2] = hap_out[k * 2 + 1] = 0;

@@ -722,7 +722,7 @@ def test_half_spill_recompute_equals_full_spill(capi):
 
 def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
     """cnf2_sweep_accumulate (the product form of HOT LOOP 2: every individual and chromosome in batched launches,
-    table form of the accumulators, reductions with atomics on the device) against the oracle's accumulate
+    path form of the accumulators, reductions with atomics on the device) against the oracle's accumulate
     (pinned bit-exact on the reference's own moveinfprobs / movehaplos): advanced intercross with active ties
     (general kernel + tie combinations), outbred with missing data, and an F2 over three ragged chromosomes.
     The sweep outputs that come with it must be those of cnf2_sweep."""
@@ -748,6 +748,11 @@ def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
             for k, sl in (("infprobs", np.s_[:, first:last + 1]), ("haplobase", np.s_[:, first:last + 1]),
                           ("haplocount", np.s_[:, first:last + 1]), ("homozyg", np.s_[:, first:last + 1])):
                 np.testing.assert_allclose(got[k][sl], want[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+        # the table form (one lane per emission-table entry; the kernel of the windows whose root is the top of its
+        # lines) on every window: the same sums as the path form, against the oracle too
+        tab = ctx.sweep_accumulate(desc, table_form=True)
+        for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+            np.testing.assert_allclose(tab[k], got[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg="table form " + k)
         # a sub-range of individuals gives that range's homozyg and (for disjoint windows) its share of the rest
         part = ctx.sweep_accumulate(desc, 1, 3)
         np.testing.assert_allclose(part["homozyg"], got["homozyg"][1:3], rtol=1e-12, atol=1e-15, equal_nan=True)

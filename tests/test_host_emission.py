@@ -118,6 +118,48 @@ def test_restricted_class_split_reproduces_reference_rows(shim, seed):
             np.testing.assert_allclose(row, r["dosage"][m], rtol=1e-10, atol=1e-14)
 
 
+@pytest.mark.parametrize("maker", [
+    lambda: synth.make_random_windows(40, 4, seed=21),
+    lambda: synth.make_random_windows(40, 3, seed=22),
+    lambda: synth.make_random_windows(40, 4, seed=23),
+    lambda: synth.make_outbred3(2, 2, 7, 1, seed=8, missing=0.25, random_hw=True, random_sure=True),
+    lambda: synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2),
+    lambda: synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
+])
+def test_path_form_of_all_accumulators_matches_fanout(shim, maker):
+    """cnf2_accpath.h (the accumulators as sums over the allele paths of a line, with the state bits entering through
+    butterfly transforms of the entry weights: what the fast accumulate kernel evaluates, emulated here lane by lane)
+    against the oracle's brute-force fan-outs, and against the table form for the NaN pattern of homozyg."""
+    ped = maker()
+    o = oracle_ped(ped)
+    checked = tied = 0
+    for ind in ped.dous:
+        slots = np.zeros(17, np.int32)
+        shim.shim_window(*_ped_args(ped), int(ind), _p(slots))
+        for m in (0, ped.n_markers - 1):
+            wg = _mode_weights(o, ped, ind, m)
+            if wg is None:
+                continue
+            inf, hz, hap = np.zeros((7, 2, 2)), np.zeros(2), np.zeros((7, 2))
+            ng = shim.shim_acc_contract_paths(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
+                                              int(ind), m, _p(np.ascontiguousarray(wg)), 0, _p(inf), _p(hz), _p(hap))
+            if ng < 0:
+                continue
+            want, want_hz = o.infprobs_row(int(ind), m, int(ped.gen[ind]))
+            want_hap = o.haplos_row(int(ind), m, int(ped.gen[ind]))
+            got, got_hap = np.zeros_like(want), np.zeros_like(want_hap)
+            for k in range(7):
+                if slots[3 + k] >= 0:
+                    got[slots[3 + k]] += inf[k]
+                    got_hap[slots[3 + k]] += hap[k]
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(hz, want_hz, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(got_hap, want_hap, rtol=1e-9, atol=1e-13)
+            checked += 1
+            tied += int(ng > 0)
+    assert checked > 0
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33])
 def test_fast_tile_producer_matches_general_producer(shim, seed):
     """cnf2_emtab.h (division-free tile producer of the fast kernel) against cnf2_emission.h:
