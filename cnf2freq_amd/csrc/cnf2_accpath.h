@@ -26,6 +26,54 @@
 
 namespace cnf2 {
 
+// a / b for the ratios of this form.  Device: reciprocal + two Newton steps + one residual correction (no scaling for
+// denormal operands, which probabilities and their products are not); 0 / 0 is NaN as with the plain division.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double path_div(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+#else
+inline double path_div(double a, double b) { return a / b; }
+#endif
+
+// What line P of a path lane receives from the root for root allele f (root_terms() + acc_root() restricted to what
+// one lane reads; the root is not the top of its lines): incoming allele and error odds, probe bases R_i, and the
+// HOMOZYGOUS scale Xo_i / d0 (cnF2freq.cpp:1304-1318).
+struct PathRoot {
+    int    inmv;
+    double sv;
+    double R0, R1;
+    double hzscale0, hzscale1;
+};
+CNF2_HD void path_root(const Slot& root, int f, int P, PathRoot* A)
+{
+    const int    mf = f ? root.a1 : root.a0, mo = f ? root.a0 : root.a1;
+    const double sf = f ? root.s1 : root.s0, so = f ? root.s0 : root.s1;
+    // line 0 gets (mf, msv / baseval), line 1 gets (mo, so / (1 - so)): one division, operands selected first
+    const double num = P ? so : ((mf != 0) ? sf : 0.0);
+    const double den = P ? 1.0 - so : 1.0 - sf;
+    A->inmv = P ? mo : mf;
+    A->sv   = (num != 0.0) ? path_div(num, den) : 0.0;
+    A->R0   = probe_base(1, P ? mo : mf, P ? so : sf);
+    A->R1   = probe_base(2, P ? mo : mf, P ? so : sf);
+    const double inv = (so != 0.0) ? path_div(1.0, 1.0 - so) : 1.0;
+    A->hzscale0 = ((1 != mo) ? (mo != 0 ? so : 1.0) : (1.0 - so)) * inv;
+    A->hzscale1 = ((2 != mo) ? (mo != 0 ? so : 1.0) : (1.0 - so)) * inv;
+}
+// c_f without the phase weight (root_terms().cbase for a root that is not the top of its lines)
+CNF2_HD double path_root_cbase(const Slot& root, int f)
+{
+    const double sf = f ? root.s1 : root.s0, so = f ? root.s0 : root.s1;
+    double       b = 1.0 - sf;
+    if (so != 0.0) b *= (1.0 - so);
+    return b;
+}
+
 // index of entry lane L in the emission-table numbering of cnf2_lane.h (P<<5 | f<<4 | sp<<3 | u1<<2 | u0<<1 | t)
 CNF2_HD int path_entry_index(int L) { return (L & 0x38) | ((L & 2) << 1) | ((L & 1) << 1) | ((L >> 2) & 1); }
 
@@ -50,17 +98,37 @@ CNF2_HD double top_value(const Slot& d, int fa, int inmv, double sv)
     return bv + msv;
 }
 
-CNF2_HD void path_terms(const Window& w, const Slot slot[7], int L, const AccRoot& ar, PathTerms* T)
+// what a lane needs of the line it works on (P = its lane bit 5): data of the parent and its two parents at the marker,
+// their window flags and tie groups
+struct PathLine {
+    Slot     par, gpa, gpb;
+    uint32_t fl_par, fl_a, fl_b;
+    int8_t   tie_par, tie_a, tie_b;
+};
+CNF2_HD void path_line(const Window& w, const Slot slot[7], int P, PathLine* ln)
 {
-    const int P = L >> 5, fp = (L >> 3) & 1, t = (L >> 2) & 1, g1 = (L >> 1) & 1, g0 = L & 1;
+    ln->par = P ? slot[4] : slot[1];
+    ln->gpa = P ? slot[5] : slot[2];
+    ln->gpb = P ? slot[6] : slot[3];
+    ln->fl_par = P ? w.flags[4] : w.flags[1];
+    ln->fl_a   = P ? w.flags[5] : w.flags[2];
+    ln->fl_b   = P ? w.flags[6] : w.flags[3];
+    ln->tie_par = P ? w.tie[4] : w.tie[1];
+    ln->tie_a   = P ? w.tie[5] : w.tie[2];
+    ln->tie_b   = P ? w.tie[6] : w.tie[3];
+}
+
+CNF2_HD void path_terms(const PathLine& ln, int L, const PathRoot& ar, PathTerms* T)
+{
+    const int fp = (L >> 3) & 1, t = (L >> 2) & 1, g1 = (L >> 1) & 1, g0 = L & 1;
     const int fg = t ? g1 : g0, fo = t ? g0 : g1;
-    const uint32_t fl_par = P ? w.flags[4] : w.flags[1], fl_a = P ? w.flags[5] : w.flags[2], fl_b = P ? w.flags[6] : w.flags[3];
+    const uint32_t fl_par = ln.fl_par, fl_a = ln.fl_a, fl_b = ln.fl_b;
     const uint32_t fl_tr = t ? fl_b : fl_a, fl_ot = t ? fl_a : fl_b;
-    const Slot par = P ? slot[4] : slot[1], gpa = P ? slot[5] : slot[2], gpb = P ? slot[6] : slot[3];
-    const Slot tr = t ? gpb : gpa, ot = t ? gpa : gpb;
-    const int    inmv = P ? ar.R.inmv1 : ar.R.inmv0;
-    const double sv = P ? ar.R.sv1 : ar.R.sv0;
-    const double R0 = P ? ar.Rs[1][0] : ar.Rs[0][0], R1 = P ? ar.Rs[1][1] : ar.Rs[0][1];
+    const Slot& par = ln.par;
+    const Slot  tr = t ? ln.gpb : ln.gpa, ot = t ? ln.gpa : ln.gpb;
+    const int    inmv = ar.inmv;
+    const double sv = ar.sv;
+    const double R0 = ar.R0, R1 = ar.R1;
     const bool   par_present = (fl_par & SLOT_PRESENT) != 0, par_founder = (fl_par & SLOT_FOUNDER) != 0;
     const bool   general = par_present && !par_founder;
     const int    mf = fp ? par.a1 : par.a0, mo = fp ? par.a0 : par.a1;
@@ -82,11 +150,11 @@ CNF2_HD void path_terms(const Window& w, const Slot slot[7], int L, const AccRoo
         double bv, msv;
         int    mv;
         match_term(inmv, sv, mf, sf, &bv, &msv, &mv);
-        if (msv != 0.0) msv /= bv;                          // cnF2freq.cpp:1220
+        if (msv != 0.0) msv = path_div(msv, bv);             // cnF2freq.cpp:1220
         double ssv = 0.0, keep = 1.0;
         if (so != 0.0) {                                    // cnF2freq.cpp:1298-1302
             keep = 1.0 - so;
-            ssv  = so / (1.0 - so);
+            ssv  = path_div(so, 1.0 - so);
         }
         B = bv * keep;
         if (!(B != 0.0)) {                                  // cnF2freq.cpp:1271: nothing below a zero base
@@ -109,8 +177,9 @@ CNF2_HD void path_terms(const Window& w, const Slot slot[7], int L, const AccRoo
     T->term0 = live ? (B * OTm) * TRm : 0.0;
     const double l0 = pb0 * pt0, l1 = pb1 * pt1;
     const double den = R0 * l0 + R1 * l1;
-    T->w0 = (R0 * l0) / den;
-    T->w1 = (R1 * l1) / den;
+    const double inv = path_div(1.0, den);
+    T->w0 = (R0 * l0) * inv;
+    T->w1 = (R1 * l1) * inv;
     T->den_ok = den != 0.0;
     const bool trlive = live && TRm != 0.0;
     T->k0 = (trlive && pb0 != 0.0) ? (pb0 * OTm) * pt0 : 0.0;
@@ -119,14 +188,8 @@ CNF2_HD void path_terms(const Window& w, const Slot slot[7], int L, const AccRoo
              ((general && (fl_b & SLOT_PRESENT)) ? PO_G1 : 0) | ((general && (fl_tr & SLOT_PRESENT)) ? PO_TR : 0);
 }
 
-// E[a][u] of one slot of the line: phase weight at parity a ^ u (^ extra) times admissibility; [a == 0] for a slot
-// that is not walked as a slot of its own (missing, or below a parent that is the top of its line)
-CNF2_HD double path_weight(bool real, uint32_t fl, const Slot& d, int a, int u, int extra, int force)
-{
-    if (!real) return a == 0 ? 1.0 : 0.0;
-    return allele_ok(fl, a, u ^ extra, force) ? phase_weight(d, a ^ u ^ extra) : 0.0;
-}
-
+// E[a][u] of one slot of the line = its phase weight at parity a ^ u times its admissibility; [a == 0] for a slot that
+// is not walked as a slot of its own (missing, or below a parent that is the top of its line).
 // The three coefficients a lane needs per butterfly position: s = E[b][b] (own term in both directions),
 // f = E[!b][b] (partner's term, paths -> entries), r = E[b][!b] (partner's term, entries -> paths); b = the lane's bit.
 struct PathCoef {
@@ -135,27 +198,58 @@ struct PathCoef {
     double g1_s, g1_f, g1_r;
 };
 
-CNF2_HD void path_coef(const Window& w, const Slot slot[7], int L, int combo, bool no_ties, PathCoef* C)
+// Which value each of the nine coefficients takes -- 0: 0.0, 1: 1.0, 2 / 3: the slot's phase weight at phase 0 / 1 --
+// as 2-bit codes (par_s, par_f, par_r, g0_s, g0_f, g0_r, g1_s, g1_f, g1_r from bit 0 up).  Depends on the window, the
+// lane and the tie combination only: formed once per job where there are no tie groups.
+CNF2_HD int path_coef_code(bool real, uint32_t fl, int a, int okbit, int phase, int force)
 {
-    const int P = L >> 5, b3 = (L >> 3) & 1, t = (L >> 2) & 1, b1 = (L >> 1) & 1, b0 = L & 1;
-    const int sp = 1 + 3 * P;
-    const uint32_t fl_par = P ? w.flags[4] : w.flags[1], fl_a = P ? w.flags[5] : w.flags[2], fl_b = P ? w.flags[6] : w.flags[3];
-    const Slot par = P ? slot[4] : slot[1], gpa = P ? slot[5] : slot[2], gpb = P ? slot[6] : slot[3];
-    const bool par_present = (fl_par & SLOT_PRESENT) != 0, general = par_present && !(fl_par & SLOT_FOUNDER);
-    const int  force_par = no_ties ? -1 : tie_force(w.tie[sp], combo), force_a = no_ties ? -1 : tie_force(w.tie[sp + 1], combo),
-               force_b = no_ties ? -1 : tie_force(w.tie[sp + 2], combo);
+    if (!real) return a == 0 ? 1 : 0;
+    return allele_ok(fl, a, okbit, force) ? 2 + (phase & 1) : 0;
+}
+CNF2_HD uint32_t path_coef_plan(const PathLine& ln, int L, int combo, bool no_ties)
+{
+    const int b3 = (L >> 3) & 1, t = (L >> 2) & 1, b1 = (L >> 1) & 1, b0 = L & 1;
+    const bool par_present = (ln.fl_par & SLOT_PRESENT) != 0, general = par_present && !(ln.fl_par & SLOT_FOUNDER);
+    const int  force_par = no_ties ? -1 : tie_force(ln.tie_par, combo), force_a = no_ties ? -1 : tie_force(ln.tie_a, combo),
+               force_b = no_ties ? -1 : tie_force(ln.tie_b, combo);
+    const bool ra = general && (ln.fl_a & SLOT_PRESENT), rb = general && (ln.fl_b & SLOT_PRESENT);
+    uint32_t plan = 0;
     // parent: admissibility by fp ^ t, phase by fp ^ t ^ sp (cnF2freq.cpp:1227-1245 with the parent's localshift)
-    C->par_s = par_present ? (allele_ok(fl_par, b3, t, force_par) ? phase_weight(par, b3 ^ t ^ b3) : 0.0) : (b3 == 0 ? 1.0 : 0.0);
-    C->par_f = par_present ? (allele_ok(fl_par, b3 ^ 1, t, force_par) ? phase_weight(par, (b3 ^ 1) ^ t ^ b3) : 0.0)
-                           : ((b3 ^ 1) == 0 ? 1.0 : 0.0);
-    C->par_r = par_present ? (allele_ok(fl_par, b3, t, force_par) ? phase_weight(par, b3 ^ t ^ (b3 ^ 1)) : 0.0) : (b3 == 0 ? 1.0 : 0.0);
-    const bool ra = general && (fl_a & SLOT_PRESENT), rb = general && (fl_b & SLOT_PRESENT);
-    C->g0_s = path_weight(ra, fl_a, gpa, b0, b0, 0, force_a);
-    C->g0_f = path_weight(ra, fl_a, gpa, b0 ^ 1, b0, 0, force_a);
-    C->g0_r = path_weight(ra, fl_a, gpa, b0, b0 ^ 1, 0, force_a);
-    C->g1_s = path_weight(rb, fl_b, gpb, b1, b1, 0, force_b);
-    C->g1_f = path_weight(rb, fl_b, gpb, b1 ^ 1, b1, 0, force_b);
-    C->g1_r = path_weight(rb, fl_b, gpb, b1, b1 ^ 1, 0, force_b);
+    plan |= path_coef_code(par_present, ln.fl_par, b3, t, t, force_par) << 0;            // fp = sp = b3
+    plan |= path_coef_code(par_present, ln.fl_par, b3 ^ 1, t, t ^ 1, force_par) << 2;    // partner's fp, own sp
+    plan |= path_coef_code(par_present, ln.fl_par, b3, t, t ^ 1, force_par) << 4;        // own fp, partner's sp
+    // grandparents: admissibility and phase by g ^ u
+    plan |= path_coef_code(ra, ln.fl_a, b0, b0, 0, force_a) << 6;
+    plan |= path_coef_code(ra, ln.fl_a, b0 ^ 1, b0, 1, force_a) << 8;
+    plan |= path_coef_code(ra, ln.fl_a, b0, b0 ^ 1, 1, force_a) << 10;
+    plan |= path_coef_code(rb, ln.fl_b, b1, b1, 0, force_b) << 12;
+    plan |= path_coef_code(rb, ln.fl_b, b1 ^ 1, b1, 1, force_b) << 14;
+    plan |= path_coef_code(rb, ln.fl_b, b1, b1 ^ 1, 1, force_b) << 16;
+    return plan;
+}
+CNF2_HD double path_coef_value(uint32_t code, double q0, double q1)
+{
+    code &= 3;
+    return code == 0 ? 0.0 : (code == 1 ? 1.0 : (code == 2 ? q0 : q1));
+}
+CNF2_HD void path_coef_apply(uint32_t plan, const PathLine& ln, PathCoef* C)
+{
+    const double p0 = phase_weight(ln.par, 0), p1 = phase_weight(ln.par, 1);
+    const double a0 = phase_weight(ln.gpa, 0), a1 = phase_weight(ln.gpa, 1);
+    const double b0 = phase_weight(ln.gpb, 0), b1 = phase_weight(ln.gpb, 1);
+    C->par_s = path_coef_value(plan >> 0, p0, p1);
+    C->par_f = path_coef_value(plan >> 2, p0, p1);
+    C->par_r = path_coef_value(plan >> 4, p0, p1);
+    C->g0_s  = path_coef_value(plan >> 6, a0, a1);
+    C->g0_f  = path_coef_value(plan >> 8, a0, a1);
+    C->g0_r  = path_coef_value(plan >> 10, a0, a1);
+    C->g1_s  = path_coef_value(plan >> 12, b0, b1);
+    C->g1_f  = path_coef_value(plan >> 14, b0, b1);
+    C->g1_r  = path_coef_value(plan >> 16, b0, b1);
+}
+CNF2_HD void path_coef(const PathLine& ln, int L, int combo, bool no_ties, PathCoef* C)
+{
+    path_coef_apply(path_coef_plan(ln, L, combo, no_ties), ln, C);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -177,13 +271,20 @@ inline void acc_contract_paths(const Window& w, const Slot slot[7], const double
     AccRoot   ar[2];
     acc_root(slot[0], false, 0, &ar[0]);
     acc_root(slot[0], false, 1, &ar[1]);
+    PathLine  ln[2];
+    path_line(w, slot, 0, &ln[0]);
+    path_line(w, slot, 1, &ln[1]);
     PathTerms T[64];
-    for (int L = 0; L < 64; L++) path_terms(w, slot, L, ar[(L >> 4) & 1], &T[L]);
+    for (int L = 0; L < 64; L++) {
+        PathRoot pr;
+        path_root(slot[0], (L >> 4) & 1, L >> 5, &pr);
+        path_terms(ln[L >> 5], L, pr, &T[L]);
+    }
     for (int combo = 0; combo < n_combo; combo++) {
         PathCoef C[64];
         double   ps[64], pf[64], pr[64], as[64], af[64], ar_[64], bs[64], bf[64], br[64];
         for (int L = 0; L < 64; L++) {
-            path_coef(w, slot, L, combo, no_ties, &C[L]);
+            path_coef(ln[L >> 5], L, combo, no_ties, &C[L]);
             ps[L] = C[L].par_s, pf[L] = C[L].par_f, pr[L] = C[L].par_r;
             as[L] = C[L].g0_s, af[L] = C[L].g0_f, ar_[L] = C[L].g0_r;
             bs[L] = C[L].g1_s, bf[L] = C[L].g1_f, br[L] = C[L].g1_r;
@@ -286,8 +387,10 @@ inline void acc_contract_paths(const Window& w, const Slot slot[7], const double
             }
             if (P == 0) {
                 const double c0 = z0[L] * p.term0, c1 = z1[L] * p.term0;
-                if (c0 != 0.0) hz[0] += ar[f].hzscale[0] * (c0 * p.w0);
-                if (c1 != 0.0) hz[1] += ar[f].hzscale[1] * (c1 * p.w1);
+                PathRoot pr;
+                path_root(slot[0], f, 0, &pr);
+                if (c0 != 0.0) hz[0] += pr.hzscale0 * (c0 * p.w0);
+                if (c1 != 0.0) hz[1] += pr.hzscale1 * (c1 * p.w1);
             }
         }
     }

@@ -2505,19 +2505,22 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_ACC_MINBLOCKS) void acc_rows_kerne
 // ---------------------------------------------------------------------------------------------------
 #define APL_RT   0                 /* [64] restricted totals, emission-table numbering */
 #define APL_HT   64                /* [i][32] HOMOZYGOUS probe sums of the entries of line 1 */
-#define APL_VT   128               /* [f][s0][16] */
-#define APL_UT   192               /* [f][16] */
-#define APL_ZT   224               /* [f][i][16] */
-#define APL_RED  288               /* [12 kinds][8 groups] */
-#define APL_TW   384               /* [i][64] GENOS terms per path lane */
-#define APL_OUT  512               /* [44] */
-#define APL_LDS  560
+#define APL_VT   128               /* [f][s0][s2][16] partial sums of v */
+#define APL_ZT   256               /* [f][i][s0][s2][16] partial sums of z */
+#define APL_UT   512               /* [f][16] */
+#define APL_RED  544               /* [12 kinds][8 groups] */
+#define APL_TW   640               /* [i][64] GENOS terms per path lane */
+#define APL_OUT  768               /* [44] accumulators; [44..47] stay 0 (padding target of the gather lists) */
+#define APL_OFF  816               /* [64][8] int: gather list of every accumulator lane */
+#define APL_LDS  (816 + 256)
+#define APL_ZERO (APL_OUT + 44)
 
 template <int BIT>
 __device__ __forceinline__ double path_xchg(double v)
 {
     if (BIT == 0) return lane_xor1(v);
     if (BIT == 1) return lane_xor2(v);
+    if (BIT == 2) return lane_xor4(v);
     return lane_xor8(v);
 }
 template <int BIT>
@@ -2525,25 +2528,136 @@ __device__ __forceinline__ double path_stage(double v, double own, double other)
 {
     return own * v + other * path_xchg<BIT>(v);
 }
+// One halving step of a sum over lanes: of the pair (a, c) the lane keeps a (its bit BIT clear) or c (set) and adds
+// the partner's copy of the same one; N values become N / 2, each summed over the lane pair.
+template <int BIT>
+__device__ __forceinline__ double halve_pair(double a, double c, bool bit)
+{
+    const double keep = bit ? c : a, send = bit ? a : c;
+    return keep + path_xchg<BIT>(send);
+}
 
-__global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
+#ifndef CNF2_APL_TILE
+#define CNF2_APL_TILE 8            /* consecutive markers per wavefront (what depends on the window only is formed once) */
+#endif
+#ifndef CNF2_APL_MINBLOCKS
+#define CNF2_APL_MINBLOCKS 2   /* 3 needs <= 168 VGPRs: 92 B of scratch and no faster */
+#endif
+__global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kernel(AccParams q)
 {
     __shared__ double lds[CNF2_WAVES_PER_BLOCK][APL_LDS];
     const int lane = threadIdx.x & 63;
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int job  = blockIdx.x;
-    const int ml   = blockIdx.y * CNF2_WAVES_PER_BLOCK + wib;
+    const int ml0  = (blockIdx.y * CNF2_WAVES_PER_BLOCK + wib) * CNF2_APL_TILE;
     const KernelParams& p = q.kp;
     const Job jb = p.jobs[job];
     const int len = jb.last - jb.first + 1;
-    if (ml >= len) return;
-    const int    m  = jb.first + ml;
+    if (ml0 >= len) return;
     const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
     if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                     // cnF2freq.cpp:5403
     const Window w = p.windows[jb.ind];
     if (w.flags[0] & SLOT_FOUNDER) return;                                              // acc_rows_kernel's
     double* L = lds[wib];
+    const bool no_ties = (q.flags & KP_NO_TIES) != 0;
+    const int  n_combo = no_ties ? 1 : (1 << w.n_groups);
+    // consumer role of this lane (step 3): shift mode bits and low state bits
+    const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
+    // path / entry role (steps 1, 2, 4, 5): this lane's line and what it reads of the window
+    const int  P = lane >> 5, f = (lane >> 4) & 1, t = (lane >> 2) & 1;
+    const int  eidx = path_entry_index(lane), e4 = eidx & 15;
+    PathLine   ln;
+    ln.fl_par  = P ? w.flags[4] : w.flags[1];
+    ln.fl_a    = P ? w.flags[5] : w.flags[2];
+    ln.fl_b    = P ? w.flags[6] : w.flags[3];
+    ln.tie_par = P ? w.tie[4] : w.tie[1];
+    ln.tie_a   = P ? w.tie[5] : w.tie[2];
+    ln.tie_b   = P ? w.tie[6] : w.tie[3];
+    const int row_root = w.row[0] < 0 ? 0 : w.row[0];
+    int       row_par = P ? w.row[4] : w.row[1], row_a = P ? w.row[5] : w.row[2], row_b = P ? w.row[6] : w.row[3];
+    row_par = row_par < 0 ? 0 : row_par;
+    row_a   = row_a < 0 ? 0 : row_a;
+    row_b   = row_b < 0 ? 0 : row_b;
+    const uint32_t plan1 = path_coef_plan(ln, lane, 0, no_ties);
+    const uint32_t outflags = ((ln.fl_par & SLOT_PRESENT) ? PO_PAR : 0) |
+                              (((ln.fl_par & (SLOT_PRESENT | SLOT_FOUNDER)) == SLOT_PRESENT && (ln.fl_a & SLOT_PRESENT)) ? PO_G0 : 0) |
+                              (((ln.fl_par & (SLOT_PRESENT | SLOT_FOUNDER)) == SLOT_PRESENT && (ln.fl_b & SLOT_PRESENT)) ? PO_G1 : 0) |
+                              (((ln.fl_par & (SLOT_PRESENT | SLOT_FOUNDER)) == SLOT_PRESENT && ((t ? ln.fl_b : ln.fl_a) & SLOT_PRESENT)) ? PO_TR : 0);
+    // gather list of this lane as an accumulator (step 5): which 8-lane sums / GENOS terms it adds up
+    {
+        int* off = (int*)(L + APL_OFF) + lane * 8;
+        int  o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = APL_ZERO;
+        if (lane < 28) {
+            const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
+            const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
+            if (slotk == 0) {                                             // root: allele index f ^ P; group = P<<2 | f<<1 | fp
+                o[0] = APL_RED + i * 8 + (0 << 2 | ax << 1);
+                o[1] = APL_RED + i * 8 + (0 << 2 | ax << 1 | 1);
+                o[2] = APL_RED + i * 8 + (1 << 2 | (ax ^ 1) << 1);
+                o[3] = APL_RED + i * 8 + (1 << 2 | (ax ^ 1) << 1 | 1);
+            } else if (rel == 0) {                                        // parent: allele index fp
+                if ((PP ? w.flags[4] : w.flags[1]) & SLOT_PRESENT) {
+                    o[0] = APL_RED + i * 8 + (PP << 2 | 0 << 1 | ax);
+                    o[1] = APL_RED + i * 8 + (PP << 2 | 1 << 1 | ax);
+                }
+            } else {                                                      // grandparent rel - 1 as the traced one: allele index g
+                const int tt = rel - 1;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                             // over f, fp and the other grandparent's allele
+                    const int ff = k & 1, pp = (k >> 1) & 1, go = k >> 2;
+                    const int gg0 = tt ? go : ax, gg1 = tt ? ax : go;
+                    o[k] = APL_TW + i * 64 + (PP << 5 | ff << 4 | pp << 3 | tt << 2 | gg1 << 1 | gg0);
+                }
+            }
+        } else if (lane < 30) {
+            const int i = lane - 28;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = APL_RED + (2 + i) * 8 + k;
+        } else if (lane < 44) {
+            const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
+            const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
+            const int kind = 4 + (rel + 1) * 2 + ph;                      // root, parent, grandparent 0, grandparent 1
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = APL_RED + kind * 8 + PP * 4 + k;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) off[k] = o[k];
+        if (lane < 4) L[APL_ZERO + lane] = 0.0;
+    }
+    // per-locus reductions (step 6): what lanes 0-6 need of the window's members
+    const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
+    const int      kk = lane < 7 ? lane : 0;
+    const int      myrec = srec[kk];
+    int            mymask = 0, mask0 = 0;                                 // slots holding the same record as mine / as the root
+    {
+        const int r0 = srec[0];
+        for (int k2 = 0; k2 < 7; k2++) {
+            const int r2 = srec[k2];
+            if (r2 == myrec) mymask |= 1 << k2;
+            if (r2 == r0) mask0 |= 1 << k2;
+        }
+    }
+    const bool   myfirst = lane < 7 && myrec >= 0 && (mymask & ((1 << kk) - 1)) == 0;              // reltree: unique members
+    const Window* wmem = p.windows + jb.ind;                              // own member: read with the lane as index from memory
+    const int    myrow_raw = wmem->row[kk];
+    const int    myrow = myrow_raw < 0 ? 0 : myrow_raw;
+    const bool   mypresent = (wmem->flags[kk] & SLOT_PRESENT) != 0;
+    double       mynorm = 0.0;                                            // 2 / 2^occ * descendants (cnF2freq.cpp:3582-3587)
+    const double descf = (double)q.desc[srec[0]];
+    if (myfirst) {
+        // reltreeordered: the individual itself always, ancestors only when non-empty (cnF2freq.cpp:3111-3152)
+        const int occ = q.rec_empty[myrec] ? (mymask & 1) : __popc(mymask);
+        mynorm = 2.0;
+        for (int k2 = 0; k2 < occ; k2++) mynorm *= 0.5;
+        mynorm *= descf;
+    }
 
+  for (int mi = 0; mi < CNF2_APL_TILE; mi++) {
+    const int ml = ml0 + mi;
+    if (ml >= len) break;
+    const int m = jb.first + ml;
     double x[8];
     {
         const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
@@ -2554,39 +2668,34 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
             x[2 * k + 1] = v2.y;
         }
     }
-    Slot slot[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) slot[k] = load_slot(p, w.row[k] < 0 ? 0 : w.row[k], m);
-    const bool no_ties = (q.flags & KP_NO_TIES) != 0;
-    const int  n_combo = no_ties ? 1 : (1 << w.n_groups);
-    // consumer role of this lane (steps 3): shift mode bits and low state bits
-    const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
-    // path / entry role (steps 1, 2, 4, 5)
-    const int  P = lane >> 5, f = (lane >> 4) & 1, fp = (lane >> 3) & 1, t = (lane >> 2) & 1;
-    const int  eidx = path_entry_index(lane), e4 = eidx & 15;
+    const Slot root = load_slot(p, row_root, m);
+    ln.par = load_slot(p, row_par, m);
+    ln.gpa = load_slot(p, row_a, m);
+    ln.gpb = load_slot(p, row_b, m);
+    const Slot mine = load_slot(p, myrow, m);
     double     cf0, cf1, hzs0, hzs1;            // c_f(s0 of the consumer role) for f = 0, 1; HOMOZYGOUS scale of this lane's f
-    bool       live0, live1;
+    bool       live;
     PathTerms  T;
     {
-        AccRoot ar0, ar1;
-        acc_root(slot[0], false, 0, &ar0);
-        acc_root(slot[0], false, 1, &ar1);
-        live0 = ar0.live;
-        live1 = ar1.live;
-        cf0   = live0 ? (s0 ? ar0.cf[1] : ar0.cf[0]) : 0.0;
-        cf1   = live1 ? (s0 ? ar1.cf[1] : ar1.cf[0]) : 0.0;
-        hzs0  = f ? ar1.hzscale[0] : ar0.hzscale[0];
-        hzs1  = f ? ar1.hzscale[1] : ar0.hzscale[1];
-        if (f) path_terms(w, slot, lane, ar1, &T);
-        else path_terms(w, slot, lane, ar0, &T);
+        const double c0 = path_root_cbase(root, 0), c1 = path_root_cbase(root, 1);
+        const double p0 = phase_weight(root, 0), p1 = phase_weight(root, 1);
+        const bool   live0 = (c0 * p0 != 0.0) || (c0 * p1 != 0.0), live1 = (c1 * p0 != 0.0) || (c1 * p1 != 0.0);
+        cf0  = live0 ? c0 * (s0 ? p1 : p0) : 0.0;              // c_0(s0) = cbase_0 * phase weight(0 ^ s0)
+        cf1  = live1 ? c1 * (s0 ? p0 : p1) : 0.0;
+        live = f ? live1 : live0;
+        PathRoot pr;
+        path_root(root, f, P, &pr);
+        hzs0 = pr.hzscale0;
+        hzs1 = pr.hzscale1;
+        path_terms(ln, lane, pr, &T);
     }
-    const bool live = f ? live1 : live0;
     if (!live) T.term0 = T.k0 = T.k1 = 0.0;
+    wave_lds_fence();
     if (lane < 44) L[APL_OUT + lane] = 0.0;
 
     for (int combo = 0; combo < n_combo; combo++) {
         PathCoef C;
-        path_coef(w, slot, lane, combo, no_ties, &C);
+        path_coef_apply(n_combo == 1 ? plan1 : path_coef_plan(ln, lane, combo, no_ties), ln, &C);
         // ---- 2. paths -> entries
         wave_lds_fence();
         {
@@ -2609,49 +2718,56 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
         wave_lds_fence();
         const double Rmine = L[APL_RT + eidx];
         // ---- 3. partial contractions (lane = shift mode and low state bits, registers = high state bits)
-#pragma unroll
-        for (int ff = 0; ff < 2; ff++) {
-            const double  cf = ff ? cf1 : cf0;
-            const double* t1 = L + APL_RT + ((1 << 5) | (ff << 4) | (s2 << 3));          // line 1 entries of this chain
-            const double* h0 = L + APL_HT + ((ff << 4) | (s2 << 3));
-            const double* h1 = h0 + 32;
-            double tr = 0.0, th0 = 0.0, th1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const double cx = cf * x[j];
-                if (cx != 0.0) {
-                    tr += cx * t1[j];
-                    th0 += cx * h0[j];
-                    th1 += cx * h1[j];
-                }
-            }
-            tr += lane_xor32(tr);
-            th0 += lane_xor32(th0);
-            th1 += lane_xor32(th1);
-            th0 += lane_xor8(th0);
-            th1 += lane_xor8(th1);
+        {
             const int e0 = (s1 << 3) | lo;
-            if (s2 == 0) L[APL_VT + (ff * 2 + s0) * 16 + e0] = tr;
-            if (s2 == 0 && s0 == 0) {
-                L[APL_ZT + (ff * 2 + 0) * 16 + e0] = th0;
-                L[APL_ZT + (ff * 2 + 1) * 16 + e0] = th1;
-            }
-            const double r0 = L[APL_RT + ((0 << 5) | (ff << 4) | (s1 << 3) | lo)];
+            double    uu[16];                                             // [f][j]: this lane's terms of u
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const double cx = cf * x[j];
-                double       pj = (cx != 0.0) ? cx * r0 : 0.0;
-                pj = chain_sum(pj);
-                pj += lane_xor8(pj);
-                pj += lane_xor16(pj);
-                if ((lane & 31) == 0) L[APL_UT + ff * 16 + (s2 << 3) + j] = pj;
+            for (int ff = 0; ff < 2; ff++) {
+                const double  cf = ff ? cf1 : cf0;
+                const double* t1 = L + APL_RT + ((1 << 5) | (ff << 4) | (s2 << 3));      // line 1 entries of this chain
+                const double* h0 = L + APL_HT + ((ff << 4) | (s2 << 3));
+                const double* h1 = h0 + 32;
+                const double  r0 = cf * L[APL_RT + ((0 << 5) | (ff << 4) | (s1 << 3) | lo)];
+                double tr = 0.0, th0 = 0.0, th1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    tr  = fma(x[j], t1[j], tr);
+                    th0 = fma(x[j], h0[j], th0);
+                    th1 = fma(x[j], h1[j], th1);
+                    uu[ff * 8 + j] = x[j] * r0;
+                }
+                // v: still to be summed over s2; z: over s0 and s2 -- by the entry lanes that read them
+                L[APL_VT + ((ff * 2 + s0) * 2 + s2) * 16 + e0]            = cf * tr;
+                L[APL_ZT + (((ff * 2 + 0) * 2 + s0) * 2 + s2) * 16 + e0] = cf * th0;
+                L[APL_ZT + (((ff * 2 + 1) * 2 + s0) * 2 + s2) * 16 + e0] = cf * th1;
             }
+            // u[f][s2][j]: sum over the 32 lanes of this half (s0, s1, low bits), 16 values -> one per lane
+            double h8[8], h4[4], h2[2];
+#pragma unroll
+            for (int k = 0; k < 8; k++) h8[k] = halve_pair<0>(uu[2 * k], uu[2 * k + 1], (lane & 1) != 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) h4[k] = halve_pair<1>(h8[2 * k], h8[2 * k + 1], (lane & 2) != 0);
+#pragma unroll
+            for (int k = 0; k < 2; k++) h2[k] = halve_pair<2>(h4[2 * k], h4[2 * k + 1], (lane & 4) != 0);
+            double h1v = halve_pair<3>(h2[0], h2[1], (lane & 8) != 0);
+            h1v += lane_xor16(h1v);
+            // the lane holds index (f<<3 | j) = its low four lane bits
+            if ((lane & 16) == 0) L[APL_UT + ((lane >> 3) & 1) * 16 + (s2 << 3) + (lane & 7)] = h1v;
         }
         wave_lds_fence();
         // ---- 4. lane = entry: weights, then entries -> paths
-        const double v0 = L[APL_VT + (f * 2 + 0) * 16 + e4], v1 = L[APL_VT + (f * 2 + 1) * 16 + e4];
-        const double wt = P ? L[APL_UT + f * 16 + e4] : v0 + v1;
-        double z0 = P ? 0.0 : L[APL_ZT + (f * 2 + 0) * 16 + e4], z1 = P ? 0.0 : L[APL_ZT + (f * 2 + 1) * 16 + e4];
+        double v0, v1, wt, z0 = 0.0, z1 = 0.0;
+        {
+            const double* vt = L + APL_VT + (f * 2) * 2 * 16 + e4;
+            v0 = vt[0] + vt[16];
+            v1 = vt[32] + vt[48];
+            if (P == 0) {
+                const double* zt = L + APL_ZT + (f * 2) * 4 * 16 + e4;
+                z0 = (zt[0] + zt[16]) + (zt[32] + zt[48]);
+                z1 = (zt[64] + zt[80]) + (zt[96] + zt[112]);
+            }
+            wt = P ? L[APL_UT + f * 16 + e4] : v0 + v1;
+        }
         // HAPLOS of the root straight from the entries: phase f ^ s0 (cnF2freq.cpp:1227)
         double hr0 = 0.0, hr1 = 0.0;
         if (P == 0 && live) {
@@ -2685,16 +2801,16 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
             val[3] = (P == 0 && c1 != 0.0) ? hzs1 * (c1 * T.w1) : 0.0;
             val[4] = hr0;
             val[5] = hr1;
-            const double ps = (T.out & PO_PAR) ? mul0(T.term0, o_par_self) : 0.0, pp = (T.out & PO_PAR) ? mul0(T.term0, o_par_part) : 0.0;
+            const double ps = (outflags & PO_PAR) ? mul0(T.term0, o_par_self) : 0.0, pp = (outflags & PO_PAR) ? mul0(T.term0, o_par_part) : 0.0;
             val[6] = t ? pp : ps;
             val[7] = t ? ps : pp;
-            val[8]  = (T.out & PO_G0) ? mul0(T.term0, o_g0_self) : 0.0;
-            val[9]  = (T.out & PO_G0) ? mul0(T.term0, o_g0_part) : 0.0;
-            val[10] = (T.out & PO_G1) ? mul0(T.term0, o_g1_self) : 0.0;
-            val[11] = (T.out & PO_G1) ? mul0(T.term0, o_g1_part) : 0.0;
+            val[8]  = (outflags & PO_G0) ? mul0(T.term0, o_g0_self) : 0.0;
+            val[9]  = (outflags & PO_G0) ? mul0(T.term0, o_g0_part) : 0.0;
+            val[10] = (outflags & PO_G1) ? mul0(T.term0, o_g1_self) : 0.0;
+            val[11] = (outflags & PO_G1) ? mul0(T.term0, o_g1_part) : 0.0;
         }
-        L[APL_TW + lane]      = (T.out & PO_TR) ? val[0] : 0.0;
-        L[APL_TW + 64 + lane] = (T.out & PO_TR) ? val[1] : 0.0;
+        L[APL_TW + lane]      = (outflags & PO_TR) ? val[0] : 0.0;
+        L[APL_TW + 64 + lane] = (outflags & PO_TR) ? val[1] : 0.0;
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             // sum over lane bits 0-2 (g0, g1, t): xor1, xor2, then the pairing i <-> 7 - i finishes it
@@ -2706,47 +2822,58 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void acc_paths_kernel(AccParams q)
         }
         wave_lds_fence();
         if (lane < 44) {
-            double acc = 0.0;
-            const double* red = L + APL_RED;                              // group = P<<2 | f<<1 | fp
-            if (lane < 28) {
-                const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
-                if (slotk == 0) {                                         // root: allele index f ^ P
-                    acc = red[i * 8 + (0 << 2 | ax << 1)] + red[i * 8 + (0 << 2 | ax << 1 | 1)] +
-                          red[i * 8 + (1 << 2 | (ax ^ 1) << 1)] + red[i * 8 + (1 << 2 | (ax ^ 1) << 1 | 1)];
-                } else {
-                    const int PP = slotk >= 4, rel = slotk - (1 + 3 * PP);
-                    if (rel == 0) {                                       // parent: allele index fp
-                        if (w.flags[slotk] & SLOT_PRESENT) acc = red[i * 8 + (PP << 2 | 0 << 1 | ax)] + red[i * 8 + (PP << 2 | 1 << 1 | ax)];
-                    } else {                                              // grandparent rel - 1 as the traced one: allele index g
-                        const int tt = rel - 1;
-                        const double* tw = L + APL_TW + i * 64;
-                        for (int k = 0; k < 8; k++) {                     // over f, fp and the other grandparent's allele
-                            const int ff = k & 1, pp = (k >> 1) & 1, go = k >> 2;
-                            const int gg0 = tt ? go : ax, gg1 = tt ? ax : go;
-                            acc += tw[PP << 5 | ff << 4 | pp << 3 | tt << 2 | gg1 << 1 | gg0];
-                        }
-                    }
-                }
-            } else if (lane < 30) {
-                const int i = lane - 28;
-                acc = red[(2 + i) * 8 + 0] + red[(2 + i) * 8 + 1] + red[(2 + i) * 8 + 2] + red[(2 + i) * 8 + 3];
-            } else {
-                const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
-                const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
-                const int kind = 4 + (rel + 1) * 2 + ph;                  // root, parent, grandparent 0, grandparent 1
-                acc = red[kind * 8 + PP * 4 + 0] + red[kind * 8 + PP * 4 + 1] + red[kind * 8 + PP * 4 + 2] + red[kind * 8 + PP * 4 + 3];
-            }
+            const int* off = (const int*)(L + APL_OFF) + lane * 8;
+            double     acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += L[off[k]];
             L[APL_OUT + lane] += acc;
         }
     }
+    // ---- 6. per-locus reductions (cnF2freq.cpp:5876-5902, 3577-3616)
+    double* out = L + APL_OUT;
+    if (lane < 7) {
+        // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
+        const bool upd = mypresent && !(mine.a0 == mine.a1 && mine.s0 == mine.s1);
+        if (!upd) out[30 + kk * 2] = out[30 + kk * 2 + 1] = 0.0;
+    }
     wave_lds_fence();
-    acc_reduce_locus(q, jb, m, lane, L + APL_OUT);
+    double self0 = 0.0;
+    for (int mm = mask0; mm; mm &= mm - 1) {
+        const int k = __ffs(mm) - 1;
+        self0 += out[k * 4 + 0] + out[k * 4 + 1];
+    }
+    const double sum = 1.0 / self0;                                                                // cnF2freq.cpp:5880-5885
+    if (lane < 2) q.acc_hz[((size_t)jb.ind * p.n_markers + m) * 2 + lane] = out[28 + lane] * sum;
+    if (myfirst) {
+        double inf[4] = {0, 0, 0, 0}, h0 = 0.0, h1 = 0.0;
+        for (int mm = mymask; mm; mm &= mm - 1) {
+            const int k2 = __ffs(mm) - 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) inf[i] += out[k2 * 4 + i];
+            h0 += out[30 + k2 * 2];
+            h1 += out[30 + k2 * 2 + 1];
+        }
+        const double norm = sum * mynorm;
+        double*      dst = q.acc_inf + ((size_t)myrec * p.n_markers + m) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) atomicAdd(dst + i, inf[i] * norm);
+        if ((h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12) {                       // cnF2freq.cpp:3601-3616
+            const double md = (double)0.000005f;
+            const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+            const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+            atomicAdd(q.acc_hb + (size_t)myrec * p.n_markers + m, b1 / (b1 + b2) * descf);
+            atomicAdd(q.acc_hc + (size_t)myrec * p.n_markers + m, descf);
+        }
+    }
+  }
 }
 
 void launch_acc_rows(const AccParams& q, hipStream_t stream)
 {
     dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-    if (!(q.flags & KP_ACC_TABLE)) hipLaunchKernelGGL(acc_paths_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
+    const int per_block = CNF2_WAVES_PER_BLOCK * CNF2_APL_TILE;
+    dim3 gridp(q.n_jobs, (q.max_len + per_block - 1) / per_block);
+    if (!(q.flags & KP_ACC_TABLE)) hipLaunchKernelGGL(acc_paths_kernel, gridp, dim3(CNF2_BLOCK), 0, stream, q);
     if (q.flags & (KP_ACC_TABLE | KP_ACC_ATTOP)) hipLaunchKernelGGL(acc_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 

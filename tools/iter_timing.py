@@ -1,7 +1,7 @@
 """Measurement aid: one haplotyping iteration of BASELINE config 5's shape (3-generation outbred, 20 % missing) on one
 GPU, through the C ABI with everything device-resident: plain sweep, sweep + HOT LOOP 2 accumulators
 (cnf2_sweep_accumulate), the update passes of every chromosome.
-usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations]"""
+usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations] [scalefactor]"""
 import ctypes as C
 import os
 import sys
@@ -64,7 +64,7 @@ for rep in range(2):
 print("turn scan          %.3f s for %d individuals  %.3g units/s (%.1f x sweep per unit)   lse[0,0,0]=%.6f"
       % (t_turn, nt, nt * M / t_turn, (t_turn / (nt * M)) / (t_sweep / units), float(lse[0, 0, 0].item())), flush=True)
 del lse
-sf = 0.013
+sf = float(sys.argv[5]) if len(sys.argv) > 5 else 0.013
 for it in range(iters):
     t = time.time()
     ctx.sweep_accumulate_device(desc, 0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(), inf.data_ptr(),
