@@ -2695,7 +2695,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
 
     for (int combo = 0; combo < n_combo; combo++) {
         PathCoef C;
-        path_coef_apply(n_combo == 1 ? plan1 : path_coef_plan(ln, lane, combo, no_ties), ln, &C);
+        uint32_t plan = plan1;
+        if (__builtin_amdgcn_readfirstlane(n_combo) != 1) plan = path_coef_plan(ln, lane, combo, no_ties);
+        path_coef_apply(plan, ln, &C);
         // ---- 2. paths -> entries
         wave_lds_fence();
         {
@@ -2771,7 +2773,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
         // HAPLOS of the root straight from the entries: phase f ^ s0 (cnF2freq.cpp:1227)
         double hr0 = 0.0, hr1 = 0.0;
         if (P == 0 && live) {
-            const double a = mul0(Rmine, v0), b = mul0(Rmine, v1);
+            const double a = Rmine * v0, b = Rmine * v1;               // totals and weights are finite: plain products
             hr0 = f ? b : a;
             hr1 = f ? a : b;
         }
@@ -2801,13 +2803,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
             val[3] = (P == 0 && c1 != 0.0) ? hzs1 * (c1 * T.w1) : 0.0;
             val[4] = hr0;
             val[5] = hr1;
-            const double ps = (outflags & PO_PAR) ? mul0(T.term0, o_par_self) : 0.0, pp = (outflags & PO_PAR) ? mul0(T.term0, o_par_part) : 0.0;
+            const double tp = (outflags & PO_PAR) ? T.term0 : 0.0, ta = (outflags & PO_G0) ? T.term0 : 0.0, tb = (outflags & PO_G1) ? T.term0 : 0.0;
+            const double ps = tp * o_par_self, pp = tp * o_par_part;
             val[6] = t ? pp : ps;
             val[7] = t ? ps : pp;
-            val[8]  = (outflags & PO_G0) ? mul0(T.term0, o_g0_self) : 0.0;
-            val[9]  = (outflags & PO_G0) ? mul0(T.term0, o_g0_part) : 0.0;
-            val[10] = (outflags & PO_G1) ? mul0(T.term0, o_g1_self) : 0.0;
-            val[11] = (outflags & PO_G1) ? mul0(T.term0, o_g1_part) : 0.0;
+            val[8]  = ta * o_g0_self;
+            val[9]  = ta * o_g0_part;
+            val[10] = tb * o_g1_self;
+            val[11] = tb * o_g1_part;
         }
         L[APL_TW + lane]      = (outflags & PO_TR) ? val[0] : 0.0;
         L[APL_TW + 64 + lane] = (outflags & PO_TR) ? val[1] : 0.0;
