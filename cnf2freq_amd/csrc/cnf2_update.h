@@ -26,14 +26,6 @@
 #define CNF2_UHD inline
 #endif
 
-// host test builds count how many quadratures the screening settled (tests/shim)
-#ifdef CNF2_SCREEN_STATS
-extern long cnf2_screen_stats[2];
-#define CNF2_SCREEN_COUNT(i) (++cnf2_screen_stats[i])
-#else
-#define CNF2_SCREEN_COUNT(i) ((void)0)
-#endif
-
 namespace cnf2 {
 
 // maxdiff is a float in the reference (cnF2freq.cpp:228) and is promoted where it is used
@@ -83,97 +75,6 @@ CNF2_UHD double gauss15(F&& f, double a, double b)
     return half * acc;
 }
 
-// ------------------------------------------------------------------ single-precision screening of the quadrature
-// The bisection of flow_step() only asks of every quadrature value t: is |t - scalefactor| under the tolerance, and if
-// not, on which side is t.  Both gradients have the form
-//     G(x) = (a b L + (a - b) Q) / Q^2 + c0 + clg * L + (pr - x) / (x (1 - x)) * desc,   L = logit(x), Q = b (1-x) + a x
-// (degree 0 in (a, b): scaled to max(a, b) = 1 here), so the SAME 15 nodes can be evaluated in single precision with a
-// running bound on the rounding error of every term (u = 2^-24; the hardware logarithm and reciprocal are good to
-// about one unit in the last place, the bounds below allow several).  Where the answer to both questions is the same
-// for every value within the bound, the double-precision quadrature is skipped; anywhere else (a node where the terms
-// of G cancel, nodes of mixed sign, a value within the bound of the tolerance band) it is evaluated as before.  The
-// sequence of bisection decisions, and with it the result, is the one of the double-precision evaluation.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float screen_log(float x) { return __logf(x); }
-__device__ __forceinline__ float screen_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-inline float screen_log(float x) { return logf(x); }
-inline float screen_rcp(float x) { return 1.0f / x; }
-#endif
-
-struct Screen {
-    bool   on;
-    float  a, b, ab, amb;
-    float  c0, clg, desc;
-    double pr;
-};
-CNF2_UHD Screen screen_setup(double a, double b, double c0, double clg, double desc, double pr)
-{
-    Screen g;
-    const double m = a > b ? a : b;
-    g.on = m > 0.0 && isfinite(m) && isfinite(c0) && isfinite(clg) && fabs(c0) < 1e30 && fabs(clg) < 1e30;
-    const double sc = g.on ? 1.0 / m : 0.0;
-    const double as = a * sc, bs = b * sc;
-    g.a = (float)as;
-    g.b = (float)bs;
-    g.ab = (float)(as * bs);
-    g.amb = (float)(as - bs);
-    g.c0 = (float)c0;
-    g.clg = (float)clg;
-    g.desc = (float)desc;
-    g.pr = pr;
-    return g;
-}
-// 1 / G at v (already clamped): value and a bound on its relative error; false where no useful bound exists
-CNF2_UHD bool screen_pace(const Screen& g, double v, float* pace, float* rel)
-{
-    const float u = 5.9604645e-8f;                                  // 2^-24
-    const float x = (float)v, o = (float)(1.0 - v);
-    const float lx = screen_log(x), lo = screen_log(o);
-    const float lg = lx - lo;
-    const float e_lg = 4.0f * u * (1.0f + fabsf(lx) + fabsf(lo));
-    const float q = g.b * o + g.a * x;
-    const float t1 = g.ab * lg, t2 = g.amb * q;
-    const float rq2 = screen_rcp(q * q);
-    const float d1 = (t1 + t2) * rq2;
-    const float e_d1 = (g.ab * e_lg + 4.0f * u * fabsf(t1) + 8.0f * u * fabsf(t2)) * rq2 + 10.0f * u * fabsf(d1);
-    const float t3 = g.clg * lg;
-    float       d2 = g.c0 + t3;
-    float       e_d2 = fabsf(g.clg) * e_lg + 2.0f * u * (fabsf(g.c0) + fabsf(t3));
-    if (g.desc != 0.0f) {
-        const float h = (float)(g.pr - v) * screen_rcp(x * o) * g.desc;
-        d2 += h;
-        e_d2 += 8.0f * u * fabsf(h);
-    }
-    const float G = d1 + d2;
-    const float e_G = e_d1 + e_d2 + 2.0f * u * (fabsf(d1) + fabsf(d2));
-    *pace = screen_rcp(G);
-    *rel = e_G * fabsf(*pace) + 4.0f * u;
-    return fabsf(G) > 8.0f * e_G && fabsf(G) < 1e30f && fabsf(G) > 1e-30f;
-}
-// the 15-point rule over [a, b] on the screened integrand: value and a bound on its absolute error
-CNF2_UHD bool screen_gauss15(const Screen& g, double a, double b, double epsilon, double top, double* t, double* err)
-{
-    const double mid = (a + b) * 0.5, half = (b - a) * 0.5;
-    double acc = 0.0;
-    float  relmax = 0.0f;
-    bool   ok = true, neg = false;
-    for (int i = -7; i <= 7; i++) {
-        const int    k = i < 0 ? -i : i;
-        double       v = mid + half * (i < 0 ? -gl15_node(k) : gl15_node(k));
-        v = (v < epsilon) ? epsilon : ((top < v) ? top : v);
-        float pc, rel;
-        ok = screen_pace(g, v, &pc, &rel) && ok;
-        if (i == -7) neg = pc < 0.0f;
-        ok = ok && ((pc < 0.0f) == neg);
-        relmax = rel > relmax ? rel : relmax;
-        acc += (double)pc * gl15_weight(k);
-    }
-    *t = half * acc;
-    *err = 2.0 * fabs(*t) * (double)relmax;
-    return ok && isfinite(*t);
-}
-
 // ------------------------------------------------------------------ cap on one iteration's move
 // caplogitchange (cnF2freq.cpp:4006-4038) with nnn = 3: a value may rise by at most 2p(1-p)/(1+2p) and fall by at
 // most 2p(1-p)/(3-2p); a capped move that stays on the far side of 1/2 counts as a "hit" (the step-size control of
@@ -198,11 +99,9 @@ CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits
     return intended;
 }
 
-// cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): gradient(x) -> dp/dt at x.  scr: the same
-// gradient for the single-precision screening of the quadrature (scr.on = false: every quadrature in double precision).
+// cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): gradient(x) -> dp/dt at x.
 template <class G>
-CNF2_UHD double flow_step(G&& gradient, const Screen& scr, double orig, double epsilon, double scalefactor, int* hits,
-                          bool breakathalf)
+CNF2_UHD double flow_step(G&& gradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
 {
     const double top = 1.0 - epsilon;
     auto pace = [&](double v) -> double {          // dt/dp: reciprocal of the gradient at the clamped position
@@ -220,7 +119,6 @@ CNF2_UHD double flow_step(G&& gradient, const Screen& scr, double orig, double e
     const bool falling = g0 < 0;
     if (falling) hi = orig;
     else lo = orig;
-    const double tol = scalefactor * 1e-3;
     for (int it = 0; it < 51 && scalefactor; it++) {
         if (lo > hilim || hi < lolim) break;                 // outside the true bounds
         const double mid = (lo + hi) / 2;
@@ -236,25 +134,11 @@ CNF2_UHD double flow_step(G&& gradient, const Screen& scr, double orig, double e
                 b = s;
             }
             if (b - a < 1e-10) break;
-            bool   decided = false;
-            double ts, err;
-            if (scr.on && screen_gauss15(scr, a, b, epsilon, top, &ts, &err)) {
-                if (b != mid) ts = -ts;
-                const double d = fabs(ts - scalefactor);
-                // inside the tolerance band, or outside it on a known side, whatever the rounding did
-                decided = (d + err < tol) || (d - err > tol);
-            }
-            if (decided) {
-                CNF2_SCREEN_COUNT(0);
-                t = ts;
-            } else {
-                CNF2_SCREEN_COUNT(1);
-                t = gauss15(pace, a, b);
-                if (b != mid) t = -t;
-                if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
-            }
+            t = gauss15(pace, a, b);
+            if (b != mid) t = -t;
+            if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
         }
-        if (fabs(t - scalefactor) < tol) break;
+        if (fabs(t - scalefactor) < scalefactor * 1e-3) break;
         if ((t < scalefactor) != falling) lo = mid;
         else hi = mid;
     }
@@ -310,7 +194,6 @@ struct SideState {
 
 // Returns true when the side's allele / sure are to be overwritten with *new_allele / *new_sure
 // (cnF2freq.cpp:4303-4313: non-empty individuals that have a prior, i.e. that were genotyped).
-template <bool SCREEN = true>
 CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side, bool empty, bool has_prior,
                                int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure)
 {
@@ -342,9 +225,7 @@ CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side
             const double lg = logit(x);
             return evidence_slope(ev, x, lg) + ef * (priord - lg);   // data + entropy (log(1/x - 1)) + prior
         };
-        Screen scr = screen_setup(ev.a, ev.b, ef * priord, -ef, 0.0, 0.0);
-        if (!SCREEN) scr.on = false;
-        out[v] = flow_step(gradient, scr, curprob, epsilon, sc.scalefactor, hits, false);
+        out[v] = flow_step(gradient, curprob, epsilon, sc.scalefactor, hits, false);
     }
     int    best = 0;
     double bestprob = 0;
@@ -411,7 +292,6 @@ CNF2_UHD void phase_ratio(const double* hw, const double* relhaplo, int first, i
 // One marker of one individual whose chromosome has any information (some haplocount != 0) and whose weight is
 // neither 0 nor 1 (locked).  haplobase / haplocount are read AND rewritten (the reference leaves the adjusted
 // values in place, cnF2freq.cpp:4660-4676: they are what a later pass of the same iteration sees).
-template <bool SCREEN = true>
 CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0,
                                    double sure1, double phaseratio, int children, int descendants,
                                    const StepControl& sc, bool breakathalf, int* hits)
@@ -441,9 +321,7 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
         const double lg = logit(x);
         return evidence_slope(ev, x, lg) + ((phaseratio - x) / (x - x * x) * descendants - ent * lg);
     };
-    Screen scr = screen_setup(ev.a, ev.b, 0.0, -ent, (double)descendants, phaseratio);
-    if (!SCREEN) scr.on = false;
-    return flow_step(gradient, scr, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
+    return flow_step(gradient, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).

@@ -25,8 +25,6 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
     return P;
 }
 
-#define CNF2_SCREEN_STATS
-long cnf2_screen_stats[2] = {0, 0};
 #include "cnf2_update.h"
 #include "cnf2_variance.h"
 
@@ -349,30 +347,6 @@ int shim_update_certainty(const double* inf, int side, int allele, double sure, 
     cnf2::SideState s = {allele, sure, has_prior ? prior_allele : 0, prior_sure};
     cnf2::StepControl sc = {scalefactor, entropyfactor};
     return cnf2::update_certainty(inf, s, side, empty != 0, has_prior != 0, children, sc, hits, new_allele, new_sure) ? 1 : 0;
-}
-// the same with every quadrature in double precision (no single-precision screening)
-int shim_update_certainty_exact(const double* inf, int side, int allele, double sure, int has_prior, int prior_allele,
-                                double prior_sure, int empty, int children, double scalefactor, double entropyfactor,
-                                int* hits, int* new_allele, double* new_sure)
-{
-    cnf2::SideState s = {allele, sure, has_prior ? prior_allele : 0, prior_sure};
-    cnf2::StepControl sc = {scalefactor, entropyfactor};
-    return cnf2::update_certainty<false>(inf, s, side, empty != 0, has_prior != 0, children, sc, hits, new_allele, new_sure) ? 1 : 0;
-}
-double shim_update_haploweight_one(int exact, double hw, double* hb, double* hc, int a0, int a1, double s0, double s1,
-                                   double ratio, int children, int descendants, double scalefactor, double entropyfactor,
-                                   int* hits)
-{
-    cnf2::StepControl sc = {scalefactor, entropyfactor};
-    return exact ? cnf2::update_haploweight<false>(hw, hb, hc, a0, a1, s0, s1, ratio, children, descendants, sc, false, hits)
-                 : cnf2::update_haploweight<true>(hw, hb, hc, a0, a1, s0, s1, ratio, children, descendants, sc, false, hits);
-}
-// how many quadratures the screening settled / left to double precision since the last call (host build only)
-void shim_screen_stats(long* out)
-{
-    out[0] = cnf2_screen_stats[0];
-    out[1] = cnf2_screen_stats[1];
-    cnf2_screen_stats[0] = cnf2_screen_stats[1] = 0;
 }
 void shim_phase_ratio(const double* hw, const double* relhaplo, int first, int end, double* ratio)
 {

@@ -124,63 +124,6 @@ def test_certainty_update_matches_processinfprobs(shim):
     assert n_assigned > 300 and n_two > 100
 
 
-def test_single_precision_screening_never_changes_a_result(shim):
-    """flow_step() settles most bisection decisions from a single-precision evaluation of the 15 quadrature nodes with
-    an error bound, and falls back to double precision wherever the bound does not separate the value from the
-    tolerance band.  The decisions, hence the results and the hit counts, must be exactly those of the
-    all-double-precision evaluation: bit-identical on random certainties and haplotype weights, including saturated
-    values, tiny evidence, large step sizes."""
-    L = shim
-    L.shim_update_certainty_exact.argtypes = L.shim_update_certainty.argtypes
-    L.shim_update_certainty_exact.restype = C.c_int
-    L.shim_update_haploweight_one.argtypes = [C.c_int, D, C.c_void_p, C.c_void_p, C.c_int, C.c_int, D, D, D, C.c_int,
-                                              C.c_int, D, D, C.c_void_p]
-    L.shim_update_haploweight_one.restype = D
-    L.shim_screen_stats.argtypes = [C.c_void_p]
-    stats = np.zeros(2, np.int64)
-    L.shim_screen_stats(_p(stats))
-    rs = np.random.RandomState(11)
-    for it in range(6000):
-        inf = np.where(rs.rand(2) < 0.85, rs.gamma(1.0, 2.0, 2), 0.0) * float(rs.choice([1.0, 1e-3, 1e-12, 40.0]))
-        side = int(rs.randint(2))
-        allele = int(rs.choice([0, 1, 2]))
-        sure = float(rs.choice([0.02, 0.0, rs.uniform(0, 0.5), 5e-6, 1e-3, 0.4999]))
-        has_prior = int(rs.rand() < 0.8)
-        prior_allele = int(rs.choice([0, 1, 2]))
-        prior_sure = float(rs.choice([0.02, 0.0, 1.0, rs.uniform(0, 0.5), 1e-4]))
-        children = int(rs.randint(0, 4))
-        sf = float(rs.choice([0.013, 0.05, 0.19, 0.6, 1e-4]))
-        ef = float(rs.choice([1.0, 0.5]))
-        res = []
-        for fn in (L.shim_update_certainty, L.shim_update_certainty_exact):
-            h, na, ns = C.c_int(0), C.c_int(-1), D(-1.0)
-            r = fn(_p(inf), side, allele, sure, has_prior, prior_allele, prior_sure, 0, children, sf, ef, C.byref(h),
-                   C.byref(na), C.byref(ns))
-            res.append((r, h.value, na.value, ns.value))
-        assert res[0] == res[1], (it, res)
-    for it in range(6000):
-        hw = float(np.clip(rs.choice([0.5, 0.2, 0.8, 0.01, 0.99, 1e-5]) + rs.uniform(-0.005, 0.005), 1e-6, 1 - 1e-6))
-        hc = float(rs.choice([0.0, 1.0, 3.0, 7.5, 120.0]))
-        hb = hc * float(rs.uniform(0, 1))
-        a0, a1 = int(rs.choice([0, 1, 2])), int(rs.choice([0, 1, 2]))
-        s0, s1 = float(rs.choice([0.02, 0.0, 0.5, 0.3, 1e-4])), float(rs.choice([0.02, 0.0, 0.5, 0.3, 1e-4]))
-        ratio = float(rs.choice([hw, rs.uniform(0, 1), 0.5]))
-        children, desc = int(rs.randint(0, 5)), int(rs.randint(1, 9))
-        sf = float(rs.choice([0.013, 0.1, 0.19, 0.6]))
-        res = []
-        for exact in (0, 1):
-            b, c, h = np.array([hb]), np.array([hc]), C.c_int(0)
-            r = L.shim_update_haploweight_one(exact, hw, _p(b), _p(c), a0, a1, s0, s1, ratio, children, desc, sf, 1.0,
-                                              C.byref(h))
-            res.append((r, h.value, b[0], c[0]))
-        assert res[0] == res[1], (it, res)
-    L.shim_screen_stats(_p(stats))
-    # the screening must actually carry the load.  stats[1] = quadratures done in double precision = every quadrature
-    # of the exact runs (as many as the screened runs needed: stats[0] + fallbacks) + the fallbacks of the screened runs
-    fallbacks = (stats[1] - stats[0]) // 2
-    assert stats[0] > 50 * fallbacks > 0, stats
-
-
 def test_phase_ratio_matches_relskewhmm(shim):
     O = pyoracle.lib()
     rs = np.random.RandomState(4)
