@@ -1093,6 +1093,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 HIP_TRY(ctx, hipGetLastError());
                 q.kp     = p;
                 q.n_jobs = (int)nb;
+                q.flags  = (q.flags & ~(uint32_t)KP_ACC_LANES) | ((pass == 1 || (flags & CNF2_ACC_LANES)) ? KP_ACC_LANES : 0);
                 launch_acc_rows(q, ctx->stream);
                 HIP_TRY(ctx, hipGetLastError());
             }

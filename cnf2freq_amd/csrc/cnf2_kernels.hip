@@ -2871,12 +2871,384 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The path form once more, laid out like the sweep's tile producer (cnf2_accpath.h, "tile form"): a wavefront takes
+// 8 consecutive markers of a job at a time and
+//   A. lane = part x marker (part = P, f, traced grandparent): the match terms of its 8 paths, butterflies in
+//      registers, its 8 restricted totals (and HOMOZYGOUS probe sums) into the marker's table in LDS;
+//   B. marker by marker, lane = (shift mode, low state bits): the contractions v, u, z of the 512 posterior weights;
+//   C. lane = part x marker again: the weights of its 8 entries back to paths, the sums over its paths;
+//   D. lane = accumulator x marker: gathers over the parts; lane = window member x marker: the per-locus
+//      reductions of doit with f64 atomics.
+// A and C run once per 8 markers instead of once per marker: the per-path work of acc_paths_kernel divided by 8.
+// Two wavefronts per block (25 KB of LDS each: three blocks per CU).  Windows with tie groups (a loop over phase
+// combinations) stay with acc_paths_kernel.
+// ---------------------------------------------------------------------------------------------------
+#define APT_WAVES 2
+#ifndef CNF2_APT_TILES
+#define CNF2_APT_TILES 4           /* tiles (of 8 markers) per wavefront: amortises the per-job set-up */
+#endif
+#define APT_SSTRIDE 170            /* staging block of one marker: 8 parts x 21 (20 sums, odd stride) + a zero slot at 168 */
+#define APT_TAB   0                /* [mi][128]: R[64], H[i][32]; later the staging blocks [mi][APT_SSTRIDE] */
+#define APT_CF    1360             /* [mi][f][s0] */
+#define APT_VUZ   (APT_CF + 32)    /* [mi][160]: V[f][s0][16], U[f][16], Z[f][i][16] */
+#define APT_OUT   (APT_VUZ + 1280) /* [mi][48] */
+#define APT_LIST  (APT_OUT + 384)  /* int [44][4]: gather list of every accumulator (offsets inside a staging block) */
+#define APT_LDS   (APT_LIST + 88)
+
+__global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q)
+{
+    __shared__ double lds[APT_WAVES][APT_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job  = blockIdx.x;
+    const KernelParams& p = q.kp;
+    const Job jb = p.jobs[job];
+    const int len = jb.last - jb.first + 1;
+    const int ml_wave = (blockIdx.y * APT_WAVES + wib) * (8 * CNF2_APT_TILES);
+    if (ml_wave >= len) return;
+    const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom];
+    if (isnan(factor) || factor < (double)CNF2_MINFACTOR_F) return;                     // cnF2freq.cpp:5403
+    const Window w = p.windows[jb.ind];
+    if (w.flags[0] & SLOT_FOUNDER) return;                                              // acc_rows_kernel's
+    double* L = lds[wib];
+    const bool no_ties = (q.flags & KP_NO_TIES) != 0;
+    if (!no_ties && w.n_groups > 0) return;                                              // tie combinations: acc_paths_kernel's
+    // role B: shift mode bits and low state bits
+    const int  s = lane >> 3, s0 = s & 1, s1 = (s >> 1) & 1, s2 = (s >> 2) & 1, lo = state_lo(lane);
+    // roles A, C: part and marker of the tile
+    const int  part = lane >> 3, mi = lane & 7;
+    const int  P = part >> 2, f = (part >> 1) & 1, t = part & 1;
+    PathLine   ln;
+    ln.fl_par  = P ? w.flags[4] : w.flags[1];
+    ln.fl_a    = P ? w.flags[5] : w.flags[2];
+    ln.fl_b    = P ? w.flags[6] : w.flags[3];
+    ln.tie_par = P ? w.tie[4] : w.tie[1];
+    ln.tie_a   = P ? w.tie[5] : w.tie[2];
+    ln.tie_b   = P ? w.tie[6] : w.tie[3];
+    const int row_root = w.row[0] < 0 ? 0 : w.row[0];
+    int       row_par = P ? w.row[4] : w.row[1], row_a = P ? w.row[5] : w.row[2], row_b = P ? w.row[6] : w.row[3];
+    row_par = row_par < 0 ? 0 : row_par;
+    row_a   = row_a < 0 ? 0 : row_a;
+    row_b   = row_b < 0 ? 0 : row_b;
+    const uint32_t plan1 = path_mats_plan(ln, t, 0, no_ties);
+    const bool     general = (ln.fl_par & (SLOT_PRESENT | SLOT_FOUNDER)) == SLOT_PRESENT;
+    const bool     do_par = (ln.fl_par & SLOT_PRESENT) != 0;
+    const bool     do_tr = general && ((t ? ln.fl_b : ln.fl_a) & SLOT_PRESENT), do_ot = general && ((t ? ln.fl_a : ln.fl_b) & SLOT_PRESENT);
+    // where entry r = sp<<2 | b_ot<<1 | b_tr of this lane sits in the table: sp<<3 | u1<<2 | u0<<1 | t, the roles mapped
+    // to grandparents 0 / 1 by t (two per-job offsets, as in the sweep's tile producer)
+    const int      e_tr = t ? 4 : 2, e_ot = t ? 2 : 4;
+    // gather lists (role D): which staged sums every accumulator adds up; offsets inside a marker's staging block
+    if (lane < 44) {
+        int o4[4] = {168, 168, 168, 168};
+        if (lane < 28) {
+            const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
+            const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
+            if (slotk == 0) {                                             // root: allele index f ^ P
+                o4[0] = (0 << 2 | ax << 1 | 0) * 21 + i;
+                o4[1] = (0 << 2 | ax << 1 | 1) * 21 + i;
+                o4[2] = (1 << 2 | (ax ^ 1) << 1 | 0) * 21 + i;
+                o4[3] = (1 << 2 | (ax ^ 1) << 1 | 1) * 21 + i;
+            } else if (rel == 0) {                                        // parent: allele index fp
+#pragma unroll
+                for (int k = 0; k < 4; k++) o4[k] = (PP << 2 | k) * 21 + 2 + ax * 2 + i;
+            } else {                                                      // grandparent rel - 1 where it is the traced one
+#pragma unroll
+                for (int k = 0; k < 2; k++) o4[k] = (PP << 2 | k << 1 | (rel - 1)) * 21 + 6 + ax * 2 + i;
+            }
+        } else if (lane < 30) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) o4[k] = k * 21 + 10 + (lane - 28);
+        } else {
+            const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
+            const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
+#pragma unroll
+            for (int k = 0; k < 4; k++) o4[k] = (PP << 2 | k) * 21 + 12 + (rel + 1) * 2 + ph;
+        }
+        int* list = (int*)(L + APT_LIST) + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) list[k] = o4[k];
+    }
+    // role D, per-locus reductions: lane = member k x marker
+    const int      dk = lane >> 3;                                        // window slot 0-6 (7: idle)
+    const int32_t* srec = q.slot_rec + (size_t)jb.ind * 7;
+    const int      kk = dk < 7 ? dk : 0;
+    const int      myrec = srec[kk];
+    int            mymask = 0, mask0 = 0;                                 // slots holding the same record as mine / as the root
+    {
+        const int r0 = srec[0];
+        for (int k2 = 0; k2 < 7; k2++) {
+            const int r2 = srec[k2];
+            if (r2 == myrec) mymask |= 1 << k2;
+            if (r2 == r0) mask0 |= 1 << k2;
+        }
+    }
+    const bool    myfirst = dk < 7 && myrec >= 0 && (mymask & ((1 << kk) - 1)) == 0;             // reltree: unique members
+    const Window* wmem = p.windows + jb.ind;
+    const int     myrow_raw = wmem->row[kk];
+    const int     myrow = myrow_raw < 0 ? 0 : myrow_raw;
+    const bool    mypresent = (wmem->flags[kk] & SLOT_PRESENT) != 0;
+    const double  descf = (double)q.desc[srec[0]];
+    double        mynorm = 0.0;                                           // 2 / 2^occ * descendants (cnF2freq.cpp:3582-3587)
+    if (myfirst) {
+        // reltreeordered: the individual itself always, ancestors only when non-empty (cnF2freq.cpp:3111-3152)
+        const int occ = q.rec_empty[myrec] ? (mymask & 1) : __popc(mymask);
+        mynorm = 2.0;
+        for (int k2 = 0; k2 < occ; k2++) mynorm *= 0.5;
+        mynorm *= descf;
+    }
+
+    for (int tile = 0; tile < CNF2_APT_TILES; tile++) {
+        const int ml0 = ml_wave + tile * 8;
+        if (ml0 >= len) break;
+        const int nvalid = (len - ml0 < 8) ? len - ml0 : 8;
+        const int mlc = ml0 + (mi < nvalid ? mi : nvalid - 1);            // lanes beyond the chromosome redo its last marker
+        const int m = jb.first + mlc;
+        // ---- A. paths of this lane's part at its marker
+        const Slot root = load_slot(p, row_root, m);
+        ln.par = load_slot(p, row_par, m);
+        ln.gpa = load_slot(p, row_a, m);
+        ln.gpb = load_slot(p, row_b, m);
+        const Slot mine = load_slot(p, myrow, m);
+        PathTile T;
+        double   hzs0, hzs1;
+        {
+            const double cb = path_root_cbase(root, f);
+            const double c0 = cb * phase_weight(root, f ^ 0), c1 = cb * phase_weight(root, f ^ 1);      // c_f(s0 = 0), c_f(1)
+            const bool   live = (c0 != 0.0) || (c1 != 0.0);
+            PathRoot pr;
+            path_root(root, f, P, &pr);
+            hzs0 = pr.hzscale0;
+            hzs1 = pr.hzscale1;
+            path_terms8(ln, t, pr, &T);
+            if (!live) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) T.term0[r] = T.k0[r] = T.k1[r] = 0.0;
+            }
+            wave_lds_fence();                                             // the previous tile's readers are done
+            if ((part & 5) == 0) {                                        // P == 0, t == 0: one writer per f
+                L[APT_CF + mi * 4 + f * 2 + 0] = c0;
+                L[APT_CF + mi * 4 + f * 2 + 1] = c1;
+            }
+        }
+        {
+            PathMats M;
+            path_mats_apply(plan1, ln, t, &M);
+            {
+                double R[8], H0[8], H1[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    R[r]  = T.term0[r];
+                    H0[r] = T.k0[r];
+                    H1[r] = T.k1[r];
+                }
+                tile_fwd<0>(R, M.tr);
+                tile_fwd<1>(R, M.ot);
+                tile_fwd<2>(R, M.par);
+                double* tab = L + APT_TAB + mi * 128 + ((f << 4) | t);
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    tab[(P << 5) + ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0)] = R[r];
+                if (P) {
+                    tile_fwd<0>(H0, M.tr);
+                    tile_fwd<0>(H1, M.tr);
+                    tile_fwd<1>(H0, M.ot);
+                    tile_fwd<1>(H1, M.ot);
+                    tile_fwd<2>(H0, M.par);
+                    tile_fwd<2>(H1, M.par);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const int e3 = ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0);
+                        tab[64 + e3] = H0[r];
+                        tab[96 + e3] = H1[r];
+                    }
+                }
+            }
+            wave_lds_fence();
+            // ---- B. contractions, one marker at a time (every lane in the consumer role)
+            for (int mj = 0; mj < nvalid; mj++) {
+                double x[8];
+                {
+                    const double* wp = p.wbuf + ((size_t)job * p.wstride + (ml0 + mj)) * 512;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double2 v2 = *(const double2*)(wp + k * 128 + lane * 2);
+                        x[2 * k]     = v2.x;
+                        x[2 * k + 1] = v2.y;
+                    }
+                }
+                const double* tab = L + APT_TAB + mj * 128;
+                double*       vuz = L + APT_VUZ + mj * 160;
+                const int     e0 = (s1 << 3) | lo;
+                double        uu[16];
+#pragma unroll
+                for (int ff = 0; ff < 2; ff++) {
+                    const double  cf = L[APT_CF + mj * 4 + ff * 2 + s0];
+                    const double* t1 = tab + ((1 << 5) | (ff << 4) | (s2 << 3));          // line 1 entries of this chain
+                    const double* h0 = tab + 64 + ((ff << 4) | (s2 << 3));
+                    const double* h1 = h0 + 32;
+                    const double  r0 = cf * tab[(0 << 5) | (ff << 4) | (s1 << 3) | lo];
+                    double tr = 0.0, th0 = 0.0, th1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        tr  = fma(x[j], t1[j], tr);
+                        th0 = fma(x[j], h0[j], th0);
+                        th1 = fma(x[j], h1[j], th1);
+                        uu[ff * 8 + j] = x[j] * r0;
+                    }
+                    tr *= cf;
+                    th0 *= cf;
+                    th1 *= cf;
+                    // v: sum over s2 (lane bit 5); z: over s0 and s2 (lane bits 3, 5)
+                    tr += lane_xor32(tr);
+                    th0 += lane_xor32(th0);
+                    th1 += lane_xor32(th1);
+                    th0 += lane_xor8(th0);
+                    th1 += lane_xor8(th1);
+                    if (s2 == 0) vuz[(ff * 2 + s0) * 16 + e0] = tr;
+                    if (s2 == 0 && s0 == 0) {
+                        vuz[96 + (ff * 2 + 0) * 16 + e0] = th0;
+                        vuz[96 + (ff * 2 + 1) * 16 + e0] = th1;
+                    }
+                }
+                // u[f][s2][j]: sum over the 32 lanes of this half, 16 values -> one per lane (index = low four lane bits)
+                double h8[8], h4[4], h2[2];
+#pragma unroll
+                for (int k = 0; k < 8; k++) h8[k] = halve_pair<0>(uu[2 * k], uu[2 * k + 1], (lane & 1) != 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) h4[k] = halve_pair<1>(h8[2 * k], h8[2 * k + 1], (lane & 2) != 0);
+#pragma unroll
+                for (int k = 0; k < 2; k++) h2[k] = halve_pair<2>(h4[2 * k], h4[2 * k + 1], (lane & 4) != 0);
+                double h1v = halve_pair<3>(h2[0], h2[1], (lane & 8) != 0);
+                h1v += lane_xor16(h1v);
+                if ((lane & 16) == 0) vuz[64 + ((lane >> 3) & 1) * 16 + (s2 << 3) + (lane & 7)] = h1v;
+            }
+            wave_lds_fence();
+            // ---- C. the weights of this lane's entries, back to its paths
+            TileSums S;
+            double   hroot0 = 0.0, hroot1 = 0.0;
+            {
+                const double* vuz = L + APT_VUZ + mi * 160;
+                const double* tab = L + APT_TAB + mi * 128;
+                double wt[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int e4 = ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0) + t;
+                    if (P) {
+                        wt[r] = vuz[64 + f * 16 + e4];
+                    } else {
+                        const double v0 = vuz[(f * 2 + 0) * 16 + e4], v1 = vuz[(f * 2 + 1) * 16 + e4];
+                        wt[r] = v0 + v1;
+                        // HAPLOS of the root straight from the entries: phase f ^ s0 (cnF2freq.cpp:1227)
+                        const double Re = tab[(f << 4) | e4];
+                        const double a = Re * v0, b = Re * v1;
+                        hroot0 += f ? b : a;
+                        hroot1 += f ? a : b;
+                    }
+                }
+                tile_accumulate(T, M, t, wt, do_par, do_tr, do_ot, do_tr, &S);
+                S.hz[0] = S.hz[1] = 0.0;
+                if (P == 0) {
+                    double z[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        z[r] = vuz[96 + (f * 2 + 0) * 16 + ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0) + t];
+                    S.hz[0] = tile_homozyg(T, M, z, T.w0, hzs0);
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        z[r] = vuz[96 + (f * 2 + 1) * 16 + ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0) + t];
+                    S.hz[1] = tile_homozyg(T, M, z, T.w1, hzs1);
+                }
+            }
+            wave_lds_fence();                                             // tables and weights are read: stage over the tables
+            {
+                double* st = L + APT_TAB + mi * APT_SSTRIDE + part * 21;
+                st[0] = S.inf_root[0];
+                st[1] = S.inf_root[1];
+                st[2] = S.inf_par[0][0];
+                st[3] = S.inf_par[0][1];
+                st[4] = S.inf_par[1][0];
+                st[5] = S.inf_par[1][1];
+                st[6] = S.inf_tr[0][0];
+                st[7] = S.inf_tr[0][1];
+                st[8] = S.inf_tr[1][0];
+                st[9] = S.inf_tr[1][1];
+                st[10] = S.hz[0];
+                st[11] = S.hz[1];
+                st[12] = hroot0;
+                st[13] = hroot1;
+                st[14] = S.hap_par[0];
+                st[15] = S.hap_par[1];
+                st[t ? 18 : 16] = S.hap_tr[0];                          // traced = grandparent t
+                st[t ? 19 : 17] = S.hap_tr[1];
+                st[t ? 16 : 18] = S.hap_ot[0];
+                st[t ? 17 : 19] = S.hap_ot[1];
+                if (part == 0) L[APT_TAB + mi * APT_SSTRIDE + 168] = 0.0;
+            }
+            wave_lds_fence();
+            // ---- D1. lane = accumulator x marker
+#pragma unroll
+            for (int round = 0; round < 6; round++) {
+                const int o = (lane >> 3) + 8 * round;
+                if (o < 44) {
+                    const int*    list = (const int*)(L + APT_LIST) + o * 4;
+                    const double* st = L + APT_TAB + mi * APT_SSTRIDE;
+                    L[APT_OUT + mi * 48 + o] = (st[list[0]] + st[list[1]]) + (st[list[2]] + st[list[3]]);
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- D2. per-locus reductions (cnF2freq.cpp:5876-5902, 3577-3616): lane = window member x marker
+        double* out = L + APT_OUT + mi * 48;
+        const bool valid = mi < nvalid;
+        if (dk < 7) {
+            // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
+            const bool upd = mypresent && !(mine.a0 == mine.a1 && mine.s0 == mine.s1);
+            if (!upd) out[30 + kk * 2] = out[30 + kk * 2 + 1] = 0.0;
+        }
+        wave_lds_fence();
+        double self0 = 0.0;
+        for (int mm = mask0; mm; mm &= mm - 1) {
+            const int k = __ffs(mm) - 1;
+            self0 += out[k * 4 + 0] + out[k * 4 + 1];
+        }
+        const double sum = 1.0 / self0;                                                            // cnF2freq.cpp:5880-5885
+        if (valid && dk < 2) q.acc_hz[((size_t)jb.ind * p.n_markers + m) * 2 + dk] = out[28 + dk] * sum;
+        if (valid && myfirst) {
+            double inf[4] = {0, 0, 0, 0}, h0 = 0.0, h1 = 0.0;
+            for (int mm = mymask; mm; mm &= mm - 1) {
+                const int k2 = __ffs(mm) - 1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) inf[i] += out[k2 * 4 + i];
+                h0 += out[30 + k2 * 2];
+                h1 += out[30 + k2 * 2 + 1];
+            }
+            const double norm = sum * mynorm;
+            double*      dst = q.acc_inf + ((size_t)myrec * p.n_markers + m) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; i++) atomicAdd(dst + i, inf[i] * norm);
+            if ((h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12) {                   // cnF2freq.cpp:3601-3616
+                const double md = (double)0.000005f;
+                const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+                const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+                atomicAdd(q.acc_hb + (size_t)myrec * p.n_markers + m, b1 / (b1 + b2) * descf);
+                atomicAdd(q.acc_hc + (size_t)myrec * p.n_markers + m, descf);
+            }
+        }
+    }
+}
+
 void launch_acc_rows(const AccParams& q, hipStream_t stream)
 {
     dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
     const int per_block = CNF2_WAVES_PER_BLOCK * CNF2_APL_TILE;
     dim3 gridp(q.n_jobs, (q.max_len + per_block - 1) / per_block);
-    if (!(q.flags & KP_ACC_TABLE)) hipLaunchKernelGGL(acc_paths_kernel, gridp, dim3(CNF2_BLOCK), 0, stream, q);
+    const int per_block_t = APT_WAVES * 8 * CNF2_APT_TILES;
+    dim3 gridt(q.n_jobs, (q.max_len + per_block_t - 1) / per_block_t);
+    if (!(q.flags & KP_ACC_TABLE)) {
+        if (q.flags & KP_ACC_LANES) hipLaunchKernelGGL(acc_paths_kernel, gridp, dim3(CNF2_BLOCK), 0, stream, q);
+        else hipLaunchKernelGGL(acc_tile_kernel, gridt, dim3(64 * APT_WAVES), 0, stream, q);
+    }
     if (q.flags & (KP_ACC_TABLE | KP_ACC_ATTOP)) hipLaunchKernelGGL(acc_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 

@@ -65,6 +65,8 @@ enum {
                                     entry) instead of the path form (one lane per allele path of a line); same sums, the
                                     slower kernel -- kept as the cross-check of the fast one and for windows whose root
                                     is the top of its own lines, which always take it */
+    CNF2_ACC_LANES    = 1u << 11, /* cnf2_sweep_accumulate: path form with one lane per path for every window (the kernel that
+                                    windows with tie groups always take) instead of the tile form; A/B and cross-check */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same

@@ -279,7 +279,8 @@ int shim_acc_contract_paths(int n_rec, const int32_t* par, const uint8_t* empty,
     for (int k = 0; k < 28; k++) inf_out[k] = 0;
     for (int k = 0; k < 14; k++) hap_out[k] = 0;
     hz_out[0] = hz_out[1] = 0;
-    acc_contract_paths(w, slot, wg, no_ties != 0, inf_out, hz_out, hap_out);
+    if (no_ties & 2) acc_contract_tile(w, slot, wg, (no_ties & 1) != 0, inf_out, hz_out, hap_out);
+    else acc_contract_paths(w, slot, wg, (no_ties & 1) != 0, inf_out, hz_out, hap_out);
     for (int k = 0; k < 7; k++) {
         const bool upd = (w.flags[k] & SLOT_PRESENT) && !(slot[k].a0 == slot[k].a1 && slot[k].s0 == slot[k].s1);
         if (!upd) hap_out[k * 2] = hap_out[k * 2 + 1] = 0;

@@ -722,7 +722,7 @@ def test_half_spill_recompute_equals_full_spill(capi):
 
 def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
     """cnf2_sweep_accumulate (the product form of HOT LOOP 2: every individual and chromosome in batched launches,
-    path form of the accumulators, reductions with atomics on the device) against the oracle's accumulate
+    path form of the accumulators in its tile layout, reductions with atomics on the device) against the oracle's accumulate
     (pinned bit-exact on the reference's own moveinfprobs / movehaplos): advanced intercross with active ties
     (general kernel + tie combinations), outbred with missing data, and an F2 over three ragged chromosomes.
     The sweep outputs that come with it must be those of cnf2_sweep."""
@@ -753,6 +753,10 @@ def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
         tab = ctx.sweep_accumulate(desc, table_form=True)
         for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
             np.testing.assert_allclose(tab[k], got[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg="table form " + k)
+        # ... and the path form with one lane per path (the kernel of the windows with tie groups) on every window
+        lanes = ctx.sweep_accumulate(desc, lane_form=True)
+        for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+            np.testing.assert_allclose(lanes[k], got[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg="lane form " + k)
         # a sub-range of individuals gives that range's homozyg and (for disjoint windows) its share of the rest
         part = ctx.sweep_accumulate(desc, 1, 3)
         np.testing.assert_allclose(part["homozyg"], got["homozyg"][1:3], rtol=1e-12, atol=1e-15, equal_nan=True)

@@ -126,10 +126,12 @@ def test_restricted_class_split_reproduces_reference_rows(shim, seed):
     lambda: synth.make_f2(3, 6, 1, seed=5, chrom_cm=20.0, missing=0.2),
     lambda: synth.make_ail(4, 6, 3, 5, 1, seed=5, chrom_cm=20.0),
 ])
-def test_path_form_of_all_accumulators_matches_fanout(shim, maker):
+@pytest.mark.parametrize("form", [0, 2])
+def test_path_form_of_all_accumulators_matches_fanout(shim, maker, form):
     """cnf2_accpath.h (the accumulators as sums over the allele paths of a line, with the state bits entering through
     butterfly transforms of the entry weights: what the fast accumulate kernel evaluates, emulated here lane by lane)
-    against the oracle's brute-force fan-outs, and against the table form for the NaN pattern of homozyg."""
+    against the oracle's brute-force fan-outs.  form 0: one lane per path, butterflies across lanes; form 2: one lane
+    per (P, f, traced grandparent) with its 8 paths in registers (the kernel's tile form)."""
     ped = maker()
     o = oracle_ped(ped)
     checked = tied = 0
@@ -142,7 +144,7 @@ def test_path_form_of_all_accumulators_matches_fanout(shim, maker):
                 continue
             inf, hz, hap = np.zeros((7, 2, 2)), np.zeros(2), np.zeros((7, 2))
             ng = shim.shim_acc_contract_paths(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers,
-                                              int(ind), m, _p(np.ascontiguousarray(wg)), 0, _p(inf), _p(hz), _p(hap))
+                                              int(ind), m, _p(np.ascontiguousarray(wg)), form, _p(inf), _p(hz), _p(hap))
             if ng < 0:
                 continue
             want, want_hz = o.infprobs_row(int(ind), m, int(ped.gen[ind]))
