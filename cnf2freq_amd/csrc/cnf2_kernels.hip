@@ -2889,11 +2889,18 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
 #define CNF2_APT_TILES 4           /* tiles (of 8 markers) per wavefront: amortises the per-job set-up */
 #endif
 #define APT_SSTRIDE 170            /* staging block of one marker: 8 parts x 21 (20 sums, odd stride) + a zero slot at 168 */
-#define APT_TAB   0                /* [mi][128]: R[64], H[i][32]; later the staging blocks [mi][APT_SSTRIDE] */
+/* strides are padded so that the 8 markers of a tile (lane bits 0-2) fall into different LDS banks */
+#define APT_TSTRIDE 138            /* table of one marker: R of line 0 [0, 32), of line 1 [34, 66), H[0] [68, 100), H[1] [102, 134) */
+#define APT_R1    34
+#define APT_H0    68
+#define APT_H1    102
+#define APT_VSTRIDE 162            /* V[f][s0][16] at 0, U[f][16] at 64, Z[f][i][16] at 96 */
+#define APT_OSTRIDE 50
+#define APT_TAB   0                /* [mi][APT_TSTRIDE]; later the staging blocks [mi][APT_SSTRIDE] */
 #define APT_CF    1360             /* [mi][f][s0] */
-#define APT_VUZ   (APT_CF + 32)    /* [mi][160]: V[f][s0][16], U[f][16], Z[f][i][16] */
-#define APT_OUT   (APT_VUZ + 1280) /* [mi][48] */
-#define APT_LIST  (APT_OUT + 384)  /* int [44][4]: gather list of every accumulator (offsets inside a staging block) */
+#define APT_VUZ   (APT_CF + 32)    /* [mi][APT_VSTRIDE] */
+#define APT_OUT   APT_VUZ           /* [mi][APT_OSTRIDE]: over the weights, once they have been read */
+#define APT_LIST  (APT_VUZ + 8 * APT_VSTRIDE) /* int [44][4]: gather list of every accumulator (offsets inside a staging block) */
 #define APT_LDS   (APT_LIST + 88)
 
 __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q)
@@ -3045,10 +3052,10 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
                 tile_fwd<0>(R, M.tr);
                 tile_fwd<1>(R, M.ot);
                 tile_fwd<2>(R, M.par);
-                double* tab = L + APT_TAB + mi * 128 + ((f << 4) | t);
+                double* tab = L + APT_TAB + mi * APT_TSTRIDE + ((f << 4) | t);
 #pragma unroll
                 for (int r = 0; r < 8; r++)
-                    tab[(P << 5) + ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0)] = R[r];
+                    tab[(P ? APT_R1 : 0) + ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0)] = R[r];
                 if (P) {
                     tile_fwd<0>(H0, M.tr);
                     tile_fwd<0>(H1, M.tr);
@@ -3059,35 +3066,47 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
 #pragma unroll
                     for (int r = 0; r < 8; r++) {
                         const int e3 = ((r >> 2) << 3) + ((r & 2) ? e_ot : 0) + ((r & 1) ? e_tr : 0);
-                        tab[64 + e3] = H0[r];
-                        tab[96 + e3] = H1[r];
+                        tab[APT_H0 + e3] = H0[r];
+                        tab[APT_H1 + e3] = H1[r];
                     }
                 }
             }
             wave_lds_fence();
             // ---- B. contractions, one marker at a time (every lane in the consumer role)
+            double xn[8];                                                 // posterior weights of the next marker, in flight
+            {
+                const double* wp = p.wbuf + ((size_t)job * p.wstride + ml0) * 512;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double2 v2 = *(const double2*)(wp + k * 128 + lane * 2);
+                    xn[2 * k]     = v2.x;
+                    xn[2 * k + 1] = v2.y;
+                }
+            }
             for (int mj = 0; mj < nvalid; mj++) {
                 double x[8];
-                {
-                    const double* wp = p.wbuf + ((size_t)job * p.wstride + (ml0 + mj)) * 512;
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = xn[k];
+                if (mj + 1 < nvalid) {
+                    const double* wp = p.wbuf + ((size_t)job * p.wstride + (ml0 + mj + 1)) * 512;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const double2 v2 = *(const double2*)(wp + k * 128 + lane * 2);
-                        x[2 * k]     = v2.x;
-                        x[2 * k + 1] = v2.y;
+                        xn[2 * k]     = v2.x;
+                        xn[2 * k + 1] = v2.y;
                     }
                 }
-                const double* tab = L + APT_TAB + mj * 128;
-                double*       vuz = L + APT_VUZ + mj * 160;
+                const double* tab = L + APT_TAB + mj * APT_TSTRIDE;
+                double*       vuz = L + APT_VUZ + mj * APT_VSTRIDE;
                 const int     e0 = (s1 << 3) | lo;
                 double        uu[16];
 #pragma unroll
                 for (int ff = 0; ff < 2; ff++) {
                     const double  cf = L[APT_CF + mj * 4 + ff * 2 + s0];
-                    const double* t1 = tab + ((1 << 5) | (ff << 4) | (s2 << 3));          // line 1 entries of this chain
-                    const double* h0 = tab + 64 + ((ff << 4) | (s2 << 3));
-                    const double* h1 = h0 + 32;
-                    const double  r0 = cf * tab[(0 << 5) | (ff << 4) | (s1 << 3) | lo];
+                    const double* t1 = tab + APT_R1 + ((ff << 4) | (s2 << 3));            // line 1 entries of this chain
+                    const double* h0 = tab + APT_H0 + ((ff << 4) | (s2 << 3));
+                    const double* h1 = tab + APT_H1 + ((ff << 4) | (s2 << 3));
+                    const double  r0 = cf * tab[(ff << 4) | (s1 << 3) | lo];
                     double tr = 0.0, th0 = 0.0, th1 = 0.0;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
@@ -3111,7 +3130,10 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
                         vuz[96 + (ff * 2 + 1) * 16 + e0] = th1;
                     }
                 }
-                // u[f][s2][j]: sum over the 32 lanes of this half, 16 values -> one per lane (index = low four lane bits)
+                // u[f][s2][j]: sum over the 32 lanes of this half, 16 values -> one per lane (index = low four lane bits).
+                // (Measured alternatives: the weights read a second time in the transposed role, from memory or through
+                // LDS, so that u sums in registers: 20 % fewer VALU instructions, 3-9 % slower -- the kernel waits on
+                // dependent LDS / memory round trips at 1.5 waves per SIMD, not on the VALU.)
                 double h8[8], h4[4], h2[2];
 #pragma unroll
                 for (int k = 0; k < 8; k++) h8[k] = halve_pair<0>(uu[2 * k], uu[2 * k + 1], (lane & 1) != 0);
@@ -3128,8 +3150,8 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
             TileSums S;
             double   hroot0 = 0.0, hroot1 = 0.0;
             {
-                const double* vuz = L + APT_VUZ + mi * 160;
-                const double* tab = L + APT_TAB + mi * 128;
+                const double* vuz = L + APT_VUZ + mi * APT_VSTRIDE;
+                const double* tab = L + APT_TAB + mi * APT_TSTRIDE;
                 double wt[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
@@ -3193,13 +3215,13 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
                 if (o < 44) {
                     const int*    list = (const int*)(L + APT_LIST) + o * 4;
                     const double* st = L + APT_TAB + mi * APT_SSTRIDE;
-                    L[APT_OUT + mi * 48 + o] = (st[list[0]] + st[list[1]]) + (st[list[2]] + st[list[3]]);
+                    L[APT_OUT + mi * APT_OSTRIDE + o] = (st[list[0]] + st[list[1]]) + (st[list[2]] + st[list[3]]);
                 }
             }
         }
         wave_lds_fence();
         // ---- D2. per-locus reductions (cnF2freq.cpp:5876-5902, 3577-3616): lane = window member x marker
-        double* out = L + APT_OUT + mi * 48;
+        double* out = L + APT_OUT + mi * APT_OSTRIDE;
         const bool valid = mi < nvalid;
         if (dk < 7) {
             // doupdatehaplo (cnF2freq.cpp:1224-1239): nothing for a slot that is homozygous with equal sure here
