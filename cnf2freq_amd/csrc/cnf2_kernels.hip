@@ -2888,7 +2888,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
 #ifndef CNF2_APT_TILES
 #define CNF2_APT_TILES 4           /* tiles (of 8 markers) per wavefront: amortises the per-job set-up */
 #endif
-#define APT_SSTRIDE 170            /* staging block of one marker: 8 parts x 21 (20 sums, odd stride) + a zero slot at 168 */
+#define APT_SSTRIDE 110            /* staging block of one marker: 4 (P, f) x 17 (16 sums over t, odd stride), then 8 parts x 5 (the
+                                      traced grandparent's 4 infprobs sums) */
 /* strides are padded so that the 8 markers of a tile (lane bits 0-2) fall into different LDS banks */
 #define APT_TSTRIDE 138            /* table of one marker: R of line 0 [0, 32), of line 1 [34, 66), H[0] [68, 100), H[1] [102, 134) */
 #define APT_R1    34
@@ -2897,11 +2898,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
 #define APT_VSTRIDE 162            /* V[f][s0][16] at 0, U[f][16] at 64, Z[f][i][16] at 96 */
 #define APT_OSTRIDE 50
 #define APT_TAB   0                /* [mi][APT_TSTRIDE]; later the staging blocks [mi][APT_SSTRIDE] */
-#define APT_CF    1360             /* [mi][f][s0] */
+#define APT_CF    (8 * APT_TSTRIDE) /* [mi][f][s0] */
 #define APT_VUZ   (APT_CF + 32)    /* [mi][APT_VSTRIDE] */
 #define APT_OUT   APT_VUZ           /* [mi][APT_OSTRIDE]: over the weights, once they have been read */
-#define APT_LIST  (APT_VUZ + 8 * APT_VSTRIDE) /* int [44][4]: gather list of every accumulator (offsets inside a staging block) */
-#define APT_LDS   (APT_LIST + 88)
+#define APT_LIST  (APT_VUZ + 8 * APT_VSTRIDE) /* int [44][2]: the two staged sums every accumulator adds (offsets inside a staging block) */
+#define APT_LDS   (APT_LIST + 44)
 
 __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q)
 {
@@ -2945,36 +2946,36 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
     // where entry r = sp<<2 | b_ot<<1 | b_tr of this lane sits in the table: sp<<3 | u1<<2 | u0<<1 | t, the roles mapped
     // to grandparents 0 / 1 by t (two per-job offsets, as in the sweep's tile producer)
     const int      e_tr = t ? 4 : 2, e_ot = t ? 2 : 4;
-    // gather lists (role D): which staged sums every accumulator adds up; offsets inside a marker's staging block
+    // gather lists (role D): the two staged sums every accumulator adds up; offsets inside a marker's staging block
+    // ((P, f) block pf = P*2 + f at pf*17: 0-1 root infprobs [i], 2-5 parent [a][i], 6-7 homozyg [i], 8-9 HAPLOS of the root
+    // [phase], 10-11 of the parent, 12-13 / 14-15 of grandparent 0 / 1; part block at 68 + part*5: traced grandparent [a][i])
     if (lane < 44) {
-        int o4[4] = {168, 168, 168, 168};
+        int o2[2];
         if (lane < 28) {
             const int slotk = lane >> 2, ax = (lane >> 1) & 1, i = lane & 1;
             const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
             if (slotk == 0) {                                             // root: allele index f ^ P
-                o4[0] = (0 << 2 | ax << 1 | 0) * 21 + i;
-                o4[1] = (0 << 2 | ax << 1 | 1) * 21 + i;
-                o4[2] = (1 << 2 | (ax ^ 1) << 1 | 0) * 21 + i;
-                o4[3] = (1 << 2 | (ax ^ 1) << 1 | 1) * 21 + i;
+                o2[0] = (0 * 2 + ax) * 17 + i;
+                o2[1] = (1 * 2 + (ax ^ 1)) * 17 + i;
             } else if (rel == 0) {                                        // parent: allele index fp
-#pragma unroll
-                for (int k = 0; k < 4; k++) o4[k] = (PP << 2 | k) * 21 + 2 + ax * 2 + i;
+                o2[0] = (PP * 2 + 0) * 17 + 2 + ax * 2 + i;
+                o2[1] = (PP * 2 + 1) * 17 + 2 + ax * 2 + i;
             } else {                                                      // grandparent rel - 1 where it is the traced one
-#pragma unroll
-                for (int k = 0; k < 2; k++) o4[k] = (PP << 2 | k << 1 | (rel - 1)) * 21 + 6 + ax * 2 + i;
+                o2[0] = 68 + (PP << 2 | 0 << 1 | (rel - 1)) * 5 + ax * 2 + i;
+                o2[1] = 68 + (PP << 2 | 1 << 1 | (rel - 1)) * 5 + ax * 2 + i;
             }
         } else if (lane < 30) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) o4[k] = k * 21 + 10 + (lane - 28);
+            o2[0] = 0 * 17 + 6 + (lane - 28);
+            o2[1] = 1 * 17 + 6 + (lane - 28);
         } else {
             const int slotk = (lane - 30) >> 1, ph = (lane - 30) & 1;
             const int PP = slotk >= 4, rel = slotk == 0 ? -1 : slotk - (1 + 3 * PP);
-#pragma unroll
-            for (int k = 0; k < 4; k++) o4[k] = (PP << 2 | k) * 21 + 12 + (rel + 1) * 2 + ph;
+            o2[0] = (PP * 2 + 0) * 17 + 8 + (rel + 1) * 2 + ph;
+            o2[1] = (PP * 2 + 1) * 17 + 8 + (rel + 1) * 2 + ph;
         }
-        int* list = (int*)(L + APT_LIST) + lane * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) list[k] = o4[k];
+        int* list = (int*)(L + APT_LIST) + lane * 2;
+        list[0] = o2[0];
+        list[1] = o2[1];
     }
     // role D, per-locus reductions: lane = member k x marker
     const int      dk = lane >> 3;                                        // window slot 0-6 (7: idle)
@@ -3184,28 +3185,24 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
             }
             wave_lds_fence();                                             // tables and weights are read: stage over the tables
             {
-                double* st = L + APT_TAB + mi * APT_SSTRIDE + part * 21;
-                st[0] = S.inf_root[0];
-                st[1] = S.inf_root[1];
-                st[2] = S.inf_par[0][0];
-                st[3] = S.inf_par[0][1];
-                st[4] = S.inf_par[1][0];
-                st[5] = S.inf_par[1][1];
-                st[6] = S.inf_tr[0][0];
-                st[7] = S.inf_tr[0][1];
-                st[8] = S.inf_tr[1][0];
-                st[9] = S.inf_tr[1][1];
-                st[10] = S.hz[0];
-                st[11] = S.hz[1];
-                st[12] = hroot0;
-                st[13] = hroot1;
-                st[14] = S.hap_par[0];
-                st[15] = S.hap_par[1];
-                st[t ? 18 : 16] = S.hap_tr[0];                          // traced = grandparent t
-                st[t ? 19 : 17] = S.hap_tr[1];
-                st[t ? 16 : 18] = S.hap_ot[0];
-                st[t ? 17 : 19] = S.hap_ot[1];
-                if (part == 0) L[APT_TAB + mi * APT_SSTRIDE + 168] = 0.0;
+                // sums over the two traced grandparents of a (P, f) first (lane bit 3), then one writer per pair
+                double sv[16] = {S.inf_root[0], S.inf_root[1], S.inf_par[0][0], S.inf_par[0][1], S.inf_par[1][0], S.inf_par[1][1],
+                                 S.hz[0], S.hz[1], hroot0, hroot1, S.hap_par[0], S.hap_par[1],
+                                 t ? S.hap_ot[0] : S.hap_tr[0], t ? S.hap_ot[1] : S.hap_tr[1],        // grandparent 0: traced iff t == 0
+                                 t ? S.hap_tr[0] : S.hap_ot[0], t ? S.hap_tr[1] : S.hap_ot[1]};
+#pragma unroll
+                for (int k = 0; k < 16; k++) sv[k] += lane_xor8(sv[k]);
+                double* blk = L + APT_TAB + mi * APT_SSTRIDE;
+                if (t == 0) {
+                    double* st = blk + (part >> 1) * 17;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) st[k] = sv[k];
+                }
+                double* sp = blk + 68 + part * 5;
+                sp[0] = S.inf_tr[0][0];
+                sp[1] = S.inf_tr[0][1];
+                sp[2] = S.inf_tr[1][0];
+                sp[3] = S.inf_tr[1][1];
             }
             wave_lds_fence();
             // ---- D1. lane = accumulator x marker
@@ -3213,9 +3210,9 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
             for (int round = 0; round < 6; round++) {
                 const int o = (lane >> 3) + 8 * round;
                 if (o < 44) {
-                    const int*    list = (const int*)(L + APT_LIST) + o * 4;
+                    const int*    list = (const int*)(L + APT_LIST) + o * 2;
                     const double* st = L + APT_TAB + mi * APT_SSTRIDE;
-                    L[APT_OUT + mi * APT_OSTRIDE + o] = (st[list[0]] + st[list[1]]) + (st[list[2]] + st[list[3]]);
+                    L[APT_OUT + mi * APT_OSTRIDE + o] = st[list[0]] + st[list[1]];
                 }
             }
         }
