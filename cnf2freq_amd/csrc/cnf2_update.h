@@ -36,6 +36,22 @@ struct StepControl {
     double entropyfactor;   // cnF2freq.cpp:3574 (1)
 };
 
+// a / b inside the gradients: on the device a reciprocal with two Newton steps and a residual correction (the operands
+// are probabilities, evidence sums and their products: no denormals to scale for); 0 and non-finite divisors give a
+// non-finite quotient, which is all the callers test for.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double upd_div(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+#else
+inline double upd_div(double a, double b) { return a / b; }
+#endif
+
 // ------------------------------------------------------------------ 15-point Gauss-Legendre
 CNF2_UHD double gl15_node(int i)
 {
@@ -99,14 +115,15 @@ CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits
     return intended;
 }
 
-// cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): gradient(x) -> dp/dt at x.
+// cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): rgradient(x) -> dt/dp = 1 / (dp/dt) at x (the
+// callers form the reciprocal of their gradient as ONE quotient).
 template <class G>
-CNF2_UHD double flow_step(G&& gradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
+CNF2_UHD double flow_step(G&& rgradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
 {
     const double top = 1.0 - epsilon;
-    auto pace = [&](double v) -> double {          // dt/dp: reciprocal of the gradient at the clamped position
+    auto pace = [&](double v) -> double {          // dt/dp at the clamped position
         v = (v < epsilon) ? epsilon : ((top < v) ? top : v);
-        return 1.0 / gradient(v);
+        return rgradient(v);
     };
     int          ignored = 0;
     // bisection bracket: slightly wider than the cap, so that the final cap_step is the one that counts the hit
@@ -169,7 +186,7 @@ CNF2_UHD Evidence evidence_terms(double y, double g, double h)
 }
 CNF2_UHD double logit(double x)
 {
-    return log(x / (1.0 - x));
+    return log(upd_div(x, 1.0 - x));
 }
 CNF2_UHD double evidence_slope(const Evidence& e, double x, double lg)
 {
@@ -221,11 +238,13 @@ CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side
             }
         }
         const Evidence ev = evidence_terms(curprob, evidence, sum);
-        auto gradient = [&](double x) -> double {
+        // gradient = data + entropy (log(1/x - 1) = -logit) + prior = (N + Q^2 E) / Q^2; its reciprocal as one quotient
+        auto rgradient = [&](double x) -> double {
             const double lg = logit(x);
-            return evidence_slope(ev, x, lg) + ef * (priord - lg);   // data + entropy (log(1/x - 1)) + prior
+            const double q = ev.b * (1.0 - x) + ev.a * x, q2 = q * q;
+            return upd_div(q2, (ev.ab * lg + ev.amb * q) + q2 * (ef * (priord - lg)));
         };
-        out[v] = flow_step(gradient, curprob, epsilon, sc.scalefactor, hits, false);
+        out[v] = flow_step(rgradient, curprob, epsilon, sc.scalefactor, hits, false);
     }
     int    best = 0;
     double bestprob = 0;
@@ -317,11 +336,14 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
     const double b = *haplobase, c = *haplocount;
     const Evidence ev = evidence_terms(hw, b, c);
     const double   ent = (1 - similarity) * ef;
-    auto gradient = [&](double x) -> double {
+    // gradient = data + phase consistency + entropy = (N + Q^2 E) / Q^2; its reciprocal as one quotient
+    auto rgradient = [&](double x) -> double {
         const double lg = logit(x);
-        return evidence_slope(ev, x, lg) + ((phaseratio - x) / (x - x * x) * descendants - ent * lg);
+        const double q = ev.b * (1.0 - x) + ev.a * x, q2 = q * q;
+        const double e = upd_div(phaseratio - x, x - x * x) * descendants - ent * lg;
+        return upd_div(q2, (ev.ab * lg + ev.amb * q) + q2 * e);
     };
-    return flow_step(gradient, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
+    return flow_step(rgradient, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).

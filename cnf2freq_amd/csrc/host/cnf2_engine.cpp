@@ -1,5 +1,6 @@
 // cnf2_engine.cpp -- see cnf2_engine.h.
 #include "cnf2_engine.h"
+#include <chrono>
 
 #include <math.h>
 #include <stdlib.h>
@@ -337,6 +338,15 @@ bool Engine::deserialize(const char* path)
 
 void Engine::iteration(FILE* out)
 {
+    // CNF2_TIMING=1: wall-clock of the steps of an iteration on stderr (tuning aid)
+    const bool timing = getenv("CNF2_TIMING") != nullptr;
+    auto       t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  [iteration] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     const int R = (int)P.inds.size();
     // children = analysed children of every individual (cnF2freq.cpp:5222-5260)
     std::fill(children_.begin(), children_.end(), 0);
@@ -362,6 +372,7 @@ void Engine::iteration(FILE* out)
                              (opt.merge_modes ? CNF2_MERGE_MODES : 0) | rowflag),
                   "cnf2_sweep");
     }
+    lap("sweep + accumulators");
     for (int c = 0; c < C; c++) {
         if (!opt.quiet)
             for (int j = 0; j < N; j++) {
@@ -384,6 +395,7 @@ void Engine::iteration(FILE* out)
             fprintf(out, "\n");
         }
         fflush(out);
+        lap("likelihood lines / rows");
         if (!opt.update || N == 0) continue;
         // cnF2freq.cpp:6232-6392: the update pass after this chromosome
         if (opt.print_rows)
@@ -404,6 +416,7 @@ void Engine::iteration(FILE* out)
         oldhits_  = hits;
         last_hits_ = hits;
         fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
+        lap("update pass");
     }
     if (opt.update && N > 0) rows_stale_ = true;
 }
