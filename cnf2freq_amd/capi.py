@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("CNF2HIP_LIB") or os.path.join(_HERE, "libcnf2hip.so")
 OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE, ACC_KEEP, XPOSE, LOG_PATHS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 ACC_TABLE = 1024
 ACC_LANES = 2048
+TIES_GENERAL = 4096
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -177,7 +178,7 @@ class Context:
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
-              merge_modes=False, xpose=False, log_paths=False):
+              merge_modes=False, xpose=False, log_paths=False, ties_general=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
@@ -185,7 +186,7 @@ class Context:
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
         flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
                  | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0)
-                 | (LOG_PATHS if log_paths else 0))
+                 | (LOG_PATHS if log_paths else 0) | (TIES_GENERAL if ties_general else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
         out = dict(factors=factors, loglik=loglik, dosage=dos)
@@ -286,7 +287,8 @@ class Context:
                                          0 if ties else NO_TIES), "cnf2_accumulate")
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
-    def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False, table_form=False, lane_form=False):
+    def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False, table_form=False, lane_form=False,
+                         ties_general=False):
         """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
@@ -301,7 +303,8 @@ class Context:
         self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(factors), _p(loglik), _p(dos),
                                                _p(inf), _p(hb), _p(hc), _p(hz),
                                                (0 if ties else NO_TIES) | (RAW_DOSAGE if raw else 0)
-                                               | (ACC_TABLE if table_form else 0) | (ACC_LANES if lane_form else 0)),
+                                               | (ACC_TABLE if table_form else 0) | (ACC_LANES if lane_form else 0)
+                                               | (TIES_GENERAL if ties_general else 0)),
                   "cnf2_sweep_accumulate")
         return dict(factors=factors, loglik=loglik, dosage=dos, infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 

@@ -694,7 +694,10 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         p.jobs   = ctx->d_jobs + n_fast;
         p.n_jobs = (int)n_general;
         p.spill  = ctx->d_spill + (size_t)((n_fast > 0 || n_packed > 0) ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
-        launch_fb(p, grid_gen, false, ctx->stream2);
+        // tied windows: the tile-producer kernel with a pass per tie combination; the general kernel (one lane per table
+        // entry, per-marker producer) with the full spill and where asked for
+        if ((flags & CNF2_FULL_SPILL) || (flags & CNF2_TIES_GENERAL)) launch_fb(p, grid_gen, false, ctx->stream2);
+        else launch_fb_fast_tied(p, grid_gen, ctx->stream2);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2, 0));
@@ -1089,7 +1092,8 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 int grid = (int)((nb + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
                 if (grid > grid_cap) grid = grid_cap;
                 if (pass == 0) launch_fb_fast_w(p, grid, ctx->stream);
-                else launch_fb_w(p, grid, ctx->stream);
+                else if (flags & CNF2_TIES_GENERAL) launch_fb_w(p, grid, ctx->stream);
+                else launch_fb_fast_tied_w(p, grid, ctx->stream);
                 HIP_TRY(ctx, hipGetLastError());
                 q.kp     = p;
                 q.n_jobs = (int)nb;

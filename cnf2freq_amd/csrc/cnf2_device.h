@@ -72,7 +72,7 @@ struct KernelParams {
     // class, 32 | homleaf = packed kernel, 64 = general kernel; NULL = not recorded
     int32_t*       path_log;
 };
-enum { PATH_PACKED = 32, PATH_GENERAL = 64 };
+enum { PATH_TIED = 16, PATH_PACKED = 32, PATH_GENERAL = 64 };
 
 // Inputs of the batched HOT LOOP 2 kernel (acc_rows_kernel): the weights a STOREW sweep left for `n_jobs` jobs and
 // where the per-record accumulators live.  After every locus the reference scales homozyg, then moveinfprobs /
@@ -92,6 +92,8 @@ struct AccParams {
     double*        acc_hz;       // [n_ind][n_markers][2] homozyg of the analysed individual (offset like windows)
 };
 void launch_acc_rows(const AccParams& q, hipStream_t stream);
+void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream);
+void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream);
 
 // Inputs of the per-iteration update kernels (cnf2_update.h): what doit does after the sweep of chromosome `chrom`
 // (cnF2freq.cpp:6232-6392): processinfprobs for the markers of that chromosome, updatehaploweights for every marker

@@ -34,6 +34,9 @@ struct PartCfg {
     uint32_t par, tr, ot;   // SLOT_* flags of the parent, the traced and the other grandparent
     int      P, f, firstpar;
     bool     root_attop;
+    // TIES only: ignoreflag2's all-or-none rule for the tie combination at hand (cnF2freq.cpp:3484-3486): -1 free, else
+    // only alleles with (allele index ^ the slot's firstpar bit) == force survive in the restricted tables
+    int      force_par = -1, force_tr = -1, force_ot = -1;
 };
 
 // Affine match term: value contributed before the phase weight is  Bv + C + K * sv,
@@ -131,13 +134,14 @@ struct SlotTable {
 struct Leaf {
     double p0[2][2], p1[2][2];
     double m1, i2[2];
+    double mk[2][2];        // TIES: [fg][bit] 0/1 admissibility of allele fg under state bit `bit` (restriction and tie rule)
 };
 
 // HOMLEAF: the caller guarantees that the slot is present and homozygous with equal sure at this marker: both
 // allele indices match the incoming value alike, so one match is evaluated (its weights are 0/1, the sums over
 // fg keep their bits).
-template <bool HOMLEAF = false, class View>
-CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Leaf* L)
+template <bool HOMLEAF = false, bool TIES = false, class View>
+CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Leaf* L, int force = -1)
 {
     const bool present = (flags & SLOT_PRESENT) != 0;
     const bool r0      = (flags & SLOT_RESTRICT0) != 0;
@@ -169,14 +173,26 @@ CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Le
     L->m1    = (present && r0) ? 0.0 : 1.0;
     L->i2[0] = (present ? d.allele(0) == 2 : parent_is2) ? 1.0 : 0.0;
     L->i2[1] = (present && d.allele(1) == 2 && !r0) ? 1.0 : 0.0;
+    if (TIES) {
+#pragma unroll
+        for (int fg = 0; fg < 2; fg++)
+#pragma unroll
+            for (int bit = 0; bit < 2; bit++)
+                L->mk[fg][bit] = (present && ((r0 && fg == 1) || (force >= 0 && ((fg ^ bit) & 1) != force))) ? 0.0 : 1.0;
+    }
 }
 
 // (V0, V1) of the leaf for state bit `bit`; kind 0 = all alleles, 1 = restricted, 2 = class-2 part of restricted
+template <bool TIES = false>
 CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1)
 {
     if (kind == 0) {
         *v0 = L.p0[0][bit] + L.p0[1][bit];
         *v1 = L.p1[0][bit] + L.p1[1][bit];
+    } else if (TIES) {
+        const double a = (kind == 2 ? L.i2[0] : 1.0) * L.mk[0][bit], b = (kind == 2 ? L.i2[1] : 1.0) * L.mk[1][bit];
+        *v0 = a * L.p0[0][bit] + b * L.p0[1][bit];
+        *v1 = a * L.p1[0][bit] + b * L.p1[1][bit];
     } else if (kind == 1) {
         *v0 = L.p0[0][bit] + L.m1 * L.p0[1][bit];
         *v1 = L.p1[0][bit] + L.m1 * L.p1[1][bit];
@@ -196,10 +212,12 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // weights are 0/1, so  wl0 * h + w1 * h  ==  (wl0 + w1) * h  bit for bit).
 // NORESTR: the caller guarantees that no slot of the window is restricted (flag2ignore == 0, a complete
 // window): the restricted table is the unrestricted one, bit for bit, and is copied instead of recomputed.
-template <bool CLASSES, bool HOMPAR, bool HOMLEAF, bool NORESTR, class VR, class VP, class VT, class VO, class Out>
+// TIES: the restricted tables (kinds 1, 2) are those of the tie combination c.force_* (line_restricted() with forces).
+template <bool CLASSES, bool HOMPAR, bool HOMLEAF, bool NORESTR, bool TIES = false, class VR, class VP, class VT, class VO, class Out>
 CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
                               Out&& out, double cw[2])
 {
+    static_assert(!TIES || (!HOMPAR && !HOMLEAF && !NORESTR), "tie combinations take the general form");
     constexpr int NFP = HOMPAR ? 1 : 2;
     // ---- root (cnF2freq.cpp:1191-1245 at genwidth 4, inmarkerval unknown)
     const int    mf = root.allele(c.f), mo = root.allele(c.f ^ 1);
@@ -230,6 +248,12 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     const bool par_founder = (c.par & SLOT_FOUNDER) != 0;
     const bool par_r0      = (c.par & SLOT_RESTRICT0) != 0;
     const bool rootcls     = (c.P == 0 && mf == 2);
+    // admissibility of the parent's allele fp in the restricted tables (cnF2freq.cpp:3462-3496)
+    double pmk[2] = {1.0, par_r0 ? 0.0 : 1.0};
+    if (TIES && c.force_par >= 0) {
+        pmk[0] = ((0 ^ c.firstpar) & 1) == c.force_par ? pmk[0] : 0.0;
+        pmk[1] = ((1 ^ c.firstpar) & 1) == c.force_par ? pmk[1] : 0.0;
+    }
 
     // ---- parent match terms per parent allele fp
     double alpha[2], beta[2];      // entry = sum_fp wl * OO * (alpha*T0 + beta*T1)
@@ -278,7 +302,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
                     // founder parent: baseval + odds, then the phase weight (cnF2freq.cpp:1213-1245)
                     const double t = (c.firstpar ? pw[(fp ^ sp) ^ 1] : pw[fp ^ sp]) * (alpha[fp] + beta[fp]);
                     v += t;
-                    if (!(par_r0 && fp == 1)) {
+                    if (TIES ? pmk[fp] != 0.0 : !(par_r0 && fp == 1)) {
                         vr += t;
                         if (pis2[fp]) v2 += t;
                     }
@@ -305,14 +329,14 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make<HOMLEAF>(trs, c.tr, vtr[fp], pis2[fp], &L);
+        leaf_make<HOMLEAF, TIES>(trs, c.tr, vtr[fp], pis2[fp], &L, c.force_tr);
 #pragma unroll
         for (int kind = 0; kind < KINDS; kind++) {
             if (NORESTR && kind == 1) continue;
 #pragma unroll
             for (int bit = 0; bit < 2; bit++) {
                 double t0, t1;
-                leaf_value(L, bit, kind, &t0, &t1);
+                leaf_value<TIES>(L, bit, kind, &t0, &t1);
                 G[kind][fp][bit] = alpha[fp] * t0 + beta[fp] * t1;
             }
         }
@@ -321,13 +345,13 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make<HOMLEAF>(ots, c.ot, vot[fp], false, &L);
+        leaf_make<HOMLEAF, TIES>(ots, c.ot, vot[fp], false, &L, c.force_ot);
 #pragma unroll
         for (int kind = 0; kind < ((CLASSES && !NORESTR) ? 2 : 1); kind++)
 #pragma unroll
             for (int bit = 0; bit < 2; bit++) {
                 double o0, o1;
-                leaf_value(L, bit, kind, &o0, &o1);
+                leaf_value<TIES>(L, bit, kind, &o0, &o1);
                 OO[kind][fp][bit] = (1.0 - so_p[fp]) * o0 + so_p[fp] * o1;
             }
     }
@@ -349,8 +373,8 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
         const int ko = NORESTR ? 0 : (kind == 2 ? 1 : kind);
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
-            const double w0 = wl[sp][0];
-            const double w1 = (kind >= 1 && !NORESTR) ? pm1 * wl[sp][1] : wl[sp][1];
+            const double w0 = (TIES && kind >= 1) ? pmk[0] * wl[sp][0] : wl[sp][0];
+            const double w1 = (kind >= 1 && !NORESTR) ? (TIES ? pmk[1] : pm1) * wl[sp][1] : wl[sp][1];
 #pragma unroll
             for (int bo = 0; bo < 2; bo++)
 #pragma unroll
@@ -365,11 +389,11 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 }
 
 // from raw slot data (every part does its own match logic)
-template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, class Out>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, bool TIES = false, class Out>
 CNF2_HD void emtab_part_to(const PartCfg& c, const Slot& root, const Slot& par, const Slot& trs, const Slot& ots,
                            Out&& out, double cw[2])
 {
-    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, NORESTR>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, NORESTR, TIES>(c, SlotDirect(root), SlotDirect(par), SlotDirect(trs), SlotDirect(ots), out, cw);
 }
 
 // from the 7 slot records of the marker (`recs` = 7 x SLOTTAB_DOUBLES, slot order of the window)
@@ -377,7 +401,7 @@ template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, class Out>
 CNF2_HD void emtab_part_tables(const PartCfg& c, const double* recs, Out&& out, double cw[2])
 {
     const int sp = 1 + 3 * c.P;
-    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, false>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
+    emtab_part_views<CLASSES, HOMPAR, HOMLEAF, false, false>(c, SlotTable(recs), SlotTable(recs + sp * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + c.firstpar) * SLOTTAB_DOUBLES),
                               SlotTable(recs + (sp + 1 + (c.firstpar ^ 1)) * SLOTTAB_DOUBLES), out, cw);
 }
@@ -408,6 +432,16 @@ CNF2_HD void make_part(const Window& w, int part, PartCfg* c, int32_t* row_par, 
     *row_par = w.row[slot_par] < 0 ? 0 : w.row[slot_par];
     *row_tr  = w.row[slot_tr] < 0 ? 0 : w.row[slot_tr];
     *row_ot  = w.row[slot_ot] < 0 ? 0 : w.row[slot_ot];
+}
+
+// the forces of tie combination `combo` for the three slots of a part (cnf2_lane.h tie_force)
+CNF2_HD void part_forces(const Window& w, int part, int combo, PartCfg* c)
+{
+    const int P = part >> 2, firstpar = part & 1, slot_par = 1 + 3 * P;
+    const int8_t tp = w.tie[slot_par], tt = w.tie[slot_par + 1 + firstpar], to = w.tie[slot_par + 1 + (firstpar ^ 1)];
+    c->force_par = tp < 0 ? -1 : ((combo >> tp) & 1);
+    c->force_tr  = tt < 0 ? -1 : ((combo >> tt) & 1);
+    c->force_ot  = to < 0 ? -1 : ((combo >> to) & 1);
 }
 
 // table index of entry e (= sp*4 + bit_ot*2 + bit_tr) of a part: (bit_a, bit_b) = firstpar ? (bit_ot, bit_tr)

@@ -676,7 +676,7 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
 }
 
 // the table row c.mi of the tile from this lane's raw inputs (valid: the row's marker exists)
-template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false>
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, bool TIES = false>
 __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool valid, const RawSlots& raw)
 {
     if (valid) {
@@ -691,7 +691,7 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         // two lane-dependent offsets are per-job constants, so no value is ever selected.  Entries are stored
         // as they are formed: the producer holds no output array in registers.
         double* rb = row + c.idx_base;
-        emtab_part_to<CLASSES, HOMPAR, HOMLEAF, NORESTR>(c.pc, root, par, tr, ot,
+        emtab_part_to<CLASSES, HOMPAR, HOMLEAF, NORESTR, TIES>(c.pc, root, par, tr, ot,
                                [&](int kind, int e, double v) {
                                    const int b  = e & 3;
                                    const int k  = b == 0 ? 0 : (b == 1 ? c.idx_k01 : (b == 2 ? c.idx_k10 : 6));
@@ -712,10 +712,15 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
 // present and homozygous everywhere as well (HOMLEAF) -- the F2 with empty F1 parents and inbred founders;
 // 3 = no slot of the window is restricted (flag2ignore == 0: a complete window): the restricted table is a
 // copy of the unrestricted one (NORESTR)
-template <bool CLASSES>
+// TIES: the restricted tables of the tie combination whose forces are in c.pc (general form of the producer)
+template <bool CLASSES, bool TIES = false>
 __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
                                              const RawSlots& raw, int hom)
 {
+    if (TIES) {
+        produce_row<CLASSES, false, false, false, CLASSES>(c, tab, m0 + c.mi <= last, raw);
+        return;
+    }
     if (hom == 2) produce_row<CLASSES, true, true>(c, tab, m0 + c.mi <= last, raw);
     else if (hom == 1) produce_row<CLASSES, true, false>(c, tab, m0 + c.mi <= last, raw);
     else if (hom == 3 && CLASSES) produce_row<CLASSES, false, false, true>(c, tab, m0 + c.mi <= last, raw);
@@ -832,16 +837,24 @@ struct BwdState {
 // HALF: alpha-minus is spilled for every second marker only; the backward pass rebuilds the odd ones
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
 // spill traffic for ~15 % more arithmetic.
-template <bool HALF, int STOREW = 0, bool XPOSE = false>
+// TIED: windows with tie groups (ignoreflag2's all-or-none rule, cnF2freq.cpp:3484-3486).  The forward pass and the beta
+// recursion do not see the rule; the per-locus rows are sums over the tie combinations of class sums taken with that
+// combination's restricted tables.  So every tile of the backward pass is run once per combination -- tables produced
+// with the combination's forces, beta and the scales restored from the tile's start -- and the tile epilogue adds the
+// combinations up before it writes the rows.  A job with n combinations costs one forward and n backward passes of the
+// tile producer's kind instead of the general kernel's per-marker producer (20 x the latency of a job).
+template <bool HALF, int STOREW = 0, bool XPOSE = false, bool TIED = false>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
     static_assert(!XPOSE || (HALF && STOREW == 0), "the transposing variant exists for the plain half-spill sweep");
+    static_assert(!TIED || (!XPOSE && STOREW != 2), "tie combinations: plain sweep and accumulate mode");
     // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
     // per lane and k), then [chain][2] = reciprocal normaliser of the (even) marker and, HALF only, of
     // an odd last marker.
     constexpr int ROW = 528;
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
     __shared__ __attribute__((aligned(16))) double xlds[XPOSE ? CNF2_WAVES_PER_BLOCK : 1][XPOSE ? 64 * XPOSE_RS : 2];
+    __shared__ double tsum[TIED ? CNF2_WAVES_PER_BLOCK : 1][TIED ? 24 : 1];     // TIED: class sums of the tile's markers over the combinations
 
     const int lane  = threadIdx.x & 63;
     const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -869,8 +882,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if ((gp & SLOT_HOM) && (gp & SLOT_PRESENT)) hom = 2;
         }
         if (hom == 0 && w.flag2ignore == 0) hom = 3;
+        if (TIED) hom = 0;
         hom = __builtin_amdgcn_readfirstlane(hom);
-        if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = hom;
+        const int n_combo = TIED ? __builtin_amdgcn_readfirstlane(1 << w.n_groups) : 1;
+        if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = TIED ? PATH_TIED : hom;
         const int s = lane >> 3;
         c.s0 = s & 1;
         c.s1 = (s >> 1) & 1;
@@ -1022,6 +1037,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         S.inv_odd = 1.0;
         load_row(HALF ? ((last - first) >> 1) : (last - first));
 
+        int cur_combo = 0;     // TIED: tie combination of the pass over the tile that is running
         // One marker of the backward pass.  ODD (HALF only): the marker's alpha-minus is rebuilt from the
         // row of its even neighbour.  LOADS: request the next spill row once this one has been used.
         auto marker = [&](auto odd_tag, double* row, int m, bool carried = false) {
@@ -1104,8 +1120,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
-            if (STOREW == 1) {
+            if (STOREW == 1 && (!TIED || cur_combo == 0)) {
                 // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta for the batched HOT LOOP 2 kernel
+                // (the same in every tie combination)
                 double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1160,10 +1177,26 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
+            // TIED: the state at the tile's start, restored for every further combination
+            BwdState  S0;
+            int       bmask0 = bmask;
+            if (TIED) {
+                S0 = S;
+                if (lane < 24) tsum[wib][lane] = 0.0;
+            }
+          for (int combo = 0; combo < n_combo; combo++) {
+            if (TIED) {
+                if (combo > 0) {
+                    S     = S0;
+                    bmask = bmask0;
+                }
+                cur_combo = combo;
+                part_forces(w, c.part, combo, &c.pc);
+            }
 #ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
             if (t == ntile - 1)
 #endif
-            produce_tile<true>(p, c, tab, m0, last, raw, hom);
+            produce_tile<true, TIED>(p, c, tab, m0, last, raw, hom);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             int       i    = mend - m0;                 // local index; its parity is the parity of m - first
@@ -1183,7 +1216,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
             // whole marker loop costs more in registers than the extra latency it hides; measured)
 #ifndef CNF2_X_NOPRODUCE
-            if (t > 0) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
+            if (t > 0 && combo == n_combo - 1) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
 #endif
             // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
             // of the tile's markers, lane sub == 0 normalises and stores the row
@@ -1197,12 +1230,26 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                     d1 += red[64 + i2];
                     d2 += red[128 + i2];
                 }
+                d0 = chain_sum(d0);
+                d1 = chain_sum(d1);
+                d2 = chain_sum(d2);
+                if (TIED) {
+                    // add this combination's class sums to the tile's; the rows are written after the last one
+                    if (sub == 0) {
+                        d0 += tsum[wib][mi2 * 3 + 0];
+                        d1 += tsum[wib][mi2 * 3 + 1];
+                        d2 += tsum[wib][mi2 * 3 + 2];
+                        tsum[wib][mi2 * 3 + 0] = d0;
+                        tsum[wib][mi2 * 3 + 1] = d1;
+                        tsum[wib][mi2 * 3 + 2] = d2;
+                    }
+                }
                 // class 0 and 1 are formed by inclusion-exclusion of non-negative sums: a true zero can come
                 // out as -1e-16; the reference adds non-negative terms (cnF2freq.cpp:3536), so clamp
-                d0 = fmax(chain_sum(d0), 0.0);
-                d1 = fmax(chain_sum(d1), 0.0);
-                d2 = fmax(chain_sum(d2), 0.0);
-                if (sub == 0 && m0 + mi2 <= last) {
+                d0 = fmax(d0, 0.0);
+                d1 = fmax(d1, 0.0);
+                d2 = fmax(d2, 0.0);
+                if (sub == 0 && m0 + mi2 <= last && combo == n_combo - 1) {
                     if (!(p.flags & KP_RAW_DOSAGE)) {
                         const double tsum = d0 + d1 + d2;
                         const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
@@ -1217,6 +1264,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
             }
             wave_lds_fence();
+          }
         }
     }
 }
@@ -3335,6 +3383,14 @@ void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
     hipLaunchKernelGGL(fb_packed_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
+void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_fast_kernel<true, 0, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
+void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fb_fast_kernel<true, 1, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+}
 void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 0, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);

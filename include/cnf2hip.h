@@ -67,6 +67,8 @@ enum {
                                     is the top of its own lines, which always take it */
     CNF2_ACC_LANES    = 1u << 11, /* cnf2_sweep_accumulate: path form with one lane per path for every window (the kernel that
                                     windows with tie groups always take) instead of the tile form; A/B and cross-check */
+    CNF2_TIES_GENERAL = 1u << 12, /* cnf2_sweep, cnf2_sweep_accumulate: windows with tie groups through the general kernel (one lane per table entry, producer
+                                    per marker) instead of the tile-producer kernel's pass per tie combination; cross-check */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same
@@ -270,8 +272,9 @@ int cnf2_selftest_lane_xor(cnf2_ctx *ctx, double *out384);
 int    cnf2_last_kernel_ms(cnf2_ctx *ctx, float *kernel_ms, int n);
 /* After a cnf2_sweep with CNF2_LOG_PATHS: paths_out[n] (n = individuals of that sweep x chromosomes, [ind][chrom]) = which
  * code swept the job: 0-3 the fast kernel with producer class 0 general / 1 both parents homozygous everywhere / 2 and the
- * grandparents too / 3 complete window (restricted table = unrestricted); 32 | homleaf the merged-modes kernel; 64 the
- * general kernel (tied windows).  Test support: the specialisations are exact shortcuts and must all be exercised. */
+ * grandparents too / 3 complete window (restricted table = unrestricted); 16 the fast kernel's instantiation for windows with
+ * tie groups (a backward pass per tie combination); 32 | homleaf the merged-modes kernel; 64 the general kernel (tied windows
+ * with CNF2_TIES_GENERAL or CNF2_FULL_SPILL).  Test support: the specialisations are exact shortcuts and must all be exercised. */
 int    cnf2_last_paths(cnf2_ctx *ctx, int32_t *paths_out, int n);
 size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
 void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */

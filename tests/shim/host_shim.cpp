@@ -132,6 +132,39 @@ int shim_emtab_fast(int n_rec, const int32_t* par, const uint8_t* empty, const i
 
 // Same tables with the single-parent-allele shortcut (HOMPAR) wherever the parent is homozygous with equal
 // sure at this marker
+// ... with the tie rule for combination `combo` (the tile producer of the tied windows' sweep)
+int shim_emtab_fast_ties(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                         const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
+                         int n_markers, int rec, int marker, int combo, double* tot, double* rtot, double* two, double* c4)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    auto slot_at = [&](int row) {
+        size_t i = (size_t)row * n_markers + marker;
+        return unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    };
+    Slot root = slot_at(w.row[0]);
+    for (int part = 0; part < 8; part++) {
+        PartCfg c;
+        int32_t rp, rt, ro;
+        make_part(w, part, &c, &rp, &rt, &ro);
+        part_forces(w, part, combo, &c);
+        double t[8], r[8], t2[8], cw[2];
+        emtab_part_to<true, false, false, false, true>(c, root, slot_at(rp), slot_at(rt), slot_at(ro),
+                      [&](int kind, int e, double v) { (kind == 0 ? t : (kind == 1 ? r : t2))[e] = v; }, cw);
+        for (int e = 0; e < 8; e++) {
+            int idx = part_entry_index(part, e);
+            tot[idx] = t[e];
+            rtot[idx] = r[e];
+            two[idx] = t2[e];
+        }
+        c4[c.f * 2 + 0] = cw[0];
+        c4[c.f * 2 + 1] = cw[1];
+    }
+    return w.n_groups;
+}
+
 int shim_emtab_hompar(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
                       const int32_t* row_of, const uint8_t* allele, const double* sure, const double* hw,
                       int n_markers, int rec, int marker, double* tot, double* rtot, double* two, double* c4)

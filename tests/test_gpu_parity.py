@@ -132,13 +132,16 @@ def test_outbred_missing_against_oracle(capi):
     ped = synth.make_outbred3(6, 4, 60, 2, seed=31, missing=0.2, random_hw=True, random_sure=True)
     ctx = capi.Context(0)
     ctx.upload(ped)
-    got = ctx.sweep()
     o = oracle_ped(ped)
-    for c in range(2):
-        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
-        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
-        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
-        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    # tied windows through the tile-producer kernel (a backward pass per tie combination: the default) and through the
+    # general kernel (per-marker producer, loop over the combinations inside a marker)
+    for general in (False, True):
+        got = ctx.sweep(ties_general=general)
+        for c in range(2):
+            first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+            want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+            np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
 
 
@@ -243,13 +246,16 @@ def test_advanced_intercross_with_active_ties_against_oracle(capi):
     ctx.upload(ped)
     tied = sum(1 for j in range(len(ped.dous)) if (ctx.window_info(j)["tie"] >= 0).any())
     assert 0 < tied < len(ped.dous), "the fixture should mix tied and untied windows"
-    got = ctx.sweep()
     o = oracle_ped(ped)
-    for c in range(2):
-        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
-        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
-        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
-        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    # tied windows through the tile-producer kernel (a backward pass per tie combination: the default) and through the
+    # general kernel (per-marker producer, loop over the combinations inside a marker)
+    for general in (False, True):
+        got = ctx.sweep(ties_general=general)
+        for c in range(2):
+            first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+            want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+            np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
 
 
@@ -739,7 +745,9 @@ def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
         desc = ctx.descendants()
         got = ctx.sweep_accumulate(desc)
         plain = ctx.sweep()
-        assert np.array_equal(got["factors"], plain["factors"]) and np.array_equal(got["loglik"], plain["loglik"])
+        # (not bit-equal: tied windows take the tile-producer kernel in cnf2_sweep and the general kernel here)
+        np.testing.assert_allclose(got["factors"], plain["factors"], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(got["loglik"], plain["loglik"], rtol=1e-12, atol=1e-9)
         np.testing.assert_allclose(got["dosage"], plain["dosage"], rtol=1e-12, atol=1e-15)
         o = oracle_ped(ped)
         for c in range(len(ped.chromstarts) - 1):
@@ -753,6 +761,10 @@ def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
         tab = ctx.sweep_accumulate(desc, table_form=True)
         for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
             np.testing.assert_allclose(tab[k], got[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg="table form " + k)
+        # ... the sweep of the tied windows through the general kernel instead of the tile-producer kernel
+        gen = ctx.sweep_accumulate(desc, ties_general=True)
+        for k in ("infprobs", "haplobase", "haplocount", "homozyg", "dosage"):
+            np.testing.assert_allclose(gen[k], got[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg="general sweep " + k)
         # ... and the path form with one lane per path (the kernel of the windows with tie groups) on every window
         lanes = ctx.sweep_accumulate(desc, lane_form=True)
         for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
@@ -936,18 +948,20 @@ def test_every_producer_specialisation_runs_and_is_exact(capi):
         ("merged-modes kernel, grandparents not homozygous (homleaf 0)", _four_founder_pedigree(5, 9, 5), True, {32, 1}),
         ("merged-modes kernel, grandparents homozygous (homleaf 1)",
          synth.make_f2(6, 9, 1, seed=6, chrom_cm=20.0, missing=0.1), True, {33, 2}),
-        ("general kernel: tied windows", synth.make_ail(4, 6, 3, 9, 1, seed=5, chrom_cm=20.0), False, {64, 3, 0}),
+        ("fast kernel, tied windows: a backward pass per tie combination (16)",
+         synth.make_ail(4, 6, 3, 9, 1, seed=5, chrom_cm=20.0), False, {16, 3, 0}),
+        ("general kernel: tied windows", synth.make_ail(4, 6, 3, 9, 1, seed=5, chrom_cm=20.0), "general", {64, 3, 0}),
     ]
     for what, ped, merge, allowed in cases:
         ctx = capi.Context(0)
         ctx.upload(ped)
-        got = ctx.sweep(merge_modes=merge, log_paths=True)
+        got = ctx.sweep(merge_modes=merge is True, log_paths=True, ties_general=merge == "general")
         paths = set(int(x) for x in got["paths"].ravel())
         assert paths <= allowed and min(allowed) in paths or max(allowed) in paths, (what, paths)
-        if merge:
+        if merge is True:
             assert any(p >= 32 and p < 64 for p in paths), (what, paths)
-        elif 64 in allowed:
-            assert 64 in paths, (what, paths)
+        elif 64 in allowed or 16 in allowed:
+            assert max(allowed) in paths, (what, paths)
         else:
             assert paths == allowed, (what, paths)
         want = oracle_ped(ped).sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)

@@ -190,6 +190,40 @@ def test_fast_tile_producer_matches_general_producer(shim, seed):
                     np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_tile_producer_with_the_tie_rule_matches_general_producer(shim, seed):
+    """The tile producer's tie form (restricted tables of one tie combination: admissibility masks per allele and state
+    bit, cnf2_emtab.h TIES) against line_restricted() with the forces of the combination, for every combination of
+    every tied window: the tables the tied windows' instantiation of the fast sweep kernel reads."""
+    ped = synth.make_random_windows(40, 4, seed=seed)
+    tot, rtot, two, c4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    ftot, frtot, ftwo, fc4 = np.zeros(64), np.zeros(64), np.zeros(64), np.zeros(4)
+    g = np.arange(64)
+    tied = 0
+    for ind in ped.dous:
+        ind = int(ind)
+        for m in (0, ped.n_markers - 1):
+            args = _ped_args(ped) + [_p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, ind, m]
+            ng = shim.shim_emtab(*args, 0, _p(tot), _p(rtot), _p(two), _p(c4))
+            for combo in range(1 << ng):
+                shim.shim_emtab(*args, combo, _p(tot), _p(rtot), _p(two), _p(c4))
+                shim.shim_emtab_fast_ties(*args, combo, _p(ftot), _p(frtot), _p(ftwo), _p(fc4))
+                # the two producers split the root's factors differently between the tables and c: compare what the
+                # kernels form, c_f(s0) * A * B, for the emission and the four class products
+                kinds = [((tot, tot), (ftot, ftot)), ((rtot, rtot), (frtot, frtot)), ((two, rtot), (ftwo, frtot)),
+                         ((rtot, two), (frtot, ftwo)), ((two, two), (ftwo, ftwo))]
+                for s in range(8):
+                    s0, s1, s2 = s & 1, (s >> 1) & 1, (s >> 2) & 1
+                    for (ta, tb), (fa, fb) in kinds:
+                        want = sum(c4[f * 2 + s0] * ta[lane_index(0, f, s1, g & 7)] * tb[lane_index(1, f, s2, g >> 3)]
+                                   for f in range(2))
+                        got = sum(fc4[f * 2 + s0] * fa[lane_index(0, f, s1, g & 7)] * fb[lane_index(1, f, s2, g >> 3)]
+                                  for f in range(2))
+                        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
+            tied += int(ng > 0)
+    assert tied > 0
+
+
 @pytest.mark.parametrize("seed", [31, 32])
 def test_table_form_of_the_tile_producer_is_identical(shim, seed):
     """The two-phase tile producer (7 per-slot match records shared by the 8 parts, SlotTable) must give
