@@ -317,14 +317,15 @@ class Context:
                                                C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
                                                flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
 
-    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True):
+    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True, ties_general=False):
         """Batched turn scan: rawervals [n][M][128][8] and / or their log-sum-exp over the admissible modes [n][M][128]."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         raw = np.zeros((n, self.n_markers, 128, 8)) if full else None
         ls = np.zeros((n, self.n_markers, 128)) if lse else None
         self._chk(self.L.cnf2_sweep_turn_scan(self.h, ind_begin, ind_end, _p(raw) if full else None, _p(ls) if lse else None,
-                                              0 if ties else NO_TIES), "cnf2_sweep_turn_scan")
+                                              (0 if ties else NO_TIES) | (TIES_GENERAL if ties_general else 0)),
+                  "cnf2_sweep_turn_scan")
         return raw, ls
 
     def fixparents_scan(self, recs):

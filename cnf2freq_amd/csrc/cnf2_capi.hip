@@ -1217,12 +1217,15 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
             p.n_jobs = (int)nb;
             int grid = (int)((nb + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
             if (grid > grid_cap) grid = grid_cap;
-            if (pass == 0) launch_fb_fast_ab(p, grid, ctx->stream);
+            // alpha and beta do not see the tie rule: tied windows take the tile-producer kernel too (its rows, which
+            // would need the rule, go to the context's scratch and are not an output of this call)
+            const bool fast = pass == 0 || !(flags & CNF2_TIES_GENERAL);
+            if (fast) launch_fb_fast_ab(p, grid, ctx->stream);
             else launch_fb_ab(p, grid, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
             q.kp     = p;
             q.n_jobs = (int)nb;
-            q.scaled_transitions = (pass == 0);
+            q.scaled_transitions = fast;
             launch_turn_rows(q, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
         }

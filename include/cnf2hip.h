@@ -67,7 +67,7 @@ enum {
                                     is the top of its own lines, which always take it */
     CNF2_ACC_LANES    = 1u << 11, /* cnf2_sweep_accumulate: path form with one lane per path for every window (the kernel that
                                     windows with tie groups always take) instead of the tile form; A/B and cross-check */
-    CNF2_TIES_GENERAL = 1u << 12, /* cnf2_sweep, cnf2_sweep_accumulate: windows with tie groups through the general kernel (one lane per table entry, producer
+    CNF2_TIES_GENERAL = 1u << 12, /* cnf2_sweep, cnf2_sweep_accumulate, cnf2_sweep_turn_scan: windows with tie groups through the general kernel (one lane per table entry, producer
                                     per marker) instead of the tile-producer kernel's pass per tie combination; cross-check */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into

@@ -824,11 +824,16 @@ def test_batched_turn_scan_matches_reference(capi, case):
 
 
 def test_batched_turn_scan_on_tied_windows_and_chromosomes(capi):
-    """Same on an advanced intercross (tied windows: general kernel) over two chromosomes, against the oracle."""
+    """Same on an advanced intercross (tied windows) over two chromosomes, against the oracle: alpha and beta do not see
+    the tie rule, so the tied windows take the tile-producer kernel too; the general kernel's route must agree."""
     ped = synth.make_ail(4, 6, 3, 7, 2, seed=5, chrom_cm=20.0, missing=0.05)
     ctx = capi.Context(0)
     ctx.upload(ped)
     raw, _ = ctx.sweep_turn_scan(lse=False)
+    raw_general, _ = ctx.sweep_turn_scan(lse=False, ties_general=True)
+    both = ~np.isnan(raw) & ~np.isnan(raw_general)
+    assert np.array_equal(np.isnan(raw), np.isnan(raw_general))
+    np.testing.assert_allclose(raw[both], raw_general[both], rtol=1e-9, atol=1e-8)
     o = oracle_ped(ped)
     checked = 0
     for j, ind in enumerate(ped.dous):
