@@ -775,6 +775,28 @@ def test_batched_accumulate_against_oracle_on_tied_and_ragged_pedigrees(capi):
         ctx.close()
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_random_windows_sweep_and_accumulate_against_oracle(capi, seed):
+    """More random pedigrees (missing and founder slots, restricted slots, tie groups, empty individuals) through the
+    product routes of this round -- tied windows on the tile-producer kernel, accumulators in the tile form -- against
+    the oracle: likelihoods, rows and every accumulator."""
+    ped = synth.make_random_windows(24, 6, seed=seed)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = ctx.descendants()
+    got = ctx.sweep_accumulate(desc)
+    plain = ctx.sweep()
+    o = oracle_ped(ped)
+    want = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    np.testing.assert_allclose(plain["factors"][:, 0], want["factors"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(plain["dosage"], want["dosage"], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-7, atol=1e-11)
+    acc = o.accumulate(ped.dous, ped.gen[ped.dous], desc, first=0, last=ped.n_markers - 1)
+    for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+        np.testing.assert_allclose(got[k], acc[k], rtol=1e-8, atol=1e-12, equal_nan=True, err_msg=k)
+    ctx.close()
+
+
 def test_batched_accumulate_rows_equal_the_per_individual_hooks(capi):
     """The table form inside the batched kernel against the per-individual closed-form hooks (cnf2_haplos,
     cnf2_infprobs_rows), which read the reference-layout store: same accumulators before the reductions.  Checked
