@@ -140,11 +140,13 @@ struct Leaf {
 // HOMLEAF: the caller guarantees that the slot is present and homozygous with equal sure at this marker: both
 // allele indices match the incoming value alike, so one match is evaluated (its weights are 0/1, the sums over
 // fg keep their bits).
-template <bool HOMLEAF = false, bool TIES = false, class View>
+// COMPLETE: the caller guarantees a complete window (every slot present, nothing restricted): the slot's presence and
+// restriction are compile-time facts.
+template <bool HOMLEAF = false, bool TIES = false, bool COMPLETE = false, class View>
 CNF2_HD void leaf_make(const View& d, uint32_t flags, int v, bool parent_is2, Leaf* L, int force = -1)
 {
-    const bool present = (flags & SLOT_PRESENT) != 0;
-    const bool r0      = (flags & SLOT_RESTRICT0) != 0;
+    const bool present = COMPLETE || (flags & SLOT_PRESENT) != 0;
+    const bool r0      = !COMPLETE && (flags & SLOT_RESTRICT0) != 0;
     const double w0 = present ? d.w(0) : 1.0;
     const double w1 = present ? d.w(1) : 1.0;
     double t0[2], t1[2];
@@ -211,7 +213,9 @@ CNF2_HD void leaf_value(const Leaf& L, int bit, int kind, double* v0, double* v1
 // terms of its two allele indices are then the same numbers and only fp = 0 is evaluated (the parent's phase
 // weights are 0/1, so  wl0 * h + w1 * h  ==  (wl0 + w1) * h  bit for bit).
 // NORESTR: the caller guarantees that no slot of the window is restricted (flag2ignore == 0, a complete
-// window): the restricted table is the unrestricted one, bit for bit, and is copied instead of recomputed.
+// window: all six ancestors present and genotyped, cnf2_window.cpp): the restricted table is the unrestricted one, bit
+// for bit, and is copied instead of recomputed; the branches for a root at the top of its lines, a missing or founder
+// parent and missing grandparents are not compiled in.
 // TIES: the restricted tables (kinds 1, 2) are those of the tie combination c.force_* (line_restricted() with forces).
 template <bool CLASSES, bool HOMPAR, bool HOMLEAF, bool NORESTR, bool TIES = false, class VR, class VP, class VT, class VO, class Out>
 CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, const VT& trs, const VO& ots,
@@ -226,7 +230,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     const double msv_r  = (mf != 0) ? sf : 0.0;
     cw[0] = root.w(c.f ^ 0);
     cw[1] = root.w(c.f ^ 1);
-    if (c.root_attop) {
+    if (!NORESTR && c.root_attop) {
         // the root is the top of its only line: e = sum_f (base + odds) * weight
         const double v = (c.P == 0) ? base_r + msv_r : 1.0;
 #pragma unroll
@@ -244,9 +248,9 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
     const double u0 = c.P ? 1.0 - so_r : base_r;      // value = u0 * R0 + u1 * R1
     const double u1 = c.P ? so_r : msv_r;
 
-    const bool par_present = (c.par & SLOT_PRESENT) != 0;
-    const bool par_founder = (c.par & SLOT_FOUNDER) != 0;
-    const bool par_r0      = (c.par & SLOT_RESTRICT0) != 0;
+    const bool par_present = NORESTR || (c.par & SLOT_PRESENT) != 0;
+    const bool par_founder = !NORESTR && (c.par & SLOT_FOUNDER) != 0;
+    const bool par_r0      = !NORESTR && (c.par & SLOT_RESTRICT0) != 0;
     const bool rootcls     = (c.P == 0 && mf == 2);
     // admissibility of the parent's allele fp in the restricted tables (cnF2freq.cpp:3462-3496)
     double pmk[2] = {1.0, par_r0 ? 0.0 : 1.0};
@@ -329,7 +333,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make<HOMLEAF, TIES>(trs, c.tr, vtr[fp], pis2[fp], &L, c.force_tr);
+        leaf_make<HOMLEAF, TIES, NORESTR>(trs, c.tr, vtr[fp], pis2[fp], &L, c.force_tr);
 #pragma unroll
         for (int kind = 0; kind < KINDS; kind++) {
             if (NORESTR && kind == 1) continue;
@@ -345,7 +349,7 @@ CNF2_HD void emtab_part_views(const PartCfg& c, const VR& root, const VP& par, c
 #pragma unroll
     for (int fp = 0; fp < NFP; fp++) {
         Leaf L;
-        leaf_make<HOMLEAF, TIES>(ots, c.ot, vot[fp], false, &L, c.force_ot);
+        leaf_make<HOMLEAF, TIES, NORESTR>(ots, c.ot, vot[fp], false, &L, c.force_ot);
 #pragma unroll
         for (int kind = 0; kind < ((CLASSES && !NORESTR) ? 2 : 1); kind++)
 #pragma unroll

@@ -723,7 +723,7 @@ __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCt
     }
     if (hom == 2) produce_row<CLASSES, true, true>(c, tab, m0 + c.mi <= last, raw);
     else if (hom == 1) produce_row<CLASSES, true, false>(c, tab, m0 + c.mi <= last, raw);
-    else if (hom == 3 && CLASSES) produce_row<CLASSES, false, false, true>(c, tab, m0 + c.mi <= last, raw);
+    else if (hom == 3) produce_row<CLASSES, false, false, true>(c, tab, m0 + c.mi <= last, raw);
     else produce_row<CLASSES, false, false>(c, tab, m0 + c.mi <= last, raw);
 }
 
