@@ -1,4 +1,6 @@
 #!/bin/bash
+# SQ counters of the sweep kernel on the F2 and the outbred workload side by side (tuning aid, GPU box):
+#   bash tools/pmc_shape.sh   -> per-kernel sums on stdout (2000 individuals each; divide by individuals x markers)
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/pmc_shape
 rm -rf $out; mkdir -p $out
