@@ -92,8 +92,70 @@ void Engine::postmarkerdata(int indcount)
     T = Tables();     // the upload tables are not needed any more (large runs)
     T.dous.assign(P.dous.begin(), P.dous.end());
     const unsigned char UNKNOWN = 0, SEXMARKER = 9;
-    typedef std::map<int, std::pair<int, double>> ValMap;     // allele value -> (supporting count, product of odds)
+    // allele value -> (supporting count, product of odds), ascending by value like the reference's std::map; a marker sees
+    // a handful of values at most, and the map is formed for every (individual, marker) with an unknown allele
+    struct ValMap {
+        int    n = 0;
+        int    key[8];
+        std::pair<int, double> val[8];
+        int find(int k) const
+        {
+            for (int i = 0; i < n; i++)
+                if (key[i] == k) return i;
+            return -1;
+        }
+        std::pair<int, double>& at_or_insert(int k, bool* fresh)
+        {
+            int i = find(k);
+            *fresh = i < 0;
+            if (i >= 0) return val[i];
+            if (n == 8) {                                    // cannot happen with allele values 1, 2, 9; keep the last slot
+                *fresh = false;
+                return val[7];
+            }
+            i = n++;
+            while (i > 0 && key[i - 1] > k) {
+                key[i] = key[i - 1];
+                val[i] = val[i - 1];
+                i--;
+            }
+            key[i] = k;
+            val[i] = std::make_pair(0, 1.0);
+            return val[i];
+        }
+        void set(int k, std::pair<int, double> v)             // operator[] = v
+        {
+            bool fresh;
+            at_or_insert(k, &fresh) = v;
+        }
+        void insert(int k, std::pair<int, double> v)          // std::map::insert: keeps an existing entry
+        {
+            bool fresh;
+            std::pair<int, double>& slot = at_or_insert(k, &fresh);
+            if (fresh) slot = v;
+        }
+        void erase(int k)
+        {
+            const int i = find(k);
+            if (i < 0) return;
+            for (int j = i; j + 1 < n; j++) {
+                key[j] = key[j + 1];
+                val[j] = val[j + 1];
+            }
+            n--;
+        }
+        size_t size() const { return (size_t)n; }
+    };
     int any, anyrem;
+    // CNF2_TIMING=1: wall-clock of the steps on stderr (tuning aid)
+    const bool timing = getenv("CNF2_TIMING") != nullptr;
+    auto       t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  [postmarkerdata] %-32s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     do {
         for (int r : recs) children_[r] = 0;
         // fixkid (cnF2freq.cpp:1470-1487): a child without a genotype takes the allele of a homozygous parent
@@ -134,10 +196,13 @@ void Engine::postmarkerdata(int indcount)
         for (int r : recs)
             for (int k = 0; k < 2; k++)
                 if (P.inds[r].pars[k] >= 0) children_[P.inds[r].pars[k]]++;
+        lap("fixkid, descendants");
         // fixparents (cnF2freq.cpp:1392-1468): the admissibility test runs on the GPU for every individual and marker
         push_rows();
+        lap("rows to the device");
         std::vector<uint8_t> ok(recs.size() * (size_t)M * 2);
         if (!recs.empty()) check(cnf2_fixparents_scan(ctx, recs.data(), (int)recs.size(), ok.data()), "cnf2_fixparents_scan");
+        lap("fixparents scan (GPU)");
         // what fixparents does to the individual itself: no admissible interpretation at all clears the genotype
         std::vector<size_t> qof(R, (size_t)-1);               // record -> position in recs
         for (size_t q = 0; q < recs.size(); q++) qof[recs[q]] = q;
@@ -170,14 +235,14 @@ void Engine::postmarkerdata(int indcount)
                 if (value == UNKNOWN) continue;
                 int    oldcount = 0;
                 double oldodds = 1;
-                auto it = vm.find(value);
-                if (it != vm.end()) {
-                    oldcount = it->second.first;
-                    oldodds  = it->second.second;
+                const int it = vm.find(value);
+                if (it >= 0) {
+                    oldcount = vm.val[it].first;
+                    oldodds  = vm.val[it].second;
                 }
                 double probit = K.sure[g * 2] + K.sure[g * 2 + 1];
                 probit /= (1 - probit);
-                vm[value] = std::make_pair(oldcount + 1, oldodds * probit);
+                vm.set(value, std::make_pair(oldcount + 1, oldodds * probit));
             }
         };
         // corrections (cnF2freq.cpp:3281-3366, latephase is never set).  The contributions were all made before this
@@ -195,25 +260,22 @@ void Engine::postmarkerdata(int indcount)
                 ValMap vm;
                 gather(r, g, vm);
                 vm.erase(UNKNOWN);
-                if (I.allele[g * 2] != UNKNOWN) vm.insert(std::make_pair((int)I.allele[g * 2], std::make_pair(children_[r], I.sure[g * 2])));
-                if (I.allele[g * 2 + 1] != UNKNOWN)
-                    vm.insert(std::make_pair((int)I.allele[g * 2 + 1], std::make_pair(children_[r], I.sure[g * 2 + 1])));
+                if (I.allele[g * 2] != UNKNOWN) vm.insert((int)I.allele[g * 2], std::make_pair(children_[r], I.sure[g * 2]));
+                if (I.allele[g * 2 + 1] != UNKNOWN) vm.insert((int)I.allele[g * 2 + 1], std::make_pair(children_[r], I.sure[g * 2 + 1]));
                 if (vm.size() >= 3) fprintf(stderr, "Error, too many matches: %d\t%d\n", I.n, g);
                 Fix fx = {r, g, I.allele[g * 2], I.allele[g * 2 + 1], I.sure[g * 2], I.sure[g * 2 + 1]};
                 bool changed = false;
                 if (vm.size() == 2) {
-                    auto a = vm.begin(), b = ++vm.begin();
-                    const int knowncount = a->second.first + b->second.first;
-                    fx.a0 = (uint8_t)a->first;
-                    fx.a1 = (uint8_t)b->first;
-                    fx.s0 = sureval_from(knowncount, a->second.first, a->second.second);
-                    fx.s1 = sureval_from(knowncount, b->second.first, b->second.second);
+                    const int knowncount = vm.val[0].first + vm.val[1].first;
+                    fx.a0 = (uint8_t)vm.key[0];
+                    fx.a1 = (uint8_t)vm.key[1];
+                    fx.s0 = sureval_from(knowncount, vm.val[0].first, vm.val[0].second);
+                    fx.s1 = sureval_from(knowncount, vm.val[1].first, vm.val[1].second);
                     changed = true;
                 } else if (vm.size() == 1 && known == 0) {
-                    auto a = vm.begin();
-                    fx.a0 = (uint8_t)a->first;
+                    fx.a0 = (uint8_t)vm.key[0];
                     fx.a1 = UNKNOWN;
-                    fx.s0 = sureval_from(a->second.first, a->second.first, a->second.second);
+                    fx.s0 = sureval_from(vm.val[0].first, vm.val[0].first, vm.val[0].second);
                     fx.s1 = 0.0;
                     changed = true;
                 }
@@ -238,6 +300,7 @@ void Engine::postmarkerdata(int indcount)
                 if (I.allele[g * 2] == SEXMARKER) std::swap(I.allele[g * 2], I.allele[g * 2 + 1]);
         }
         fprintf(stderr, "Number of corrected genotypes: %d\n", any);
+        lap("corrections");
     } while (any > anyrem);
 
     // variances with the record's own window, founder flags as fixtrees has assigned them so far (cnF2freq.cpp:3373-3389)
@@ -251,6 +314,7 @@ void Engine::postmarkerdata(int indcount)
                 if (v == v) variances_[(size_t)recs[q] * M + g] = v;       // NaN: the reference leaves the entry alone
             }
     }
+    lap("variances (GPU)");
     // lockhaplos (cnF2freq.cpp:3045-3081): per chromosome, lock the phase at the marker of largest variance
     for (int r : recs) {
         Individual& I = P.inds[r];
@@ -271,6 +335,7 @@ void Engine::postmarkerdata(int indcount)
         }
     }
     push_rows();
+    lap("lockhaplos, rows to the device");
 }
 
 bool Engine::deserialize(const char* path)
