@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/pmc_shape
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for wl in f2 outbred; do
+for wl in ${PMC_WORKLOADS:-f2 outbred}; do
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -15,7 +15,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
         python3 $R/bench.py --workload $wl --inds 2000 --steps 1 --warmup 0 --cpu-seconds 0 --no-merge-probe > $out/$wl$i.log 2>&1 || echo "pass failed"
 done
 done
-for wl in f2 outbred; do
+for wl in ${PMC_WORKLOADS:-f2 outbred}; do
   echo "== $wl"
   python3 $R/profiles/pmc_summarize.py $out/${wl}1 $out/${wl}2 $out/${wl}3 --kernel fb_fast
 done
