@@ -28,8 +28,13 @@
 
 namespace cnf2 {
 
-// maxdiff is a float in the reference (cnF2freq.cpp:228) and is promoted where it is used
-#define CNF2_MAXDIFF ((double)0.000005f)
+// maxdiff is a float in the reference (cnF2freq.cpp:228) and its expressions stay in float arithmetic where it meets an
+// int: the clamp distance maxdiff / (children + 1) (cnF2freq.cpp:4240, 4703) is a float quotient and the similarity cap
+// 1 - maxdiff (cnF2freq.cpp:4667) a float difference (0.99999499..., i.e. 1 - similarity >= 5.0068e-6, not 5e-6); both are
+// promoted to double afterwards.  (Found by pinning against the reference's own text, goldens G14.)
+#define CNF2_MAXDIFF_F 0.000005f
+CNF2_UHD double clamp_distance(int children) { return (double)(CNF2_MAXDIFF_F / (float)(children + 1)); }
+#define CNF2_SIMILARITY_CAP ((double)(1.0f - CNF2_MAXDIFF_F))
 
 struct StepControl {
     double scalefactor;     // cnF2freq.cpp:3573 (0.013 at start, adapted after every update pass, 6373-6392)
@@ -247,7 +252,7 @@ CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side
     for (int v = 0; v < 2; v++)
         if (inf[v] > 0) sum += inf[v];
     const double ef = sc.entropyfactor;                       // exp(0 * -0.01 * iter) * entropyfactor
-    const double epsilon = CNF2_MAXDIFF / (children + 1);
+    const double epsilon = clamp_distance(children);
     double       out[2] = {0, 0};
     for (int v = 0; v < 2; v++) {
         if (!(inf[v] > 0)) continue;
@@ -352,7 +357,7 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
         *haplocount = (*haplocount < 1.0) ? 1.0 : *haplocount;
         *haplobase  = hw * *haplocount;
     } else {
-        if (similarity >= 1 - CNF2_MAXDIFF) similarity = 1 - CNF2_MAXDIFF;
+        if (similarity >= CNF2_SIMILARITY_CAP) similarity = CNF2_SIMILARITY_CAP;
         double count = *haplocount;
         *haplobase -= count * hw;
         count = count - similarity * count;
@@ -372,7 +377,7 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
         const double e = upd_div(phaseratio - x, x - x * x) * descendants - ent * lg;
         return upd_div(q2, (ev.ab * lg + ev.amb * q) + q2 * e);
     };
-    return flow_step(rgradient, hw, CNF2_MAXDIFF / (children + 1), sc.scalefactor, hits, breakathalf);
+    return flow_step(rgradient, hw, clamp_distance(children), sc.scalefactor, hits, breakathalf);
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).

@@ -21,7 +21,13 @@
 #include <stdlib.h>
 #include <string.h>
 
-static const double maxdiff_f = (double)0.000005f; /* cpp:228: const float maxdiff */
+/* cpp:228: `const float maxdiff`.  The reference's expressions keep float arithmetic wherever maxdiff meets an int:
+ * `maxdiff / (ind->children + 1)` (cpp:4240, 4703) is a FLOAT division and `1 - maxdiff` (cpp:4667) a FLOAT
+ * subtraction (0.99999499320983887, not 1 - 5e-6), both promoted to double afterwards.  Found by the bit-level pin
+ * against the reference's own text (goldens G14). */
+static const float maxdiff = 0.000005f;
+static double epsilon_of(int children) { return (double)(maxdiff / (float)(children + 1)); }
+static double similarity_cap(void) { return (double)(1.0f - maxdiff); }
 
 /* 15-point Gauss-Legendre rule, non-negative abscissas in ascending order with their weights
  * (Abramowitz & Stegun table 25.4; the values boost/math/quadrature/gauss.hpp tabulates for N = 15) */
@@ -205,7 +211,7 @@ int cnf2o_processinfprobs(const double inf_in[2], const int present[2], int side
         if (curmarker != 0) curprob = fabs((curmarker == first ? 1 : 0) - cursure);   /* cpp:4228-4231 */
         double hzygcorred = second;
         double etf = 1 * ef;
-        double epsilon = maxdiff_f / (children + 1);
+        double epsilon = epsilon_of(children);
         double priord = 0;
         double priorprob = 0.5;
         if (priorval != 0) {                                               /* cpp:4245-4268 */
@@ -331,7 +337,7 @@ void cnf2o_updatehaploweights(int n_chrom, const int *chromstarts, double *haplo
                 haplocount[j] = haplocount[j] < 1.0 ? 1.0 : haplocount[j];
                 haplobase[j] = haploweight[j] * haplocount[j];
             } else {                                                       /* cpp:4665-4677 */
-                if (similarity >= 1 - maxdiff_f) similarity = 1 - maxdiff_f;
+                if (similarity >= similarity_cap()) similarity = similarity_cap();
                 double count = haplocount[j];
                 haplobase[j] -= count * haploweight[j];
                 count = count - similarity * count;
@@ -342,7 +348,7 @@ void cnf2o_updatehaploweights(int n_chrom, const int *chromstarts, double *haplo
             }
             double ef = exp(0 * -0.01 * 1) * entropyfactor;                /* cpp:4679 */
             uhw_ctx c = {haploweight[j], haplobase[j], haplocount[j], similarity, ef, relskewterm, (double)descendants};
-            double intended = cappedgd(uhw_gradient, &c, haploweight[j], maxdiff_f / (children + 1), scalefactor,
+            double intended = cappedgd(uhw_gradient, &c, haploweight[j], epsilon_of(children), scalefactor,
                                        hitnnn, 0 /* lastinved[cno] != -1 */);   /* cpp:4703 */
             haploweight[j] = intended;                                     /* cpp:4714 */
         }

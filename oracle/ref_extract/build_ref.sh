@@ -52,6 +52,7 @@ cat > "$TU" <<'EOF'
 #include <numeric>
 #include <utility>
 #include <unistd.h>
+#include <atomic>
 using namespace std;
 #define _isnan isnan
 #define _finite isfinite
@@ -83,8 +84,12 @@ r 3045 3097
 r 3099 3187
 r 3190 3412
 r 3462 3496
+r 3548 3551
 r 3553 3570
+r 3571 3574
 r 3577 3616
+echo "#include \"$HERE/boost_gauss_shim.h\"" >> "$TU"
+r 4004 4734
 echo "#include \"$HERE/ref_driver.inc\"" >> "$TU"
 
 mkdir -p "$OUT"

@@ -53,6 +53,23 @@ def lib(ieee=True):
         L.ref_get_counts.argtypes = [C.c_int, C.c_void_p]
         L.ref_get_variance.argtypes = [C.c_int, C.c_int]
         L.ref_get_variance.restype = C.c_double
+        L.ref_set_prior.argtypes = [C.c_int]
+        L.ref_set_dous.argtypes = [C.c_void_p, C.c_int]
+        L.ref_set_stepsize.argtypes = [C.c_double, C.c_int, C.c_int]
+        L.ref_get_stepsize.argtypes = [C.c_void_p]
+        L.ref_get_haplo_accumulators.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_set_haplo_accumulators.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        L.ref_set_counts.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ref_set_infprobs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_caplogitchange.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int]
+        L.ref_caplogitchange.restype = C.c_double
+        L.ref_processinfprobs.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ref_updatehaploweights.argtypes = [C.c_int]
+        L.ref_gauss15_reciprocal_linear.argtypes = [C.c_double] * 4
+        L.ref_gauss15_reciprocal_linear.restype = C.c_double
+        L.ref_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_copy_prior.argtypes = [C.c_int] * 4
+        L.ref_set_empty.argtypes = [C.c_int, C.c_int]
         _libs[key] = L
     return _libs[key]
 
@@ -180,3 +197,52 @@ class RefPed:
         f = np.zeros((len(ns), 8))
         used = self.L.ref_sweep_batch(ns.ctypes.data, len(ns), first, last, threads, f.ctypes.data)
         return f, used
+
+    # ---- the per-iteration updates (the reference's own cnF2freq.cpp:4004-4734 behind ref_driver.inc) ----
+    def set_priors(self, has_prior=None):
+        """readalphadata's copy of the rows as read (cnF2freq.cpp:6664-6665) for the genotyped records."""
+        hp = (1 - np.asarray(self.ped.empty)) if has_prior is None else np.asarray(has_prior)
+        for r in range(self.ped.n_rec):
+            if hp[r]:
+                self.L.ref_set_prior(r + 1)
+
+    def set_dous(self, recs=None):
+        ns = np.ascontiguousarray(np.asarray(self.ped.dous if recs is None else recs) + 1, np.int32)
+        self.L.ref_set_dous(ns.ctypes.data, len(ns))
+
+    def rows(self):
+        """allele [R][M][2], sure [R][M][2], hw [R][M], haplobase [R][M], haplocount [R][M] as they stand."""
+        R, M = self.ped.n_rec, self.M
+        allele = np.zeros((R, M, 2), np.int32)
+        sure = np.zeros((R, M, 2))
+        hw = np.zeros((R, M))
+        hb = np.zeros((R, M))
+        hc = np.zeros((R, M))
+        buf = np.zeros(5)
+        acc = np.zeros(2)
+        for r in range(R):
+            for m in range(M):
+                self.L.ref_get_marker(r + 1, m, buf.ctypes.data)
+                allele[r, m] = buf[:2]
+                sure[r, m] = buf[2:4]
+                hw[r, m] = buf[4]
+                self.L.ref_get_haplo_accumulators(r + 1, m, acc.ctypes.data)
+                hb[r, m], hc[r, m] = acc
+        return dict(allele=allele, sure=sure, hw=hw, haplobase=hb, haplocount=hc)
+
+    def stepsize(self):
+        out = np.zeros(3)
+        self.L.ref_get_stepsize(out.ctypes.data)
+        return float(out[0]), int(out[1]), int(out[2])
+
+    def iteration(self):
+        """One doit<false, genotypereporter> (cnF2freq.cpp:8132): returns the state it leaves plus hits[C] and the
+        scale factor, and the mask of elements whose result is rounding noise in the reference itself (see ref_iteration)."""
+        hits = np.zeros(len(self.ped.chromstarts) - 1, np.int32)
+        unstable = np.zeros((self.ped.n_rec, self.M, 2), np.uint8)
+        self.L.ref_iteration(hits.ctypes.data, unstable.ctypes.data, self.ped.n_rec)
+        st = self.rows()
+        st["hits"] = hits
+        st["unstable"] = unstable
+        st["scalefactor"] = self.stepsize()[0]
+        return st

@@ -22,6 +22,12 @@ seeds) and the reference's outputs for them -- data only, no reference text:
      descendant counts stored next to them (acc_desc)
   G12 the reference's own postmarkerdata (cpp:3190-3412 with fixkid / fixparents 1392-1487, lockhaplos 3045-3081) run on
      the inputs as main() does: pm_allele / pm_sure / pm_hw / pm_descendants / pm_children / pm_variances
+  G13 (traj_<case>.npz) trajectories: main()'s sequence readers -> postmarkerdata -> 3 x doit<false, genotypereporter>
+     (cpp:8083-8136) replayed by ref_driver.inc's ref_iteration around the reference's own update functions
+     (cpp:4004-4734; the one stand-in is oracle/ref_extract/boost_gauss_shim.h): after each iteration allele / sure / hw
+     of every record, haplobase / haplocount as the last pass left them, hitnnn of every chromosome's pass, scalefactor,
+     and the mask `unstable` of elements whose result is rounding noise in the reference itself (oracle/pyiter.py)
+  G14 (update_units.npz) the reference's caplogitchange / processinfprobs / updatehaploweights on random inputs
   G10 variances[record][marker] of individ::addvariance with the record's own flag2ignore (NaN where the
      function leaves the entry alone)                                                    (cpp:1489-1558, 3373-3389)
 """
@@ -165,6 +171,156 @@ def generate(name):
     print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+TRAJ_CASES = dict(CASES)
+# two chromosomes: the update pass of chromosome c runs again after every later chromosome of the iteration
+TRAJ_CASES["outbred3_two_chrom"] = (synth.make_outbred3, dict(n_fam=2, kids_per_fam=3, markers_per_chrom=9, n_chrom=2,
+                                                             seed=3, missing=0.2))
+# windows with tie groups (an ancestor in two slots), 3 analysed generations
+TRAJ_CASES["ail_ties"] = (synth.make_ail, dict(n_f1=4, n_per_gen=6, n_gen=3, markers_per_chrom=7, n_chrom=1, seed=5,
+                                               chrom_cm=20.0, missing=0.05))
+TRAJ_ITERATIONS = 3
+
+
+def traj_ped(name):
+    ctor, kw = TRAJ_CASES[name]
+    return make_f2_ungenotyped() if ctor is None else ctor(**kw)
+
+
+def generate_trajectory(name):
+    ped = traj_ped(name)
+    R = RefPed(ped, ieee=True, fixtrees_all=False)
+    R.set_priors()                      # the readers' last step (cnF2freq.cpp:6664-6665)
+    R.set_dous()
+    pm = R.postmarkerdata()             # cnF2freq.cpp:8083-8085
+    out = {"in_" + k: v for k, v in ped_inputs(ped).items()}
+    out.update(pm_allele=pm["allele"].astype(np.uint8), pm_sure=pm["sure"], pm_hw=pm["hw"],
+               pm_descendants=pm["descendants"])
+    for k in range(1, TRAJ_ITERATIONS + 1):
+        st = R.iteration()
+        out["it%d_allele" % k] = st["allele"].astype(np.uint8)
+        for key in ("sure", "hw", "haplobase", "haplocount", "hits", "unstable"):
+            out["it%d_%s" % (k, key)] = st[key]
+        out["it%d_scalefactor" % k] = np.float64(st["scalefactor"])
+    path = os.path.join(os.path.dirname(__file__), "traj_" + name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024), "hits",
+          [list(out["it%d_hits" % k]) for k in range(1, TRAJ_ITERATIONS + 1)])
+
+
+def generate_update_units(seed=20261004):
+    """G14: the reference's own update functions on random inputs, one call per case."""
+    import ctypes as C
+    rs = np.random.RandomState(seed)
+    ped = synth.make_outbred3(1, 1, 12, 2, seed=1)     # any loaded pedigree: record 0 (individual 1) is the scratch individual
+    R = RefPed(ped, ieee=True, fixtrees_all=False)
+    L = R.L
+    M = ped.n_markers
+    out = {"chromstarts": np.asarray(ped.chromstarts, np.int32)}
+    # caplogitchange
+    n = 400
+    cap = np.zeros((n, 6))
+    for i in range(n):
+        eps = 5e-6 / rs.randint(1, 5)
+        orig = rs.choice([rs.rand(), eps, 1 - eps, 0.5, rs.rand() * 1e-3, 1 - rs.rand() * 1e-3])
+        intended = rs.choice([rs.rand(), eps, 1 - eps, orig, 0.0, 1.0])
+        bh = int(rs.rand() < 0.3)
+        h = C.c_int(0)
+        cap[i] = (intended, orig, eps, bh, L.ref_caplogitchange(intended, orig, eps, C.byref(h), bh), h.value)
+    out["cap"] = cap
+    # processinfprobs: (inputs) inf[2], present[2], side, curmarker, cursure, has_prior, priorval, priorsure, empty,
+    # children, scalefactor -> allele, sure after the call and the hits
+    n = 600
+    pin = np.zeros((n, 13))
+    pout = np.zeros((n, 3))
+    for i in range(n):
+        side = rs.randint(2)
+        present = [int(rs.rand() < 0.8), int(rs.rand() < 0.8)]
+        if not any(present):
+            present[rs.randint(2)] = 1
+        scale = 10.0 ** rs.uniform(-3, 2)
+        inf = rs.rand(2) * scale
+        if rs.rand() < 0.1:
+            inf[rs.randint(2)] = 0.0                       # a key that exists with value 0
+        if rs.rand() < 0.15:
+            inf[rs.randint(2)] *= 1e-6
+        cur = rs.randint(3)
+        cursure = rs.choice([rs.rand() * 0.5, 0.02, 0.0, rs.rand(), 1e-7])
+        has_prior = int(rs.rand() < 0.8)
+        priorval = rs.randint(3)
+        priorsure = rs.choice([0.02, rs.rand() * 0.3, 0.0, 1.0, 0.5])
+        empty = int(rs.rand() < 0.1)
+        children = rs.randint(4)
+        sf = rs.choice([0.013, 0.05, 0.19, 1e-3, 0.0])
+        m = rs.randint(M)
+        other = rs.randint(3)
+        pa = [0, 0]
+        ps = [0.0, 0.0]
+        pa[side], ps[side] = priorval, priorsure
+        L.ref_set_stepsize(float(sf), 0, 0)
+        L.ref_set_marker(1, m, cur if side == 0 else other, cur if side == 1 else other, cursure if side == 0 else 0.1,
+                         cursure if side == 1 else 0.1, 0.5)
+        # priors: exist for the whole individual or not at all
+        ind_has = has_prior
+        L.ref_set_marker(2, m, pa[0], pa[1], ps[0], ps[1], 0.5)
+        L.ref_copy_prior(1, 2, m, ind_has)
+        L.ref_set_counts(1, children, 1)
+        L.ref_set_empty(1, empty)
+        pr = np.array(present, np.int32)
+        L.ref_set_infprobs(1, m, side, pr.ctypes.data, inf.ctypes.data, None)
+        hits = L.ref_processinfprobs(1, m, side)
+        buf = np.zeros(5)
+        L.ref_get_marker(1, m, buf.ctypes.data)
+        pin[i] = (inf[0], inf[1], present[0], present[1], side, cur, cursure, has_prior, priorval, priorsure, empty,
+                  children, sf)
+        pout[i] = (buf[side], buf[2 + side], hits)
+    out["pip_in"], out["pip_out"] = pin, pout
+    L.ref_set_empty(1, 0)
+    # updatehaploweights: per case the whole individual (two chromosomes)
+    n = 60
+    uin = np.zeros((n, M, 7))      # hw, haplobase, haplocount, a0, a1, s0, s1
+    umeta = np.zeros((n, 3))       # children, descendants, scalefactor
+    uout = np.zeros((n, M, 3))     # hw, haplobase, haplocount after
+    uhits = np.zeros(n, np.int32)
+    for i in range(n):
+        children, desc = rs.randint(4), rs.randint(1, 9)
+        sf = rs.choice([0.013, 0.05, 0.19])
+        hw = np.where(rs.rand(M) < 0.15, 0.5, rs.rand(M))
+        hw[rs.rand(M) < 0.1] = rs.choice([0.0, 1.0])
+        hw[rs.rand(M) < 0.1] = rs.choice([1e-6, 1 - 1e-6, 5e-6])
+        hc = np.where(rs.rand(M) < 0.3, 0.0, rs.rand(M) * desc * 3)
+        if i % 5 == 0:
+            hc[:ped.chromstarts[1]] = 0                     # a chromosome without any information
+        hb = hc * np.clip(rs.rand(M) * 1.2 - 0.1, 0, 1)
+        a = rs.randint(0, 3, size=(M, 2))
+        s = np.where(rs.rand(M, 2) < 0.5, 0.02, rs.rand(M, 2) * 0.5)
+        s[rs.rand(M, 2) < 0.05] = 0.0
+        L.ref_set_stepsize(float(sf), 0, 0)
+        L.ref_set_counts(1, children, desc)
+        for m in range(M):
+            L.ref_set_marker(1, m, int(a[m, 0]), int(a[m, 1]), float(s[m, 0]), float(s[m, 1]), float(hw[m]))
+            L.ref_set_haplo_accumulators(1, m, float(hb[m]), float(hc[m]))
+        uhits[i] = L.ref_updatehaploweights(1)
+        buf = np.zeros(5)
+        acc = np.zeros(2)
+        for m in range(M):
+            L.ref_get_marker(1, m, buf.ctypes.data)
+            L.ref_get_haplo_accumulators(1, m, acc.ctypes.data)
+            uout[i, m] = (buf[4], acc[0], acc[1])
+        uin[i] = np.concatenate([hw[:, None], hb[:, None], hc[:, None], a, s], axis=1)
+        umeta[i] = (children, desc, sf)
+    out.update(uhw_in=uin, uhw_meta=umeta, uhw_out=uout, uhw_hits=uhits)
+    path = os.path.join(os.path.dirname(__file__), "update_units.npz")
+    np.savez_compressed(path, **out)
+    print("update units ->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    for name in CASES:
-        generate(name)
+    what = sys.argv[1:] or ["fixtures", "traj", "units"]
+    if "fixtures" in what:
+        for name in CASES:
+            generate(name)
+    if "traj" in what:
+        for name in TRAJ_CASES:
+            generate_trajectory(name)
+    if "units" in what:
+        generate_update_units()

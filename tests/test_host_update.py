@@ -2,7 +2,8 @@
 (cnf2freq_amd/csrc/cnf2_update.h, the header the update kernels include, compiled for the host) against the
 oracle's literal restatement of processinfprobs / updatehaploweights / cappedgd / relskewhmm
 (oracle/cnf2_oracle_iter.c, cnF2freq.cpp:4004-4734).  Tolerance 1e-9; parity of
-the restatement itself is unpinned: these ranges need Boost's quadrature, which the image lacks."""
+the restatement itself: bit-exact on goldens G14 (tests/test_oracle_iter_golden.py).  The last two tests put the product's
+form directly against G14, i.e. against the outputs of the reference's own functions."""
 import ctypes as C
 import os
 import subprocess
@@ -10,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN_DIR, ROOT
 from oracle import pyoracle
 
 SHIM_DIR = os.path.join(ROOT, "tests", "shim")
@@ -187,3 +188,45 @@ def test_scalefactor_control(shim):
         s1 = shim.shim_adapt_scalefactor(s1, hits, _p(old1), 100)
         s2 = O.cnf2o_scalefactor_step(s2, hits, _p(old2), 100)
         assert s1 == s2 and np.array_equal(old1, old2)
+
+
+def test_certainty_update_matches_the_reference_goldens(shim):
+    """update_certainty against G14: the reference's own processinfprobs on random inputs (cnF2freq.cpp:4179-4323).
+    Cases holding a key with value 0 are left out: the product takes an entry as present when it is > 0."""
+    z = np.load(os.path.join(GOLDEN_DIR, "update_units.npz"))
+    n = 0
+    for row, (want_a, want_s, want_hits) in zip(z["pip_in"], z["pip_out"]):
+        inf = np.array(row[0:2])
+        present = row[2:4].astype(bool)
+        if (present & ~(inf > 0)).any():
+            continue
+        inf = np.where(present, inf, 0.0)
+        side, cur, cursure, has_prior, priorval, priorsure, empty, children, sf = row[4:]
+        hits = C.c_int(0)
+        na, ns = C.c_int(int(cur)), D(cursure)
+        shim.shim_update_certainty(_p(inf), int(side), int(cur), float(cursure), int(has_prior),
+                                   int(priorval) if has_prior else 0, float(priorsure), int(empty), int(children), float(sf),
+                                   1.0, C.byref(hits), C.byref(na), C.byref(ns))
+        assert na.value == int(want_a)
+        assert abs(ns.value - want_s) < 1e-9
+        assert hits.value == int(want_hits)
+        n += 1
+    assert n > 400
+
+
+def test_haploweight_update_matches_the_reference_goldens(shim):
+    """update_haploweight / phase_ratio against G14: the reference's own updatehaploweights (cnF2freq.cpp:4533-4734)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "update_units.npz"))
+    cs = np.ascontiguousarray(z["chromstarts"], np.int32)
+    rel = np.full(int(cs[-1]), 0.5)
+    for x, (children, desc, sf), want, want_hits in zip(z["uhw_in"], z["uhw_meta"], z["uhw_out"], z["uhw_hits"]):
+        hw, hb, hc = (np.ascontiguousarray(x[:, k]) for k in range(3))
+        a32 = np.ascontiguousarray(x[:, 3:5], np.int32)
+        sure = np.ascontiguousarray(x[:, 5:7])
+        hits = C.c_int(0)
+        shim.shim_update_haploweights(len(cs) - 1, _p(cs), _p(hw), _p(hb), _p(hc), _p(a32), _p(sure), _p(rel), int(children),
+                                      int(desc), float(sf), 1.0, C.byref(hits))
+        np.testing.assert_allclose(hw, want[:, 0], rtol=1e-9, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(hb, want[:, 1], rtol=1e-9, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(hc, want[:, 2], rtol=1e-9, atol=1e-12, equal_nan=True)
+        assert hits.value == int(want_hits)
