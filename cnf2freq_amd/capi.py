@@ -18,6 +18,8 @@ OUT_DEVICE, NO_DOSAGE, RAW_DOSAGE, NO_TIES, FULL_SPILL, MERGE_MODES, ACC_DEVICE,
 ACC_TABLE = 1024
 ACC_LANES = 2048
 TIES_GENERAL = 4096
+UPDATE_PLAIN = 8192
+DETERMINISTIC = 16384
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -28,7 +30,7 @@ SYMBOLS = [
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
-    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
+    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -39,6 +41,28 @@ class Cnf2Error(RuntimeError):
 
 
 _lib = None
+
+
+def hip_runtimes():
+    """Paths of the HIP runtime libraries mapped into this process.  PyTorch's ROCm wheel carries its own libamdhip64.so
+    (SONAME libamdhip64.so.7); libcnf2hip.so asks for libamdhip64.so.7.  If torch is imported FIRST the loader hands its
+    copy to this library too (one runtime: device pointers, streams and RCCL buffers are interchangeable); the other way
+    round torch loads a second copy next to /opt/rocm's and the two do not know each other's allocations.  Processes
+    that use both import torch before the first cnf2freq_amd.capi.load()."""
+    paths = set()
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def require_single_hip_runtime():
+    r = hip_runtimes()
+    if len(r) > 1:
+        raise Cnf2Error("two HIP runtimes are loaded (%s): import torch before cnf2freq_amd loads libcnf2hip.so" % ", ".join(r))
 
 
 def load():
@@ -83,6 +107,9 @@ def load():
         L.cnf2_snapshot_priors.argtypes = [vp, vp]
         L.cnf2_update_pass.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, C.c_uint32]
         L.cnf2_download_rows.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.cnf2_download_accumulators.argtypes = [vp, vp, vp, vp]
+        L.cnf2_upload_accumulators.argtypes = [vp, vp, vp, vp]
+        L.cnf2_accumulator_ptrs.argtypes = [vp, vp, vp, vp]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
@@ -288,7 +315,7 @@ class Context:
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False, table_form=False, lane_form=False,
-                         ties_general=False):
+                         ties_general=False, deterministic=False):
         """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
@@ -304,7 +331,8 @@ class Context:
                                                _p(inf), _p(hb), _p(hc), _p(hz),
                                                (0 if ties else NO_TIES) | (RAW_DOSAGE if raw else 0)
                                                | (ACC_TABLE if table_form else 0) | (ACC_LANES if lane_form else 0)
-                                               | (TIES_GENERAL if ties_general else 0)),
+                                               | (TIES_GENERAL if ties_general else 0)
+                                               | (DETERMINISTIC if deterministic else 0)),
                   "cnf2_sweep_accumulate")
         return dict(factors=factors, loglik=loglik, dosage=dos, infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
@@ -346,7 +374,7 @@ class Context:
         assert len(hp) == self.n_rec
         self._chk(self.L.cnf2_snapshot_priors(self.h, _p(hp)), "cnf2_snapshot_priors")
 
-    def update_pass(self, chrom, children, descendants, scalefactor, entropyfactor=1.0, acc=None):
+    def update_pass(self, chrom, children, descendants, scalefactor, entropyfactor=1.0, acc=None, flags=0):
         """acc: dict with host arrays infprobs / haplobase / haplocount (updated in place), or None for the
         accumulators the last sweep_accumulate(..., keep=True) left in the context.  Returns hitnnn."""
         ch = np.ascontiguousarray(children, np.int32)
@@ -354,8 +382,28 @@ class Context:
         hits = np.zeros(1, np.int32)
         a = (None, None, None) if acc is None else (_p(acc["infprobs"]), _p(acc["haplobase"]), _p(acc["haplocount"]))
         self._chk(self.L.cnf2_update_pass(self.h, chrom, _p(ch), _p(de), a[0], a[1], a[2], scalefactor, entropyfactor,
-                                          _p(hits), 0), "cnf2_update_pass")
+                                          _p(hits), flags), "cnf2_update_pass")
         return int(hits[0])
+
+    def download_accumulators(self):
+        """The accumulators the context holds: dict(infprobs [R][M][2][2], haplobase [R][M], haplocount [R][M])."""
+        R, M = self.n_rec, self.n_markers
+        inf, hb, hc = np.zeros((R, M, 2, 2)), np.zeros((R, M)), np.zeros((R, M))
+        self._chk(self.L.cnf2_download_accumulators(self.h, _p(inf), _p(hb), _p(hc)), "cnf2_download_accumulators")
+        return dict(infprobs=inf, haplobase=hb, haplocount=hc)
+
+    @staticmethod
+    def accumulators_of(ctx_handle, n_rec, n_markers):
+        """download_accumulators() for a raw cnf2_ctx handle (e.g. cnf2h_context of a host run)."""
+        L = load()
+        inf, hb, hc = np.zeros((n_rec, n_markers, 2, 2)), np.zeros((n_rec, n_markers)), np.zeros((n_rec, n_markers))
+        if L.cnf2_download_accumulators(ctx_handle, _p(inf), _p(hb), _p(hc)) != 0:
+            raise Cnf2Error("cnf2_download_accumulators: " + L.cnf2_last_error(ctx_handle).decode())
+        return dict(infprobs=inf, haplobase=hb, haplocount=hc)
+
+    def upload_accumulators(self, acc):
+        a = [np.ascontiguousarray(acc[k], np.float64) for k in ("infprobs", "haplobase", "haplocount")]
+        self._chk(self.L.cnf2_upload_accumulators(self.h, _p(a[0]), _p(a[1]), _p(a[2])), "cnf2_upload_accumulators")
 
     def download_rows(self, row0, n):
         allele = np.zeros((n, self.n_markers, 2), np.uint8)

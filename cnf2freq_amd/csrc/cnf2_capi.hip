@@ -89,6 +89,13 @@ struct cnf2_ctx {
     double * d_fw = nullptr, *d_ratio = nullptr;
     size_t   fw_cap = 0, ratio_cap = 0;
     int*     d_hits = nullptr;
+    unsigned long long* d_flow_next = nullptr;
+    double*  d_flow_out = nullptr;
+    double*  d_part = nullptr;            // CNF2_DETERMINISTIC rows
+    size_t   part_cap = 0;
+    int32_t* d_gather = nullptr;          // rec_start [n_rec + 1] followed by the list
+    size_t   gather_cap = 0;
+    size_t   flow_out_cap = 0;
     int32_t* d_pathlog = nullptr;
     size_t   pathlog_cap = 0;
     int      pathlog_n = 0;
@@ -213,6 +220,10 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_fw);
     (void)hipFree(ctx->d_ratio);
     (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_flow_next);
+    (void)hipFree(ctx->d_flow_out);
+    (void)hipFree(ctx->d_part);
+    (void)hipFree(ctx->d_gather);
     (void)hipFree(ctx->d_scanwin);
     (void)hipFree(ctx->d_pathlog);
     (void)hipFree(ctx->d_okout);
@@ -414,6 +425,7 @@ int cnf2_upload_pedigree(cnf2_ctx* ctx, int n_rec, const int32_t* par, const uin
     P.row_hom.clear();
     ctx->windows.assign(n_dous, Window());
     ctx->windows_dirty = true;
+    ctx->priors_set = false;         // the per-record prior flags belong to the pedigree that was replaced
     return CNF2_OK;
 }
 
@@ -1082,6 +1094,33 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         q.acc_hc    = a_hc;
         q.acc_hz    = a_hz;
         q.max_len   = mlen;
+        std::vector<int32_t> gather;               // CNF2_DETERMINISTIC: rec_start[R + 1], then ind * 8 + slot per record
+        if (flags & CNF2_DETERMINISTIC) {
+            const size_t need = (size_t)n * M * 42;
+            if (need * sizeof(double) > free_b / 2)
+                return fail(ctx, CNF2_ERR_NOMEM, "CNF2_DETERMINISTIC needs %zu MB for the per-individual rows", (need * 8) >> 20);
+            if ((rc = ensure(ctx, &ctx->d_part, &ctx->part_cap, need))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_part, 0, need * sizeof(double), ctx->stream));
+            q.part = ctx->d_part;
+            std::vector<int32_t> count(R + 1, 0);
+            auto first_slots = [&](int j, auto&& f) {         // the slots that emit: first occurrence of their record
+                const int32_t* sr = &ctx->slot_rec[(size_t)(ind_begin + j) * 7];
+                for (int k = 0; k < 7; k++) {
+                    if (sr[k] < 0) continue;
+                    bool first = true;
+                    for (int k2 = 0; k2 < k; k2++) first = first && sr[k2] != sr[k];
+                    if (first) f(sr[k], k);
+                }
+            };
+            for (int j = 0; j < n; j++) first_slots(j, [&](int r, int) { count[r + 1]++; });
+            for (size_t r = 0; r < R; r++) count[r + 1] += count[r];
+            gather.assign(R + 1 + (size_t)count[R], 0);
+            std::copy(count.begin(), count.end(), gather.begin());
+            std::vector<int32_t> fill(count.begin(), count.end() - 1);
+            for (int j = 0; j < n; j++) first_slots(j, [&](int r, int k) { gather[R + 1 + fill[r]++] = j * 8 + k; });
+            if ((rc = ensure(ctx, &ctx->d_gather, &ctx->gather_cap, gather.size()))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_gather, gather.data(), gather.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (int pass = 0; pass < 2; pass++) {
             const size_t lo = pass ? n_fast : 0, hi = pass ? jobs.size() : n_fast;
@@ -1101,6 +1140,11 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 launch_acc_rows(q, ctx->stream);
                 HIP_TRY(ctx, hipGetLastError());
             }
+        }
+        if (q.part) {
+            launch_acc_gather(q, ctx->d_gather, ctx->d_gather + R + 1, (int)R, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // `gather` (host staging of the lists) goes out of scope
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         ctx->timed = true;
@@ -1289,12 +1333,17 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     if (acc_dev && !given) return fail(ctx, CNF2_ERR_ARG, "accumulator pointers are NULL");
     const HostPedigree& P = ctx->ped;
     const size_t R = (size_t)P.n_rec, M = (size_t)ctx->n_markers;
-    // a row that is written must belong to one record (all empty individuals may share the blank row: never written)
+    // a row that is written must belong to one record.  Row 0 is the shared blank row of a de-duplicated upload: the
+    // kernels never write it (a record on it keeps haplotype weight 1/2); every other row has exactly one owner, empty
+    // records included (updatehaploweights moves their weights too).
     {
         std::vector<int32_t> owner(ctx->n_rows, -1);
         for (int r = 0; r < P.n_rec; r++) {
-            if (P.empty[r]) continue;
-            if (owner[P.row_of[r]] >= 0) return fail(ctx, CNF2_ERR_ARG, "records %d and %d share genotype row %d: updates need one row per non-empty record", owner[P.row_of[r]], r, P.row_of[r]);
+            if (P.row_of[r] == 0) {
+                if (!P.empty[r]) return fail(ctx, CNF2_ERR_ARG, "record %d has data but sits on the blank row 0", r);
+                continue;
+            }
+            if (owner[P.row_of[r]] >= 0) return fail(ctx, CNF2_ERR_ARG, "records %d and %d share genotype row %d: updates need one row per record (or the blank row 0)", owner[P.row_of[r]], r, P.row_of[r]);
             owner[P.row_of[r]] = r;
         }
     }
@@ -1376,6 +1425,12 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     u.scalefactor = scalefactor;
     u.entropyfactor = entropyfactor;
     u.hits = ctx->d_hits;
+    if (!(flags & CNF2_UPDATE_PLAIN)) {
+        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 2 * sizeof(unsigned long long)));
+        if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)(u.last - u.first + 1) * 4))) return rc;
+        u.flow_next = ctx->d_flow_next;
+        u.flow_out = ctx->d_flow_out;
+    }
     launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->windows_dirty = true;          // rows changed: the "homozygous everywhere" flags must be derived again
@@ -1386,6 +1441,51 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
         HIP_TRY(ctx, hipMemcpyAsync(haplocount, a_hc, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_download_accumulators(cnf2_ctx* ctx, double* infprobs, double* haplobase, double* haplocount)
+{
+    if (!ctx) return fail(ctx, CNF2_ERR_ARG, "ctx is NULL");
+    const size_t R = (size_t)ctx->ped.n_rec, M = (size_t)ctx->n_markers;
+    if (!ctx->d_acc_inf || !ctx->d_acc_hb || !ctx->d_acc_hc || ctx->acc_inf_cap < R * M * 4 || ctx->acc_hb_cap < R * M ||
+        ctx->acc_hc_cap < R * M)
+        return fail(ctx, CNF2_ERR_STATE, "the context holds no accumulators (cnf2_sweep_accumulate with NULL accumulator pointers first)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (infprobs) HIP_TRY(ctx, hipMemcpy(infprobs, ctx->d_acc_inf, R * M * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (haplobase) HIP_TRY(ctx, hipMemcpy(haplobase, ctx->d_acc_hb, R * M * sizeof(double), hipMemcpyDeviceToHost));
+    if (haplocount) HIP_TRY(ctx, hipMemcpy(haplocount, ctx->d_acc_hc, R * M * sizeof(double), hipMemcpyDeviceToHost));
+    return CNF2_OK;
+}
+
+int cnf2_accumulator_ptrs(cnf2_ctx* ctx, double** infprobs, double** haplobase, double** haplocount)
+{
+    if (!ctx || !infprobs || !haplobase || !haplocount) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    const size_t R = (size_t)ctx->ped.n_rec, M = (size_t)ctx->n_markers;
+    if (!ctx->d_acc_inf || !ctx->d_acc_hb || !ctx->d_acc_hc || ctx->acc_inf_cap < R * M * 4 || ctx->acc_hb_cap < R * M ||
+        ctx->acc_hc_cap < R * M)
+        return fail(ctx, CNF2_ERR_STATE, "the context holds no accumulators (cnf2_sweep_accumulate with NULL accumulator pointers first)");
+    *infprobs = ctx->d_acc_inf;
+    *haplobase = ctx->d_acc_hb;
+    *haplocount = ctx->d_acc_hc;
+    return CNF2_OK;
+}
+
+int cnf2_upload_accumulators(cnf2_ctx* ctx, const double* infprobs, const double* haplobase, const double* haplocount)
+{
+    if (!ctx) return fail(ctx, CNF2_ERR_ARG, "ctx is NULL");
+    const size_t R = (size_t)ctx->ped.n_rec, M = (size_t)ctx->n_markers;
+    if (R == 0 || M == 0) return fail(ctx, CNF2_ERR_STATE, "map and pedigree must be uploaded first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, &ctx->d_acc_inf, &ctx->acc_inf_cap, R * M * 4))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_acc_hb, &ctx->acc_hb_cap, R * M))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_acc_hc, &ctx->acc_hc_cap, R * M))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (infprobs) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_inf, infprobs, R * M * 4 * sizeof(double), hipMemcpyHostToDevice));
+    if (haplobase) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_hb, haplobase, R * M * sizeof(double), hipMemcpyHostToDevice));
+    if (haplocount) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_hc, haplocount, R * M * sizeof(double), hipMemcpyHostToDevice));
     return CNF2_OK;
 }
 
@@ -1440,17 +1540,22 @@ int cnf2_fixparents_scan(cnf2_ctx* ctx, const int32_t* recs, int n, uint8_t* ok_
     if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
     if (n == 0) return CNF2_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = scan_windows(ctx, recs, n, 0);
-    if (rc) return rc;
-    const size_t cnt = (size_t)n * ctx->n_markers * 2;
-    if ((rc = ensure(ctx, &ctx->d_okout, &ctx->okout_cap, cnt))) return rc;
-    KernelParams p;
-    base_params(ctx, &p);
-    p.windows = ctx->d_scanwin;
-    launch_okvals(p, n, ctx->d_okout, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ok_out, ctx->d_okout, cnt, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // grid.y holds the record index: slabs of at most 65 535 records (a pedigree of config 4's size has ~300 000)
+    const int    slab = 65535;
+    const size_t per = (size_t)ctx->n_markers * 2;
+    int rc;
+    if ((rc = ensure(ctx, &ctx->d_okout, &ctx->okout_cap, (size_t)(n < slab ? n : slab) * per))) return rc;
+    for (int i0 = 0; i0 < n; i0 += slab) {
+        const int k = n - i0 < slab ? n - i0 : slab;
+        if ((rc = scan_windows(ctx, recs + i0, k, 0))) return rc;
+        KernelParams p;
+        base_params(ctx, &p);
+        p.windows = ctx->d_scanwin;
+        launch_okvals(p, k, ctx->d_okout, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ok_out + (size_t)i0 * per, ctx->d_okout, (size_t)k * per, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return CNF2_OK;
 }
 

@@ -90,8 +90,10 @@ struct AccParams {
     double*        acc_hb;       // [n_rec][n_markers] haplobase
     double*        acc_hc;       // [n_rec][n_markers] haplocount
     double*        acc_hz;       // [n_ind][n_markers][2] homozyg of the analysed individual (offset like windows)
+    double*        part;         // CNF2_DETERMINISTIC: [n_ind][n_markers][7][6] per-job rows (offset like windows), else null
 };
 void launch_acc_rows(const AccParams& q, hipStream_t stream);
+void launch_acc_gather(const AccParams& q, const int32_t* rec_start, const int32_t* list, int n_rec, hipStream_t stream);
 void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream);
 
@@ -121,6 +123,8 @@ struct UpdateParams {
     double         relhaplo;      // 0.5 on this path (cnF2freq.cpp:2496)
     double         scalefactor, entropyfactor;
     int*           hits;          // device counter
+    unsigned long long* flow_next;   // [2] item counters of the persistent flow kernels; null = one thread per element
+    double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);

@@ -2261,7 +2261,7 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
     if (!u.anyinfo[(size_t)r * u.n_chrom + c]) return;
     const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
     const double hw = u.hw[i];
-    if (!(hw != 0.0 && hw != 1.0)) return;                                  // cnF2freq.cpp:4591
+    if (!(hw != 0.0 && hw != 1.0) || u.row_of[r] == 0) return;              // cnF2freq.cpp:4591; the shared blank row is never written
     const uint8_t ap = u.allele8[i];
     const double2 su = u.sure[i];
     const size_t  k = (size_t)r * u.n_markers + m;
@@ -2276,15 +2276,192 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
     if (hits) atomicAdd(u.hits, hits);
 }
 
+// ---- the same two updates as persistent flow kernels ----------------------------------------------------------
+// A flow (cnf2_update.h) takes between 1 and 51 bisection steps of 16 gradient evaluations each, and the few per cent
+// that run into their cap always take all 51: with one thread per element nearly every wavefront waits for a lane like
+// that.  Here a wavefront runs ONE step of 64 independent flows at a time and hands a lane the next flow from a global
+// counter when its own has ended (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else is
+// running, because the set-up of a flow -- loads, the prior's logarithms, the gradient at the start -- is executed by the
+// whole wave).  Every wave ends when the counter has passed the last item and its lanes have drained.
+#define FLOW_REFILL 16
+
+// next items for the free lanes of the wave; returns false when the counter has passed n_items (wave-uniform)
+__device__ __forceinline__ bool flow_take(unsigned long long* next, unsigned long long n_items, bool want,
+                                          unsigned long long* item, bool* got)
+{
+    const unsigned long long need = __ballot(want);
+    const int                cnt = __popcll(need), leader = __ffsll((long long)need) - 1;
+    unsigned long long       base = 0;
+    if ((int)threadIdx.x == leader) base = atomicAdd(next, (unsigned long long)cnt);
+    base = __shfl(base, leader);
+    *got = false;
+    if (want) {
+        *item = base + (unsigned)__popcll(need & ((1ull << threadIdx.x) - 1ull));
+        *got = *item < n_items;
+    }
+    return base + (unsigned)cnt < n_items;
+}
+
+// item = ((r * len + mi) * 2 + side) * 2 + v: the flow of value v + 1 on one side of (record, marker);
+// flow_out[item] = its new probability (0 where the value has no evidence)
+__global__ __launch_bounds__(64) void certainty_flow_kernel(UpdateParams u, unsigned long long* next, double* flow_out)
+{
+    const int                len = u.last - u.first + 1;
+    const unsigned long long n_items = (unsigned long long)u.n_rec * len * 4;
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    bool               have = false, more = true;
+    unsigned long long item = 0;
+    CertaintyFlow      c;
+    FlowState          f;
+    int                hits = 0;
+    auto grad = [&](double x) { return certainty_rgradient(c, x); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if (more && (busy <= 64 - FLOW_REFILL)) {
+            bool got;
+            more = flow_take(next, n_items, !have, &item, &got);
+            if (got) {
+                const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
+                const unsigned long long e = item >> 2;
+                const int          r = (int)(e / len), m = u.first + (int)(e % len);
+                const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
+                const double       pair[2] = {inf[0], inf[1]};
+                const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
+                const bool         has_prior = u.has_prior[r] != 0;
+                const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
+                const double2      su = u.sure[i];
+                const double2      psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
+                SideState s;
+                s.allele = side ? (ap >> 4) : (ap & 15);
+                s.sure = side ? su.y : su.x;
+                s.prior_allele = side ? (pap >> 4) : (pap & 15);
+                s.prior_sure = side ? psu.y : psu.x;
+                if (certainty_flow_setup(pair, v, s, u.children[r], sc, &c)) {
+                    flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+                    have = true;
+                } else {
+                    flow_out[item] = 0.0;
+                }
+            }
+            continue;                       // lanes whose item held no flow ask again
+        }
+        if (busy == 0) break;               // nothing running and nothing left
+        if (have && !flow_advance(&f, grad, sc.scalefactor)) {
+            flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+            have = false;
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+}
+
+// one thread per (record, marker of the chromosome): cnF2freq.cpp:4292-4322 from the flows' results
+__global__ __launch_bounds__(256) void certainty_pick_kernel(UpdateParams u, const double* flow_out)
+{
+    const int    len = u.last - u.first + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * len) return;
+    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
+    const double4 a = *(const double4*)inf, o = *(const double4*)(flow_out + t * 4);
+    if (a.x == 0.0 && a.y == 0.0 && a.z == 0.0 && a.w == 0.0) return;          // nothing was added, nothing to clear
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool   has_prior = u.has_prior[r] != 0, empty = u.rec_empty[r] != 0;
+    uint8_t ap = u.allele8[i];
+    double2 su = u.sure[i];
+    bool    changed = false;
+    const double in2[2][2] = {{a.x, a.y}, {a.z, a.w}}, out2[2][2] = {{o.x, o.y}, {o.z, o.w}};
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        int    na;
+        double ns;
+        if (!(in2[side][0] > 0) && !(in2[side][1] > 0)) continue;
+        if (certainty_pick(in2[side], out2[side], side, empty, has_prior, &na, &ns)) {
+            if (side) {
+                ap = (uint8_t)((ap & 15) | (na << 4));
+                su.y = ns;
+            } else {
+                ap = (uint8_t)((ap & 0xF0) | na);
+                su.x = ns;
+            }
+            changed = true;
+        }
+    }
+    *(double4*)inf = make_double4(0.0, 0.0, 0.0, 0.0);          // infprobs[j][side].clear() (cnF2freq.cpp:4315)
+    if (changed) {
+        u.allele8[i] = ap;
+        u.sure[i] = su;
+    }
+}
+
+// item = r * upto + m over the markers of the chromosomes <= chrom
+__global__ __launch_bounds__(64) void haploweight_flow_kernel(UpdateParams u, unsigned long long* next)
+{
+    const int                upto = u.chromstarts_host_upto;
+    const unsigned long long n_items = (unsigned long long)u.n_rec * upto;
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    bool               have = false, more = true;
+    unsigned long long item = 0;
+    size_t             row_i = 0;
+    HaploFlow          h;
+    FlowState          f;
+    int                hits = 0;
+    auto grad = [&](double x) { return haplo_rgradient(h, x); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if (more && (busy <= 64 - FLOW_REFILL)) {
+            bool got;
+            more = flow_take(next, n_items, !have, &item, &got);
+            if (got) {
+                const int r = (int)(item / upto), m = (int)(item % upto);
+                int       c = 0;
+                while (m >= u.chromstarts[c + 1]) c++;
+                row_i = (size_t)u.row_of[r] * u.n_markers + m;
+                const double hw = u.hw[row_i];
+                if (u.anyinfo[(size_t)r * u.n_chrom + c] && hw != 0.0 && hw != 1.0 && u.row_of[r] != 0) {   // cnF2freq.cpp:4591
+                    const uint8_t ap = u.allele8[row_i];
+                    const double2 su = u.sure[row_i];
+                    const size_t  k = (size_t)r * u.n_markers + m;
+                    double hb = u.acc_hb[k], hcv = u.acc_hc[k];
+                    haplo_flow_setup(hw, &hb, &hcv, ap & 15, ap >> 4, su.x, su.y, u.ratio[k], u.children[r], u.descendants[r], sc,
+                                     &h);
+                    u.acc_hb[k] = hb;
+                    u.acc_hc[k] = hcv;
+                    flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+                    have = true;
+                }
+            }
+            continue;
+        }
+        if (busy == 0) break;
+        if (have && !flow_advance(&f, grad, sc.scalefactor)) {
+            u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+            have = false;
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+}
+
 void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 {
     const int    len = u.last - u.first + 1;
     const size_t n1 = (size_t)u.n_rec * len;
-    hipLaunchKernelGGL(certainty_update_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u);
-    const int n2 = u.n_rec * (u.chrom + 1);
-    hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+    const int    n2 = u.n_rec * (u.chrom + 1);
     const size_t n3 = (size_t)u.n_rec * u.chromstarts_host_upto;
-    hipLaunchKernelGGL(haploweight_update_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream, u);
+    if (!u.flow_next) {                                       // CNF2_UPDATE_PLAIN: one thread per element
+        hipLaunchKernelGGL(certainty_update_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u);
+        hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+        hipLaunchKernelGGL(haploweight_update_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream, u);
+        return;
+    }
+    const size_t resident = (size_t)256 * 16;                 // wavefronts the chip holds at 4 per SIMD
+    (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+    const size_t w1 = (n1 * 4 + 63) / 64, w3 = (n3 + 63) / 64;
+    hipLaunchKernelGGL(certainty_flow_kernel, dim3((unsigned)(w1 < resident ? w1 : resident)), dim3(64), 0, stream, u,
+                       u.flow_next, u.flow_out);
+    hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
+    hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+    hipLaunchKernelGGL(haploweight_flow_kernel, dim3((unsigned)(w3 < resident ? w3 : resident)), dim3(64), 0, stream, u,
+                       u.flow_next + 1);
 }
 
 // =====================================================================================
@@ -2298,6 +2475,58 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 //      3577-3616) with f64 atomics into the per-record arrays.
 // Not tuned beyond the algebra (the table entries are evaluated by the plain host/device code of cnf2_accum.h).
 // =====================================================================================
+// What a window member receives at a locus (moveinfprobs / movehaplos, cnF2freq.cpp:3577-3616).  Default: f64 atomics on
+// the per-record slabs (ranks and jobs add in whatever order they arrive).  CNF2_DETERMINISTIC (q.part != null): the six
+// values go to the job's own row part[ind][m][slot][6] instead, and acc_gather_kernel adds the rows of a record in
+// ascending order of the analysed individual -- one writer per element, the same sum to the bit on every run.
+__device__ __forceinline__ void acc_emit(const AccParams& q, int ind, int slot, int rec, int m, const double inf[4], double norm,
+                                         bool hap, double hbv, double hcv)
+{
+    const size_t M = (size_t)q.kp.n_markers;
+    if (q.part) {
+        double* d = q.part + (((size_t)ind * M + m) * 7 + slot) * 6;
+#pragma unroll
+        for (int t = 0; t < 4; t++) d[t] = inf[t] * norm;
+        d[4] = hap ? hbv : 0.0;
+        d[5] = hap ? hcv : 0.0;
+        return;
+    }
+    double* dst = q.acc_inf + ((size_t)rec * M + m) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
+    if (hap) {
+        atomicAdd(q.acc_hb + (size_t)rec * M + m, hbv);
+        atomicAdd(q.acc_hc + (size_t)rec * M + m, hcv);
+    }
+}
+
+// CNF2_DETERMINISTIC: one thread per (record, marker) adds the rows its record received, in the order of list
+// (ascending analysed individual, then slot): list[rec_start[r] .. rec_start[r + 1]) holds ind * 8 + slot.
+__global__ __launch_bounds__(256) void acc_gather_kernel(AccParams q, const int32_t* rec_start, const int32_t* list, int n_rec)
+{
+    const size_t M = (size_t)q.kp.n_markers;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_rec * M) return;
+    const int    r = (int)(t / M), m = (int)(t % M);
+    double       v[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = rec_start[r]; e < rec_start[r + 1]; e++) {
+        const int     ind = list[e] >> 3, slot = list[e] & 7;
+        const double* d = q.part + (((size_t)ind * M + m) * 7 + slot) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] += d[i];
+    }
+    double* dst = q.acc_inf + t * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dst[i] += v[i];
+    q.acc_hb[t] += v[4];
+    q.acc_hc[t] += v[5];
+}
+void launch_acc_gather(const AccParams& q, const int32_t* rec_start, const int32_t* list, int n_rec, hipStream_t stream)
+{
+    const size_t n = (size_t)n_rec * q.kp.n_markers;
+    hipLaunchKernelGGL(acc_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, rec_start, list, n_rec);
+}
+
 // The per-locus reductions of doit for one (job, marker) (cnF2freq.cpp:5876-5902, 3577-3616): out[44] = inf[7][2][2],
 // homozyg[2], haplos[7][2] of the window's slots -> homozyg scale, moveinfprobs, movehaplos with f64 atomics.
 __device__ __forceinline__ void acc_reduce_locus(const AccParams& q, const Job& jb, int m, int lane, double* out)
@@ -2339,17 +2568,11 @@ __device__ __forceinline__ void acc_reduce_locus(const AccParams& q, const Job& 
             double       norm = sum * 2;                                                       // cnF2freq.cpp:3582-3587
             for (int t = 0; t < occ; t++) norm /= 2;
             norm *= descf;
-            double* dst = q.acc_inf + ((size_t)r * p.n_markers + m) * 4;
-            for (int t = 0; t < 4; t++) atomicAdd(dst + t, inf[t] * norm);
-            if (h0 != 0.0 || h1 != 0.0) {                                                      // cnF2freq.cpp:3601-3616
-                if (fabs(mine.hw - 0.5) < 0.5 - 1e-12) {
-                    const double md = (double)0.000005f;
-                    const double b1 = h0 + exp(-400.0) * md * md * 0.5;
-                    const double b2 = h1 + exp(-400.0) * md * md * 0.5;
-                    atomicAdd(q.acc_hb + (size_t)r * p.n_markers + m, b1 / (b1 + b2) * descf);
-                    atomicAdd(q.acc_hc + (size_t)r * p.n_markers + m, descf);
-                }
-            }
+            const bool   hap = (h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12;      // cnF2freq.cpp:3601-3616
+            const double md = (double)0.000005f;
+            const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+            const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+            acc_emit(q, jb.ind, k, r, m, inf, norm, hap, b1 / (b1 + b2) * descf, descf);
         }
     }
 }
@@ -2905,16 +3128,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, CNF2_APL_MINBLOCKS) void acc_paths_kern
             h1 += out[30 + k2 * 2 + 1];
         }
         const double norm = sum * mynorm;
-        double*      dst = q.acc_inf + ((size_t)myrec * p.n_markers + m) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) atomicAdd(dst + i, inf[i] * norm);
-        if ((h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12) {                       // cnF2freq.cpp:3601-3616
-            const double md = (double)0.000005f;
-            const double b1 = h0 + exp(-400.0) * md * md * 0.5;
-            const double b2 = h1 + exp(-400.0) * md * md * 0.5;
-            atomicAdd(q.acc_hb + (size_t)myrec * p.n_markers + m, b1 / (b1 + b2) * descf);
-            atomicAdd(q.acc_hc + (size_t)myrec * p.n_markers + m, descf);
-        }
+        const bool   hap = (h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12;         // cnF2freq.cpp:3601-3616
+        const double md = (double)0.000005f;
+        const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+        const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+        acc_emit(q, jb.ind, kk, myrec, m, inf, norm, hap, b1 / (b1 + b2) * descf, descf);
     }
   }
 }
@@ -3291,16 +3509,11 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
                 h1 += out[30 + k2 * 2 + 1];
             }
             const double norm = sum * mynorm;
-            double*      dst = q.acc_inf + ((size_t)myrec * p.n_markers + m) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; i++) atomicAdd(dst + i, inf[i] * norm);
-            if ((h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12) {                   // cnF2freq.cpp:3601-3616
-                const double md = (double)0.000005f;
-                const double b1 = h0 + exp(-400.0) * md * md * 0.5;
-                const double b2 = h1 + exp(-400.0) * md * md * 0.5;
-                atomicAdd(q.acc_hb + (size_t)myrec * p.n_markers + m, b1 / (b1 + b2) * descf);
-                atomicAdd(q.acc_hc + (size_t)myrec * p.n_markers + m, descf);
-            }
+            const bool   hap = (h0 != 0.0 || h1 != 0.0) && fabs(mine.hw - 0.5) < 0.5 - 1e-12;     // cnF2freq.cpp:3601-3616
+            const double md = (double)0.000005f;
+            const double b1 = h0 + exp(-400.0) * md * md * 0.5;
+            const double b2 = h1 + exp(-400.0) * md * md * 0.5;
+            acc_emit(q, jb.ind, kk, myrec, m, inf, norm, hap, b1 / (b1 + b2) * descf, descf);
         }
     }
 }

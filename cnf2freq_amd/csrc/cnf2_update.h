@@ -121,51 +121,85 @@ CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits
 }
 
 // cappedgd (cnF2freq.cpp:4040-4177, the branch that is compiled in): rgradient(x) -> dt/dp = 1 / (dp/dt) at x (the
-// callers form the reciprocal of their gradient as ONE quotient).
+// callers form the reciprocal of their gradient as ONE quotient).  The bisection is kept as data (FlowState) with
+// begin / advance / end, so that the device kernels can run one step of 64 independent flows per wavefront and hand a
+// lane the next flow as soon as its own has ended (flows take between 1 and 51 steps); flow_step() is the plain loop.
+struct FlowState {
+    double orig, epsilon, lolim, hilim, lo, hi;
+    int    it;            // steps taken so far
+    bool   falling;       // the gradient at the starting point is negative
+    bool   live;          // more steps to take
+};
+template <class G>
+CNF2_UHD double flow_pace(G&& rgradient, double v, double epsilon)      // dt/dp at the clamped position
+{
+    const double top = 1.0 - epsilon;
+    v = (v < epsilon) ? epsilon : ((top < v) ? top : v);
+    return rgradient(v);
+}
+template <class G>
+CNF2_UHD void flow_begin(FlowState* f, G&& rgradient, double orig, double epsilon, double scalefactor, bool breakathalf)
+{
+    const double top = 1.0 - epsilon;
+    int          ignored = 0;
+    // bisection bracket: slightly wider than the cap, so that the final cap_step is the one that counts the hit
+    f->epsilon = epsilon;
+    f->lolim = cap_step(epsilon, orig, epsilon, &ignored, breakathalf);
+    f->hilim = cap_step(top, orig, epsilon, &ignored, breakathalf);
+    f->lo = f->lolim - epsilon * 0.125;
+    f->hi = f->hilim + epsilon * 0.125;
+    f->orig = cap_step(orig, orig, epsilon, &ignored, breakathalf);
+    const double g0 = flow_pace(rgradient, f->orig, epsilon);
+    if (!isfinite(g0) || !scalefactor) f->lo = f->hi = f->orig;
+    f->falling = g0 < 0;
+    if (f->falling) f->hi = f->orig;
+    else f->lo = f->orig;
+    f->it = 0;
+    f->live = scalefactor != 0;
+}
+// one bisection step; returns whether another one follows
+template <class G>
+CNF2_UHD bool flow_advance(FlowState* f, G&& rgradient, double scalefactor)
+{
+    if (!f->live) return false;
+    if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) return f->live = false;   // done / outside the true bounds
+    f->it++;
+    const double mid = (f->lo + f->hi) / 2;
+    const double gm = flow_pace(rgradient, mid, f->epsilon);
+    double       t;                                          // time the flow needs from orig to mid
+    if (((gm < 0) != f->falling) || !isfinite(gm)) {
+        t = (scalefactor + 0.1) * 1.1;                        // the gradient turns round before mid: too far
+    } else {
+        double a = f->orig, b = mid;
+        if (a > b) {
+            const double s = a;
+            a = b;
+            b = s;
+        }
+        if (b - a < 1e-10) return f->live = false;
+        const double eps = f->epsilon;
+        t = gauss15([&](double v) { return flow_pace(rgradient, v, eps); }, a, b);
+        if (b != mid) t = -t;
+        if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+    }
+    if (fabs(t - scalefactor) < scalefactor * 1e-3) return f->live = false;
+    if ((t < scalefactor) != f->falling) f->lo = mid;
+    else f->hi = mid;
+    return true;
+}
+CNF2_UHD double flow_end(const FlowState& f, double scalefactor, int* hits, bool breakathalf)
+{
+    double lo = f.lo, hi = f.hi;
+    if (!scalefactor) lo = hi = f.orig;
+    return cap_step((lo + hi) / 2, f.orig, f.epsilon, hits, breakathalf);
+}
 template <class G>
 CNF2_UHD double flow_step(G&& rgradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
 {
-    const double top = 1.0 - epsilon;
-    auto pace = [&](double v) -> double {          // dt/dp at the clamped position
-        v = (v < epsilon) ? epsilon : ((top < v) ? top : v);
-        return rgradient(v);
-    };
-    int          ignored = 0;
-    // bisection bracket: slightly wider than the cap, so that the final cap_step is the one that counts the hit
-    const double lolim = cap_step(epsilon, orig, epsilon, &ignored, breakathalf);
-    const double hilim = cap_step(top, orig, epsilon, &ignored, breakathalf);
-    double       lo = lolim - epsilon * 0.125, hi = hilim + epsilon * 0.125;
-    orig = cap_step(orig, orig, epsilon, &ignored, breakathalf);
-    const double g0 = pace(orig);
-    if (!isfinite(g0) || !scalefactor) lo = hi = orig;
-    const bool falling = g0 < 0;
-    if (falling) hi = orig;
-    else lo = orig;
-    for (int it = 0; it < 51 && scalefactor; it++) {
-        if (lo > hilim || hi < lolim) break;                 // outside the true bounds
-        const double mid = (lo + hi) / 2;
-        const double gm = pace(mid);
-        double       t;                                      // time the flow needs from orig to mid
-        if (((gm < 0) != falling) || !isfinite(gm)) {
-            t = (scalefactor + 0.1) * 1.1;                    // the gradient turns round before mid: too far
-        } else {
-            double a = orig, b = mid;
-            if (a > b) {
-                const double s = a;
-                a = b;
-                b = s;
-            }
-            if (b - a < 1e-10) break;
-            t = gauss15(pace, a, b);
-            if (b != mid) t = -t;
-            if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
-        }
-        if (fabs(t - scalefactor) < scalefactor * 1e-3) break;
-        if ((t < scalefactor) != falling) lo = mid;
-        else hi = mid;
-    }
-    if (!scalefactor) lo = hi = orig;
-    return cap_step((lo + hi) / 2, orig, epsilon, hits, breakathalf);
+    FlowState f;
+    flow_begin(&f, rgradient, orig, epsilon, scalefactor, breakathalf);
+    while (flow_advance(&f, rgradient, scalefactor)) {}
+    return flow_end(f, scalefactor, hits, breakathalf);
 }
 
 // The data term shared by both updates.  With a current value y of the parameter, g the evidence for "1" gathered
@@ -243,43 +277,53 @@ struct SideState {
     double prior_sure;
 };
 
-// Returns true when the side's allele / sure are to be overwritten with *new_allele / *new_sure
-// (cnF2freq.cpp:4303-4313: non-empty individuals that have a prior, i.e. that were genotyped).
-CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side, bool empty, bool has_prior,
-                               int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure)
+// The flow of ONE value v + 1 of a side as data: gradient = data + entropy (log(1/x - 1) = -logit) + prior
+// = (N + Q^2 E) / Q^2; its reciprocal is formed as one quotient.
+struct CertaintyFlow {
+    Evidence ev;
+    double   ef, priord;
+    double   curprob, epsilon;
+};
+// false when the value takes no part (no evidence for it)
+CNF2_UHD bool certainty_flow_setup(const double inf[2], int v, const SideState& s, int children, const StepControl& sc,
+                                   CertaintyFlow* c)
 {
+    if (!(inf[v] > 0)) return false;
     double sum = 0;
-    for (int v = 0; v < 2; v++)
-        if (inf[v] > 0) sum += inf[v];
-    const double ef = sc.entropyfactor;                       // exp(0 * -0.01 * iter) * entropyfactor
-    const double epsilon = clamp_distance(children);
-    double       out[2] = {0, 0};
-    for (int v = 0; v < 2; v++) {
-        if (!(inf[v] > 0)) continue;
-        const int value = v + 1;
-        double    curprob = 0.5;
-        if (s.allele != 0) curprob = fabs((s.allele == value ? 1 : 0) - s.sure);
-        const double evidence = inf[v];
-        double       priord = 0;
-        if (s.prior_allele != 0) {                            // cnF2freq.cpp:4245-4268
-            double priorprob = 1.0 - s.prior_sure;
-            if (value != s.prior_allele) priorprob = 1.0 - priorprob;
-            if (priorprob == 0) priord -= 10000;
-            else if (priorprob == 1) priord += 10000;
-            else {
-                priorprob = priorprob < 1e-14 ? 1e-14 : (priorprob > 1 - 1e-14 ? 1 - 1e-14 : priorprob);
-                priord += log(priorprob) - log(1 - priorprob);
-            }
+    for (int k = 0; k < 2; k++)
+        if (inf[k] > 0) sum += inf[k];
+    const int value = v + 1;
+    double    curprob = 0.5;
+    if (s.allele != 0) curprob = fabs((s.allele == value ? 1 : 0) - s.sure);
+    double priord = 0;
+    if (s.prior_allele != 0) {                                // cnF2freq.cpp:4245-4268
+        double priorprob = 1.0 - s.prior_sure;
+        if (value != s.prior_allele) priorprob = 1.0 - priorprob;
+        if (priorprob == 0) priord -= 10000;
+        else if (priorprob == 1) priord += 10000;
+        else {
+            priorprob = priorprob < 1e-14 ? 1e-14 : (priorprob > 1 - 1e-14 ? 1 - 1e-14 : priorprob);
+            priord += log(priorprob) - log(1 - priorprob);
         }
-        const Evidence ev = evidence_terms(curprob, evidence, sum);
-        // gradient = data + entropy (log(1/x - 1) = -logit) + prior = (N + Q^2 E) / Q^2; its reciprocal as one quotient
-        auto rgradient = [&](double x) -> double {
-            const double lg = logit(x);
-            const double q = ev.b * (1.0 - x) + ev.a * x, q2 = q * q;
-            return upd_div(q2, (ev.ab * lg + ev.amb * q) + q2 * (ef * (priord - lg)));
-        };
-        out[v] = flow_step(rgradient, curprob, epsilon, sc.scalefactor, hits, false);
     }
+    c->ev = evidence_terms(curprob, inf[v], sum);
+    c->ef = sc.entropyfactor;                                 // exp(0 * -0.01 * iter) * entropyfactor
+    c->priord = priord;
+    c->curprob = curprob;
+    c->epsilon = clamp_distance(children);
+    return true;
+}
+CNF2_UHD double certainty_rgradient(const CertaintyFlow& c, double x)
+{
+    const double lg = logit(x);
+    const double q = c.ev.b * (1.0 - x) + c.ev.a * x, q2 = q * q;
+    return upd_div(q2, (c.ev.ab * lg + c.ev.amb * q) + q2 * (c.ef * (c.priord - lg)));
+}
+// cnF2freq.cpp:4292-4313: the more probable value wins; true when the side's allele / sure are to be overwritten
+// (non-empty individuals that have a prior, i.e. that were genotyped).  out[v] = the new probability of value v + 1.
+CNF2_UHD bool certainty_pick(const double inf[2], const double out[2], int side, bool empty, bool has_prior,
+                             int* new_allele, double* new_sure)
+{
     int    best = 0;
     double bestprob = 0;
     for (int v = 0; v < 2; v++) {
@@ -295,6 +339,18 @@ CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side
         return true;
     }
     return false;
+}
+CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side, bool empty, bool has_prior,
+                               int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure)
+{
+    double out[2] = {0, 0};
+    for (int v = 0; v < 2; v++) {
+        CertaintyFlow c;
+        if (!certainty_flow_setup(inf, v, s, children, sc, &c)) continue;
+        out[v] = flow_step([&](double x) { return certainty_rgradient(c, x); }, c.curprob, c.epsilon, sc.scalefactor, hits,
+                           false);
+    }
+    return certainty_pick(inf, out, side, empty, has_prior, new_allele, new_sure);
 }
 
 // ------------------------------------------------------------------ phase-consistency ratio (relskewhmm)
@@ -345,9 +401,14 @@ CNF2_UHD void phase_ratio(const double* hw, const double* relhaplo, int first, i
 // One marker of one individual whose chromosome has any information (some haplocount != 0) and whose weight is
 // neither 0 nor 1 (locked).  haplobase / haplocount are read AND rewritten (the reference leaves the adjusted
 // values in place, cnF2freq.cpp:4660-4676: they are what a later pass of the same iteration sees).
-CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0,
-                                   double sure1, double phaseratio, int children, int descendants,
-                                   const StepControl& sc, bool breakathalf, int* hits)
+struct HaploFlow {
+    Evidence ev;
+    double   ent, phaseratio, descendants;
+    double   epsilon;
+};
+// rewrites haplobase / haplocount (cnF2freq.cpp:4660-4677) and forms the gradient's data
+CNF2_UHD void haplo_flow_setup(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0, double sure1,
+                               double phaseratio, int children, int descendants, const StepControl& sc, HaploFlow* h)
 {
     const double scorea = 1.0 - sure0;
     double       scoreb = 1.0 - sure1;
@@ -366,18 +427,27 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
         if (*haplobase < 0) *haplobase = 0;
         if (*haplobase >= *haplocount) *haplobase = *haplocount;
     }
-    const double ef = sc.entropyfactor;
-    const double b = *haplobase, c = *haplocount;
-    const Evidence ev = evidence_terms(hw, b, c);
-    const double   ent = (1 - similarity) * ef;
-    // gradient = data + phase consistency + entropy = (N + Q^2 E) / Q^2; its reciprocal as one quotient
-    auto rgradient = [&](double x) -> double {
-        const double lg = logit(x);
-        const double q = ev.b * (1.0 - x) + ev.a * x, q2 = q * q;
-        const double e = upd_div(phaseratio - x, x - x * x) * descendants - ent * lg;
-        return upd_div(q2, (ev.ab * lg + ev.amb * q) + q2 * e);
-    };
-    return flow_step(rgradient, hw, clamp_distance(children), sc.scalefactor, hits, breakathalf);
+    h->ev = evidence_terms(hw, *haplobase, *haplocount);
+    h->ent = (1 - similarity) * sc.entropyfactor;
+    h->phaseratio = phaseratio;
+    h->descendants = descendants;
+    h->epsilon = clamp_distance(children);
+}
+// gradient = data + phase consistency + entropy = (N + Q^2 E) / Q^2; its reciprocal as one quotient
+CNF2_UHD double haplo_rgradient(const HaploFlow& h, double x)
+{
+    const double lg = logit(x);
+    const double q = h.ev.b * (1.0 - x) + h.ev.a * x, q2 = q * q;
+    const double e = upd_div(h.phaseratio - x, x - x * x) * h.descendants - h.ent * lg;
+    return upd_div(q2, (h.ev.ab * lg + h.ev.amb * q) + q2 * e);
+}
+CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0,
+                                   double sure1, double phaseratio, int children, int descendants,
+                                   const StepControl& sc, bool breakathalf, int* hits)
+{
+    HaploFlow h;
+    haplo_flow_setup(hw, haplobase, haplocount, a0, a1, sure0, sure1, phaseratio, children, descendants, sc, &h);
+    return flow_step([&](double x) { return haplo_rgradient(h, x); }, hw, h.epsilon, sc.scalefactor, hits, breakathalf);
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).

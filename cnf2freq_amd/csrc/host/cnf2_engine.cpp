@@ -15,10 +15,7 @@ Engine::Engine(Pedigree& ped, cnf2_ctx* c, const EngineOptions& o) : P(ped), ctx
 
 void Engine::check(int rc, const char* what)
 {
-    if (rc != CNF2_OK) {
-        fprintf(stderr, "%s failed (%d): %s\n", what, rc, cnf2_last_error(ctx));
-        abort();   // the reference aborts on any failure (cnF2freq.cpp:21-25)
-    }
+    if (rc != CNF2_OK) throw EngineError(rc, std::string(what) + " failed: " + cnf2_last_error(ctx));
 }
 
 void Engine::upload()
@@ -43,34 +40,95 @@ void Engine::upload()
     lockstart_.assign(P.inds.size() * (size_t)(C > 0 ? C : 1), 0);
 }
 
+// rows travel in slabs of records: the staging copy stays bounded (config 4: 300 000 records x 200 080 markers would be
+// half a terabyte in one piece)
+static const size_t ROW_SLAB_BYTES = (size_t)256 << 20;
+
 void Engine::push_rows()
 {
     const int R = (int)P.inds.size();
-    std::vector<uint8_t> allele((size_t)R * M * 2);
-    std::vector<double>  sure((size_t)R * M * 2), hw((size_t)R * M);
-    for (int r = 0; r < R; r++) {
-        const Individual& I = P.inds[r];
-        std::copy(I.allele.begin(), I.allele.end(), allele.begin() + (size_t)r * M * 2);
-        std::copy(I.sure.begin(), I.sure.end(), sure.begin() + (size_t)r * M * 2);
-        std::copy(I.hw.begin(), I.hw.end(), hw.begin() + (size_t)r * M);
+    if (R == 0) return;
+    const int slab = (int)std::max<size_t>(1, ROW_SLAB_BYTES / ((size_t)M * 26));
+    std::vector<uint8_t> allele((size_t)std::min(R, slab) * M * 2);
+    std::vector<double>  sure((size_t)std::min(R, slab) * M * 2), hw((size_t)std::min(R, slab) * M);
+    for (int r0 = 0; r0 < R; r0 += slab) {
+        const int k = std::min(slab, R - r0);
+        for (int r = 0; r < k; r++) {
+            const Individual& I = P.inds[r0 + r];
+            std::copy(I.allele.begin(), I.allele.end(), allele.begin() + (size_t)r * M * 2);
+            std::copy(I.sure.begin(), I.sure.end(), sure.begin() + (size_t)r * M * 2);
+            std::copy(I.hw.begin(), I.hw.end(), hw.begin() + (size_t)r * M);
+        }
+        check(cnf2_update_rows(ctx, 1 + r0, k, allele.data(), sure.data(), hw.data()), "cnf2_update_rows");
     }
-    if (R > 0) check(cnf2_update_rows(ctx, 1, R, allele.data(), sure.data(), hw.data()), "cnf2_update_rows");
+    rows_stale_ = false;
 }
 
 void Engine::pull_rows()
 {
     const int R = (int)P.inds.size();
     if (R == 0) return;
-    std::vector<uint8_t> allele((size_t)R * M * 2);
-    std::vector<double>  sure((size_t)R * M * 2), hw((size_t)R * M);
-    check(cnf2_download_rows(ctx, 1, R, allele.data(), sure.data(), hw.data()), "cnf2_download_rows");
-    for (int r = 0; r < R; r++) {
-        Individual& I = P.inds[r];
-        std::copy(allele.begin() + (size_t)r * M * 2, allele.begin() + (size_t)(r + 1) * M * 2, I.allele.begin());
-        std::copy(sure.begin() + (size_t)r * M * 2, sure.begin() + (size_t)(r + 1) * M * 2, I.sure.begin());
-        std::copy(hw.begin() + (size_t)r * M, hw.begin() + (size_t)(r + 1) * M, I.hw.begin());
+    const int slab = (int)std::max<size_t>(1, ROW_SLAB_BYTES / ((size_t)M * 26));
+    std::vector<uint8_t> allele((size_t)std::min(R, slab) * M * 2);
+    std::vector<double>  sure((size_t)std::min(R, slab) * M * 2), hw((size_t)std::min(R, slab) * M);
+    for (int r0 = 0; r0 < R; r0 += slab) {
+        const int k = std::min(slab, R - r0);
+        check(cnf2_download_rows(ctx, 1 + r0, k, allele.data(), sure.data(), hw.data()), "cnf2_download_rows");
+        for (int r = 0; r < k; r++) {
+            Individual& I = P.inds[r0 + r];
+            std::copy(allele.begin() + (size_t)r * M * 2, allele.begin() + (size_t)(r + 1) * M * 2, I.allele.begin());
+            std::copy(sure.begin() + (size_t)r * M * 2, sure.begin() + (size_t)(r + 1) * M * 2, I.sure.begin());
+            std::copy(hw.begin() + (size_t)r * M, hw.begin() + (size_t)(r + 1) * M, I.hw.begin());
+        }
     }
     rows_stale_ = false;
+}
+
+void Engine::set_block(int begin, int end)
+{
+    if (begin < 0 || end > N || begin > end) throw EngineError(CNF2_ERR_ARG, "block of analysed individuals out of range");
+    block_begin_ = begin;
+    block_end_ = end;
+}
+
+std::vector<double> Engine::work_costs()
+{
+    std::vector<double> cost(N, 0.0);
+    for (int j = 0; j < N; j++) {
+        int32_t w[17];
+        check(cnf2_window_info(ctx, j, w), "cnf2_window_info");
+        int groups = 0;
+        for (int k = 0; k < 7; k++) groups = std::max(groups, w[10 + k] + 1);
+        cost[j] = (double)M * (1.0 + (double)(1 << groups));
+    }
+    return cost;
+}
+
+void Engine::balanced_block(int rank, int world, int* begin, int* end)
+{
+    if (world < 1 || rank < 0 || rank >= world) throw EngineError(CNF2_ERR_ARG, "rank out of range");
+    const std::vector<double> cost = work_costs();
+    double total = 0;
+    for (double c : cost) total += c;
+    // boundary b_k = first individual whose prefix cost reaches k / world of the total
+    auto boundary = [&](int k) {
+        if (k <= 0) return 0;
+        if (k >= world) return N;
+        const double target = total * k / world;
+        double       run = 0;
+        for (int j = 0; j < N; j++) {
+            if (run + 0.5 * cost[j] >= target) return j;
+            run += cost[j];
+        }
+        return N;
+    };
+    *begin = boundary(rank);
+    *end = boundary(rank + 1);
+}
+
+void Engine::accumulators(double* haplobase, double* haplocount)
+{
+    check(cnf2_download_accumulators(ctx, nullptr, haplobase, haplocount), "cnf2_download_accumulators");
 }
 
 // dosureval (cnF2freq.cpp:3084-3097): certainty from the number of supporting relatives and the product of their odds
@@ -83,6 +141,7 @@ static double sureval_from(int what, int /*count*/, double oddsproduct)
 
 void Engine::postmarkerdata(int indcount)
 {
+    sync_rows();                // the genotype inference below works on the host copies of the rows
     const int R = (int)P.inds.size();
     // individuals the reference's loops reach: numbers 1 .. indcount - 1
     auto in_scope = [&](int r) { return P.inds[r].n < indcount; };
@@ -323,8 +382,11 @@ void Engine::postmarkerdata(int indcount)
             if (ls >= P.chromstarts[c + 1]) ls = 0;
             int    bestpos = -1;
             double bestvar = 0;
+            // the reference takes the first marker of strictly largest variance.  Markers whose genotype configuration is
+            // the same have the same variance to the bit there; here the closed form agrees with it to ~1e-9 only, so a
+            // marker must beat the best one so far by more than that to replace it (ties go to the first, as there)
             for (int j = std::max(P.chromstarts[c], ls); j != P.chromstarts[c + 1]; j++)
-                if (variances_[(size_t)r * M + j] > bestvar) {
+                if (variances_[(size_t)r * M + j] > bestvar * (1.0 + 1e-8)) {
                     bestpos = j;
                     bestvar = variances_[(size_t)r * M + j];
                 }
@@ -421,35 +483,48 @@ void Engine::iteration(FILE* out)
     std::vector<int32_t> desc(descendants_.begin(), descendants_.end());
     for (auto& d : desc)
         if (d == 0) d = 1;     // postmarkerdata leaves no zero; a run without it counts every individual once
-    std::vector<double> factors((size_t)N * C * 8), loglik((size_t)N * C), dosage(opt.print_rows ? (size_t)N * M * 3 : 0);
-    const uint32_t rowflag = opt.normalise ? 0 : CNF2_RAW_DOSAGE;
+    // this rank's block of analysed individuals (all of them in a single-process run)
+    const int b0 = block_end_ < 0 ? 0 : block_begin_, b1 = block_end_ < 0 ? N : block_end_, nb = b1 - b0;
+    std::vector<double> factors((size_t)nb * C * 8), loglik((size_t)nb * C), dosage(opt.print_rows ? (size_t)nb * M * 3 : 0);
+    const uint32_t rowflag = (opt.normalise ? 0 : CNF2_RAW_DOSAGE) | (deterministic_ ? CNF2_DETERMINISTIC : 0);
     if (N > 0) {
         if (opt.update)
-            check(cnf2_sweep_accumulate(ctx, 0, N, desc.data(), factors.data(), loglik.data(),
+            check(cnf2_sweep_accumulate(ctx, b0, b1, desc.data(), factors.data(), loglik.data(),
                                         opt.print_rows ? dosage.data() : nullptr, nullptr, nullptr, nullptr, nullptr, rowflag),
                   "cnf2_sweep_accumulate");
+        else if (nb == 0) {}
         else if (!opt.print_rows)
-            check(cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), nullptr,
+            check(cnf2_sweep(ctx, b0, b1, factors.data(), loglik.data(), nullptr,
                              (opt.merge_modes ? CNF2_MERGE_MODES : 0) | CNF2_NO_DOSAGE),
                   "cnf2_sweep");
         else
-            check(cnf2_sweep(ctx, 0, N, factors.data(), loglik.data(), dosage.data(),
+            check(cnf2_sweep(ctx, b0, b1, factors.data(), loglik.data(), dosage.data(),
                              (opt.merge_modes ? CNF2_MERGE_MODES : 0) | rowflag),
                   "cnf2_sweep");
     }
     lap("sweep + accumulators");
+    if (opt.update && N > 0 && exchange_) {
+        // ranks share ancestors: their slabs are partial sums until the one all-reduce of the iteration
+        double *d_inf, *d_hb, *d_hc;
+        check(cnf2_sync(ctx), "cnf2_sync");
+        check(cnf2_accumulator_ptrs(ctx, &d_inf, &d_hb, &d_hc), "cnf2_accumulator_ptrs");
+        const int rc = exchange_(exchange_user_, d_inf, d_hb, d_hc, (size_t)R, (size_t)M);
+        if (rc != 0) throw EngineError(CNF2_ERR_STATE, "the exchange callback failed (" + std::to_string(rc) + ")");
+        lap("exchange of the accumulators");
+    }
+    pass_hits_.assign(C, 0);
     for (int c = 0; c < C; c++) {
         if (!opt.quiet)
-            for (int j = 0; j < N; j++) {
+            for (int j = 0; j < nb; j++) {
                 int32_t w[17];
-                check(cnf2_window_info(ctx, j, w), "cnf2_window_info");
+                check(cnf2_window_info(ctx, b0 + j, w), "cnf2_window_info");
                 double mx = -1e15;               // the two printf of cnF2freq.cpp:5399-5401
                 for (int s = 0; s < 8; s++) mx = std::max(mx, factors[((size_t)j * C + c) * 8 + s]);
-                printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
-                       P.inds[T.dous[j]].gen < 2 ? 2 : 8);
+                printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[b0 + j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
+                       P.inds[T.dous[b0 + j]].gen < 2 ? 2 : 8);
             }
-        for (int j = 0; j < N && opt.print_rows; j++) {            // cnF2freq.cpp:6183-6188
-            fprintf(out, "%s:%d\n", P.inds[T.dous[j]].name.c_str(), c + 1);
+        for (int j = 0; j < nb && opt.print_rows; j++) {            // cnF2freq.cpp:6183-6188
+            fprintf(out, "%s:%d\n", P.inds[T.dous[b0 + j]].name.c_str(), c + 1);
             const double ll = loglik[(size_t)j * C + c];
             const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
             if (!skipped)
@@ -480,6 +555,7 @@ void Engine::iteration(FILE* out)
         oldhits2_ = oldhits_;
         oldhits_  = hits;
         last_hits_ = hits;
+        pass_hits_[c] = hits;
         fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
         lap("update pass");
     }

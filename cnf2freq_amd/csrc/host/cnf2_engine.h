@@ -12,8 +12,10 @@
 #ifndef CNF2_ENGINE_H
 #define CNF2_ENGINE_H
 
+#include <stddef.h>
 #include <stdio.h>
 
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -31,6 +33,19 @@ struct EngineOptions {
     bool print_rows = true;     // false: rows of this iteration are not formatted at all (large runs, non-final iterations)
 };
 
+// A call into libcnf2hip.so failed (out of memory, launch error, bad state).  The command line turns it into the
+// reference's abort() (cnF2freq.cpp:21-25); libcnf2host.so into an error code and cnf2h_last_error().
+struct EngineError : std::runtime_error {
+    int code;
+    EngineError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// The one exchange of a multi-process haplotyping iteration (the reference's reduce calls,
+// cnF2freq.cpp:6245-6254): sums the per-record accumulator slabs of all ranks in place.  The pointers are DEVICE
+// addresses (infprobs [n_rec][n_markers][2][2], haplobase / haplocount [n_rec][n_markers]); return 0 on success.
+typedef int (*ExchangeFn)(void* user, double* d_infprobs, double* d_haplobase, double* d_haplocount, size_t n_rec,
+                          size_t n_markers);
+
 class Engine {
 public:
     Engine(Pedigree& ped, cnf2_ctx* ctx, const EngineOptions& opt);
@@ -46,6 +61,21 @@ public:
     // cnF2freq.cpp:8157-8192
     void dump(FILE* out, int limit);
 
+    // multi-process runs: this rank sweeps the analysed individuals [begin, end) of dous (ancestors' rows are replicated on
+    // every rank), `fn` sums the accumulators of all ranks after the sweep, every rank then runs the same update pass on the
+    // same numbers (cnF2freq.cpp:5297-5299, 6245-6254, 6344-6392).  Rows are printed for the rank's own block.
+    void   set_block(int begin, int end);
+    // what the sweep kernels spend on every analysed individual, up to a constant: markers x (1 forward + one backward pass
+    // per tie combination).  The shift modes of cnF2freq.cpp:5359, 5378 do not enter: a wavefront carries all 8 modes of
+    // its individual whether they are masked or not (SURVEY 8(e)'s sum of M x S_act is the cost model of the CPU path).
+    std::vector<double> work_costs();
+    // contiguous blocks of dous with near-equal cost: block `rank` of `world` (cnF2freq.cpp:5297-5299 deals individuals
+    // round-robin; contiguous blocks keep a rank's output rows together)
+    void   balanced_block(int rank, int world, int* begin, int* end);
+    void   set_exchange(ExchangeFn fn, void* user) { exchange_ = fn; exchange_user_ = user; }
+    void   set_deterministic(bool d) { deterministic_ = d; }
+    const std::vector<int>& pass_hits() const { return pass_hits_; }       // hitnnn of every chromosome's pass of the last iteration
+    void   accumulators(double* haplobase, double* haplocount);            // [inds][M] as the last pass left them
     void   set_update(bool u) { opt.update = u; }
     void   set_print_rows(bool p) { opt.print_rows = p; }
     void   sync_rows() { if (rows_stale_) pull_rows(); }   // host copies of the individuals' rows up to date
@@ -71,6 +101,11 @@ private:
     double scalefactor_ = 0.013, entropyfactor_ = 1.0;   // cnF2freq.cpp:3573-3574
     int    oldhits_ = 0, oldhits2_ = 0, last_hits_ = 0;
     bool   rows_stale_ = false;   // the device rows were updated since they were last copied to the host
+    int    block_begin_ = 0, block_end_ = -1;     // analysed individuals of this rank (-1: all)
+    ExchangeFn exchange_ = nullptr;
+    void*      exchange_user_ = nullptr;
+    bool       deterministic_ = false;
+    std::vector<int> pass_hits_;
 };
 
 }  // namespace cnf2host

@@ -18,6 +18,22 @@ struct cnf2h_run {
 
 static std::string g_err;
 
+// runs f(); an EngineError becomes its code and g_err
+template <class F>
+static int guarded(F&& f)
+{
+    try {
+        f();
+        return 0;
+    } catch (const EngineError& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return CNF2_ERR_STATE;
+    }
+}
+
 extern "C" {
 
 const char* cnf2h_last_error(void) { return g_err.c_str(); }
@@ -25,6 +41,14 @@ const char* cnf2h_last_error(void) { return g_err.c_str(); }
 cnf2h_run* cnf2h_create(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const uint8_t* has_prior,
                         const uint8_t* allele, const double* sure, const double* hw, const double* pos, int n_markers,
                         const int32_t* chromstarts, int n_chrom, const int32_t* dous, int n_dous, int quiet)
+{
+    return cnf2h_create_on(0, n_rec, par, empty, gen, has_prior, allele, sure, hw, pos, n_markers, chromstarts, n_chrom, dous,
+                           n_dous, quiet);
+}
+
+cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
+                           const uint8_t* has_prior, const uint8_t* allele, const double* sure, const double* hw, const double* pos,
+                           int n_markers, const int32_t* chromstarts, int n_chrom, const int32_t* dous, int n_dous, int quiet)
 {
     if (n_rec <= 0 || !par || !empty || !gen || !has_prior || !allele || !sure || !hw || !pos || n_markers <= 0 || !chromstarts ||
         n_chrom <= 0 || !dous || n_dous < 0) {
@@ -57,7 +81,7 @@ cnf2h_run* cnf2h_create(int n_rec, const int32_t* par, const uint8_t* empty, con
         P.inds.push_back(I);
     }
     P.dous.assign(dous, dous + n_dous);
-    if (cnf2_ctx_create(0, &run->ctx) != CNF2_OK) {
+    if (cnf2_ctx_create(device, &run->ctx) != CNF2_OK) {
         g_err = cnf2_last_error(nullptr);
         delete run;
         return nullptr;
@@ -65,7 +89,10 @@ cnf2h_run* cnf2h_create(int n_rec, const int32_t* par, const uint8_t* empty, con
     EngineOptions eo;
     eo.quiet = quiet != 0;
     run->E = new Engine(P, run->ctx, eo);
-    run->E->upload();
+    if (guarded([&] { run->E->upload(); }) != 0) {
+        cnf2h_destroy(run);
+        return nullptr;
+    }
     return run;
 }
 
@@ -80,8 +107,7 @@ void cnf2h_destroy(cnf2h_run* run)
 int cnf2h_postmarkerdata(cnf2h_run* run, int indcount)
 {
     if (!run) return -2;
-    run->E->postmarkerdata(indcount);
-    return 0;
+    return guarded([&] { run->E->postmarkerdata(indcount); });
 }
 
 int cnf2h_iteration(cnf2h_run* run, const char* rows_path, int update)
@@ -94,9 +120,9 @@ int cnf2h_iteration(cnf2h_run* run, const char* rows_path, int update)
     }
     run->E->set_update(update != 0);
     run->E->set_print_rows(rows_path != nullptr);
-    run->E->iteration(f);
+    const int rc = guarded([&] { run->E->iteration(f); });
     fclose(f);
-    return 0;
+    return rc;
 }
 
 int cnf2h_dump(cnf2h_run* run, const char* path, int limit)
@@ -104,22 +130,25 @@ int cnf2h_dump(cnf2h_run* run, const char* path, int limit)
     if (!run || !path) return -2;
     FILE* f = fopen(path, "a");
     if (!f) return -2;
-    run->E->dump(f, limit);
+    const int rc = guarded([&] { run->E->dump(f, limit); });
     fclose(f);
-    return 0;
+    return rc;
 }
 
 int cnf2h_deserialize(cnf2h_run* run, const char* path)
 {
     if (!run || !path) return -2;
-    return run->E->deserialize(path) ? 0 : -2;
+    bool ok = false;
+    const int rc = guarded([&] { ok = run->E->deserialize(path); });
+    return rc ? rc : (ok ? 0 : -2);
 }
 
 int cnf2h_get_state(cnf2h_run* run, uint8_t* allele, double* sure, double* hw, int32_t* descendants, int32_t* children,
                     double* variances, double* scalefactor, int32_t* last_hits)
 {
     if (!run) return -2;
-    run->E->sync_rows();
+    const int rc = guarded([&] { run->E->sync_rows(); });
+    if (rc) return rc;
     const Pedigree& P = run->P;
     const size_t    M = P.pos.size();
     for (size_t r = 0; r < P.inds.size(); r++) {
@@ -133,6 +162,46 @@ int cnf2h_get_state(cnf2h_run* run, uint8_t* allele, double* sure, double* hw, i
     if (variances) std::copy(run->E->variances().begin(), run->E->variances().end(), variances);
     if (scalefactor) *scalefactor = run->E->scalefactor();
     if (last_hits) *last_hits = run->E->last_hits();
+    return 0;
+}
+
+int cnf2h_set_block(cnf2h_run* run, int begin, int end)
+{
+    if (!run) return -2;
+    return guarded([&] { run->E->set_block(begin, end); });
+}
+
+int cnf2h_balanced_block(cnf2h_run* run, int rank, int world, int32_t* begin, int32_t* end)
+{
+    if (!run || !begin || !end) return -2;
+    int b = 0, e = 0;
+    const int rc = guarded([&] { run->E->balanced_block(rank, world, &b, &e); });
+    *begin = b;
+    *end = e;
+    return rc;
+}
+
+int cnf2h_set_exchange(cnf2h_run* run, cnf2h_exchange_fn fn, void* user)
+{
+    if (!run) return -2;
+    run->E->set_exchange(fn, user);
+    return 0;
+}
+
+int cnf2h_set_deterministic(cnf2h_run* run, int on)
+{
+    if (!run) return -2;
+    run->E->set_deterministic(on != 0);
+    return 0;
+}
+
+void* cnf2h_context(cnf2h_run* run) { return run ? run->ctx : nullptr; }
+
+int cnf2h_get_passes(cnf2h_run* run, int32_t* hits, double* haplobase, double* haplocount)
+{
+    if (!run) return -2;
+    if (hits) std::copy(run->E->pass_hits().begin(), run->E->pass_hits().end(), hits);
+    if (haplobase || haplocount) return guarded([&] { run->E->accumulators(haplobase, haplocount); });
     return 0;
 }
 

@@ -148,6 +148,8 @@ int main(int argc, char** argv)
     // main() trims dous only after postmarkerdata (cnF2freq.cpp:8083, 8124); the analysed list is fixed at upload here,
     // and postmarkerdata does not read it
     if ((int)P.dous.size() > opt.limit) P.dous.resize(opt.limit);
+    // any failure below the C ABI ends the run the way the reference ends on every failure (cnF2freq.cpp:21-25)
+    try {
     Engine E(P, ctx, eo);
     E.upload();
     if (opt.preprocess) E.postmarkerdata(opt.limit);                 // cnF2freq.cpp:8083-8085
@@ -173,6 +175,10 @@ int main(int argc, char** argv)
         fflush(out);
     }
     if (out != stdout) fclose(out);
+    } catch (const EngineError& e) {
+        fprintf(stderr, "%s\n", e.what());
+        abort();
+    }
     cnf2_ctx_destroy(ctx);
     return 0;
 }

@@ -107,6 +107,92 @@ def allreduce_accumulators(infprobs, haplobase, haplocount):
         w.wait()
 
 
+def balanced_blocks(costs, world):
+    """Boundaries [b_0 = 0, ..., b_world = n] of `world` contiguous blocks with near-equal cost (the rule of
+    Engine::balanced_block in csrc/host/cnf2_engine.cpp, for callers that hold the costs themselves)."""
+    costs = np.asarray(costs, np.float64)
+    n = len(costs)
+    total = float(costs.sum())
+    prefix = np.concatenate([[0.0], np.cumsum(costs)])[:-1]
+    bounds = [0]
+    for k in range(1, world):
+        hit = np.flatnonzero(prefix + 0.5 * costs >= total * k / world)
+        bounds.append(int(hit[0]) if len(hit) else n)
+    bounds.append(n)
+    return bounds
+
+
+class _DeviceSlab:
+    """A device address as an object torch.as_tensor() accepts (CUDA array interface; zero copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2)
+
+
+def device_slabs(d_inf, d_hb, d_hc, n_rec, n_markers, device=None):
+    """The three accumulator slabs at the device addresses the engine hands to its exchange callback, as flat float64
+    torch tensors that alias them."""
+    from . import capi
+    capi.require_single_hip_runtime()          # the addresses belong to the runtime libcnf2hip.so uses
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    return [torch.as_tensor(_DeviceSlab(p, n), device=dev)
+            for p, n in ((d_inf, n_rec * n_markers * 4), (d_hb, n_rec * n_markers), (d_hc, n_rec * n_markers))]
+
+
+def make_exchange(run):
+    """The exchange callback of a multi-process haplotyping run (cnf2host.h: cnf2h_set_exchange): one all-reduce(sum) of the
+    three accumulator slabs per iteration.  nccl (= RCCL): in place on the device addresses the engine hands over;
+    gloo (a transport that moves host memory, e.g. two test ranks sharing one GPU): through the host with
+    cnf2_download_accumulators / cnf2_upload_accumulators."""
+    from . import capi
+    backend = dist.get_backend() if dist.is_initialized() else None
+    L = capi.load()
+    ctx = run.context()
+    bufs = {}
+
+    def exchange(d_inf, d_hb, d_hc, n_rec, n_markers):
+        if backend is None or dist.get_world_size() == 1:
+            return 0
+        if backend == "nccl":
+            allreduce_accumulators(*device_slabs(d_inf, d_hb, d_hc, n_rec, n_markers))
+            torch.cuda.synchronize()
+            return 0
+        if "inf" not in bufs:
+            bufs["inf"] = torch.zeros(n_rec * n_markers * 4, dtype=torch.float64)
+            bufs["hb"] = torch.zeros(n_rec * n_markers, dtype=torch.float64)
+            bufs["hc"] = torch.zeros(n_rec * n_markers, dtype=torch.float64)
+        import ctypes as C
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        if L.cnf2_download_accumulators(ctx, ptr(bufs["inf"]), ptr(bufs["hb"]), ptr(bufs["hc"])) != 0:
+            return -1
+        allreduce_accumulators(bufs["inf"], bufs["hb"], bufs["hc"])
+        if L.cnf2_upload_accumulators(ctx, ptr(bufs["inf"]), ptr(bufs["hb"]), ptr(bufs["hc"])) != 0:
+            return -1
+        return 0
+
+    return exchange
+
+
+def start_iterations(ped, device=0, has_prior=None, postmarkerdata=True, deterministic=False, quiet=True):
+    """One rank's run of a multi-process haplotyping job (BASELINE config 5; the reference's dead MPI code: partition
+    cnF2freq.cpp:5297-5299, reduce 6245-6254, updates on the reduced slabs 6344-6392): the whole pedigree on every rank,
+    the rank's work-balanced block of analysed individuals, the all-reduce of the accumulators as the one exchange of
+    an iteration.  Returns the cnf2freq_amd.host.Run; call run.iteration() in step on every rank."""
+    from . import host
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    run = host.Run(ped, has_prior=has_prior, quiet=quiet, device=device)
+    if postmarkerdata:
+        run.postmarkerdata()            # replicated: every rank infers the same genotypes from the same rows
+    b, e = run.balanced_block(rank, world)
+    run.set_block(b, e)
+    run.block = (b, e)
+    run.set_exchange(make_exchange(run))
+    if deterministic:
+        run.set_deterministic(True)
+    return run
+
+
 def gather_ragged_to_root(a, dst=0):
     """Gather numpy arrays whose first dimension differs per rank (block partition);
     returns the concatenation on `dst`, None elsewhere."""

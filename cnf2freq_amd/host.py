@@ -9,8 +9,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnf2host.so")
 
-SYMBOLS = ["cnf2h_create", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration", "cnf2h_dump",
-           "cnf2h_deserialize", "cnf2h_get_state"]
+SYMBOLS = ["cnf2h_create", "cnf2h_create_on", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration",
+           "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_exchange",
+           "cnf2h_set_deterministic", "cnf2h_context", "cnf2h_get_passes"]
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
 
 _lib = None
 
@@ -24,6 +27,15 @@ def load():
         vp, i32 = C.c_void_p, C.c_int
         L.cnf2h_create.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32]
         L.cnf2h_create.restype = vp
+        L.cnf2h_create_on.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32]
+        L.cnf2h_create_on.restype = vp
+        L.cnf2h_set_block.argtypes = [vp, i32, i32]
+        L.cnf2h_balanced_block.argtypes = [vp, i32, i32, vp, vp]
+        L.cnf2h_set_exchange.argtypes = [vp, EXCHANGE_FN, vp]
+        L.cnf2h_set_deterministic.argtypes = [vp, i32]
+        L.cnf2h_context.argtypes = [vp]
+        L.cnf2h_context.restype = vp
+        L.cnf2h_get_passes.argtypes = [vp, vp, vp, vp]
         L.cnf2h_destroy.argtypes = [vp]
         L.cnf2h_destroy.restype = None
         L.cnf2h_last_error.restype = C.c_char_p
@@ -44,7 +56,7 @@ class Run:
     """One run over a cnf2freq_amd.synth.Pedigree (records that are not `empty` count as genotyped, i.e. they have
     priors, unless has_prior is given)."""
 
-    def __init__(self, ped, has_prior=None, quiet=True):
+    def __init__(self, ped, has_prior=None, quiet=True, device=0):
         self.L = load()
         a, s, h = ped.dense()
         self.n_rec, self.M = ped.n_rec, ped.n_markers
@@ -55,8 +67,9 @@ class Run:
                 np.ascontiguousarray(ped.pos, np.float64)]
         cs = np.ascontiguousarray(ped.chromstarts, np.int32)
         dous = np.ascontiguousarray(ped.dous, np.int32)
-        self.h = self.L.cnf2h_create(ped.n_rec, *[_p(x) for x in args[:8]], self.M, _p(cs), len(cs) - 1, _p(dous),
-                                     len(dous), 1 if quiet else 0)
+        self.n_chrom = len(cs) - 1
+        self.h = self.L.cnf2h_create_on(device, ped.n_rec, *[_p(x) for x in args[:8]], self.M, _p(cs), len(cs) - 1, _p(dous),
+                                        len(dous), 1 if quiet else 0)
         if not self.h:
             raise RuntimeError("cnf2h_create: %s" % self.L.cnf2h_last_error().decode())
 
@@ -71,13 +84,51 @@ class Run:
         except Exception:
             pass
 
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, self.L.cnf2h_last_error().decode()))
+
     def postmarkerdata(self, indcount=None):
-        rc = self.L.cnf2h_postmarkerdata(self.h, self.n_rec + 1 if indcount is None else indcount)
-        assert rc == 0
+        self._chk(self.L.cnf2h_postmarkerdata(self.h, self.n_rec + 1 if indcount is None else indcount), "cnf2h_postmarkerdata")
 
     def iteration(self, rows_path=None, update=True):
-        rc = self.L.cnf2h_iteration(self.h, None if rows_path is None else str(rows_path).encode(), 1 if update else 0)
-        assert rc == 0
+        self._chk(self.L.cnf2h_iteration(self.h, None if rows_path is None else str(rows_path).encode(), 1 if update else 0),
+                  "cnf2h_iteration")
+
+    def set_block(self, begin, end):
+        self._chk(self.L.cnf2h_set_block(self.h, begin, end), "cnf2h_set_block")
+
+    def balanced_block(self, rank, world):
+        b, e = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.cnf2h_balanced_block(self.h, rank, world, C.byref(b), C.byref(e)), "cnf2h_balanced_block")
+        return b.value, e.value
+
+    def set_exchange(self, fn):
+        """fn(d_infprobs, d_haplobase, d_haplocount, n_rec, n_markers) -> 0: device addresses as ints (see cnf2host.h)."""
+        def tramp(_user, a, b, c, n_rec, n_markers):
+            try:
+                return int(fn(a, b, c, n_rec, n_markers) or 0)
+            except Exception as e:            # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._exchange = EXCHANGE_FN(tramp)   # keep the trampoline alive
+        self._chk(self.L.cnf2h_set_exchange(self.h, self._exchange, None), "cnf2h_set_exchange")
+
+    def set_deterministic(self, on=True):
+        self._chk(self.L.cnf2h_set_deterministic(self.h, 1 if on else 0), "cnf2h_set_deterministic")
+
+    def context(self):
+        return self.L.cnf2h_context(self.h)
+
+    def passes(self, accumulators=True):
+        """hits[C] of the last iteration's update passes and (optionally) haplobase / haplocount [R][M] as left behind."""
+        hits = np.zeros(self.n_chrom, np.int32)
+        hb = np.zeros((self.n_rec, self.M)) if accumulators else None
+        hc = np.zeros((self.n_rec, self.M)) if accumulators else None
+        self._chk(self.L.cnf2h_get_passes(self.h, _p(hits), None if hb is None else _p(hb), None if hc is None else _p(hc)),
+                  "cnf2h_get_passes")
+        return dict(hits=hits, haplobase=hb, haplocount=hc)
 
     def dump(self, path, limit=1000000):
         assert self.L.cnf2h_dump(self.h, str(path).encode(), limit) == 0

@@ -59,7 +59,11 @@ enum {
                                     share a wavefront.  Same outputs for all 8 modes (rows to rounding).
                                     Ignored together with CNF2_FULL_SPILL. */
     CNF2_ACC_DEVICE   = 1u << 6, /* cnf2_sweep_accumulate: the four accumulator pointers are device pointers owned by the
-                                    caller (a multi-GPU driver all-reduces them in place) */
+                                    caller (a multi-GPU driver all-reduces them in place).  They must be ordinary
+                                    (coarse-grained) device memory -- hipMalloc or a torch CUDA tensor: the kernels add with
+                                    hardware f64 atomics (-munsafe-fp-atomics), which fine-grained or host-mapped memory
+                                    silently drops.  The order of the additions is not fixed: accumulators are
+                                    reproducible to rounding, not to the bit, unless CNF2_DETERMINISTIC is set */
     CNF2_ACC_KEEP     = 1u << 7, /* cnf2_sweep_accumulate: add to the per-record accumulators instead of zeroing them */
     CNF2_ACC_TABLE    = 1u << 10, /* cnf2_sweep_accumulate: evaluate every window in the table form (one lane per emission-table
                                     entry) instead of the path form (one lane per allele path of a line); same sums, the
@@ -69,6 +73,14 @@ enum {
                                     windows with tie groups always take) instead of the tile form; A/B and cross-check */
     CNF2_TIES_GENERAL = 1u << 12, /* cnf2_sweep, cnf2_sweep_accumulate, cnf2_sweep_turn_scan: windows with tie groups through the general kernel (one lane per table entry, producer
                                     per marker) instead of the tile-producer kernel's pass per tie combination; cross-check */
+    CNF2_UPDATE_PLAIN = 1u << 13, /* cnf2_update_pass: one thread per (record, marker) instead of the persistent flow kernels
+                                    (a wavefront steps 64 independent flows and refills lanes as flows end); same arithmetic,
+                                    same results -- cross-check and A/B */
+    CNF2_DETERMINISTIC = 1u << 14, /* cnf2_sweep_accumulate: every analysed individual writes what its window members receive at a
+                                    locus into a row of its own (336 B per individual x marker, allocated for the whole
+                                    range) and one more kernel adds the rows of every record in ascending order of the
+                                    individual, instead of f64 atomics in order of arrival: accumulators -- and with them
+                                    whole iterations -- reproduce to the bit from run to run */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same
@@ -254,6 +266,15 @@ int cnf2_update_pass(cnf2_ctx *ctx, int chrom, const int32_t *children, const in
                      double *haplobase, double *haplocount, double scalefactor, double entropyfactor, int *hits_out,
                      uint32_t flags);
 int cnf2_download_rows(cnf2_ctx *ctx, int row0, int n, uint8_t *allele, double *sure, double *hw);
+/* The accumulators the context holds (what cnf2_sweep_accumulate left and cnf2_update_pass rewrote when they were called
+ * with NULL accumulator pointers): host copies infprobs[n_rec][M][2][2], haplobase / haplocount[n_rec][M]; any pointer may
+ * be NULL.  cnf2_upload_accumulators is the reverse (a multi-process driver whose transport moves host memory sums the
+ * slabs of its ranks between the two calls). */
+int cnf2_download_accumulators(cnf2_ctx *ctx, double *infprobs, double *haplobase, double *haplocount);
+/* Device addresses of the same three slabs (valid until the pedigree or the map is replaced): what a multi-GPU driver
+ * hands to its all-reduce (RCCL) between cnf2_sweep_accumulate and cnf2_update_pass.  Call cnf2_sync first. */
+int cnf2_accumulator_ptrs(cnf2_ctx *ctx, double **infprobs, double **haplobase, double **haplocount);
+int cnf2_upload_accumulators(cnf2_ctx *ctx, const double *infprobs, const double *haplobase, const double *haplocount);
 
 /* Emission lookup of one analysed individual and marker, all 8 shift modes (parity hook
  * for trackpossible, cnF2freq.cpp:1075-1359): e_out[8][64] path-free emission e(g). */

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libcnf2hip.so is loaded: one HIP runtime per process (cnf2freq_amd.capi.hip_runtimes)
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
@@ -85,9 +86,18 @@ class TrajectoryChecker:
                 assert np.array_equal(st["hits"], z["it%d_hits" % k]), (k, st["hits"], z["it%d_hits" % k])
             np.testing.assert_allclose(st["scalefactor"], float(z["it%d_scalefactor" % k]), rtol=1e-15 if exact_hits else 0.25)
         assert np.array_equal(np.asarray(st["allele"])[ok], z["it%d_allele" % k][ok]), k
+        # haplobase / haplocount as left behind: a slot that is homozygous with EQUAL certainties takes no part in the HAPLOS
+        # update (cnF2freq.cpp:1224-1239 compares the two certainties for equality), and certainties that are equal by
+        # symmetry are equal to the bit or not depending on the order of the additions behind them: left out
+        za, zs = z["it%d_allele" % k], z["it%d_sure" % k]
+        knife = (za[..., 0] == za[..., 1]) & np.isclose(zs[..., 0], zs[..., 1], rtol=1e-9, atol=0)
         for key in ("sure", "hw", "haplobase", "haplocount"):
             if key in st:
-                np.testing.assert_allclose(np.asarray(st[key])[ok], z["it%d_%s" % (k, key)][ok], rtol=rtol, atol=atol,
+                keep = ok[:, None] & ~knife if key in ("haplobase", "haplocount") else ok
+                # haplobase is rewritten as (hb - c w + c (1 - s) w) / (1 - s) with 1 - s down to 5e-6 (cnF2freq.cpp:4667-4675):
+                # rounding of the weight w is amplified by up to 1 / (1 - s)
+                np.testing.assert_allclose(np.asarray(st[key])[keep], z["it%d_%s" % (k, key)][keep],
+                                           rtol=max(rtol, 1e-8) if key == "haplobase" else rtol, atol=atol,
                                            err_msg="%s after iteration %d" % (key, k))
         return int(ok.sum())
 

@@ -153,3 +153,21 @@ def test_accumulator_allreduce_two_ranks():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True and q.get(timeout=5) is True
+
+
+def test_balanced_blocks_cover_and_balance():
+    """Contiguous blocks balanced by cost: windows with tie groups cost up to 17 passes where an
+    untied one costs 2."""
+    from cnf2freq_amd import dist as cdist
+    rs = np.random.RandomState(3)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 40, 1000):
+            costs = np.where(rs.rand(n) < 0.05, 17.0, 2.0) * 1000
+            b = cdist.balanced_blocks(costs, world)
+            assert b[0] == 0 and b[-1] == n and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+            if n >= 100 * world:
+                share = [costs[x:y].sum() for x, y in zip(b, b[1:])]
+                assert max(share) - min(share) <= 2 * costs.max()
+    # head-count would give [0, 4, 8]; the tied window at position 3 moves the boundary
+    assert cdist.balanced_blocks([2, 2, 2, 17, 2, 2, 2, 2], 2) == [0, 4, 8]
+    assert cdist.balanced_blocks([17, 2, 2, 2, 2, 2, 2, 2], 2) == [0, 1, 8]

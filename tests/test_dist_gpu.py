@@ -58,3 +58,62 @@ def test_two_rank_hip_sweep_equals_single_rank(tmp_path, tile):
     assert tiles[0, 0] == 0 and tiles[-1, 1] == ped.n_markers and np.all(tiles[1:, 0] == tiles[:-1, 1])
     # rank 0 never held more than depth (2) tiles x world for receiving
     assert int(z["root_bytes"]) <= 2 * int(z["world"]) * int(z["tile_bytes"])
+
+
+def _row_blocks(path):
+    """{header: [row lines]} of a rows file (cnF2freq.cpp:6183-6188: "name:chrom", the rows, a blank line)."""
+    blocks, cur = {}, None
+    for line in open(path).read().split("\n"):
+        if cur is None:
+            if ":" in line and not line.startswith(("FIRST PASS", "SKEWNESS PASS")):
+                cur = line
+                blocks[cur] = []
+        elif line == "":
+            cur = None
+        else:
+            blocks[cur].append(line)
+    return blocks
+
+
+def test_two_rank_iterations_equal_single_rank(tmp_path):
+    """BASELINE config 5's multi-GPU leg, correct before it is fast: 2 ranks x 3 haplotyping iterations (sweep of the
+    rank's block, ONE all-reduce of the accumulator slabs, the same update passes on every rank) on an outbred pedigree
+    whose families straddle the split = the single-rank run: genotypes and hit counters identical, certainties /
+    haplotype weights / haplobase / haplocount to 1e-9, both ranks bit-identical to each other, and the rows of the first
+    sweep (same parameters on both sides) equal to the character."""
+    import __graft_entry__ as g
+    g.build()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "dist_iter_worker.py")
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), worker, two, "gloo", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, worker, one, "gloo", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z0, z1, z = np.load(two + "_rank0.npz"), np.load(two + "_rank1.npz"), np.load(one + "_rank0.npz")
+    b0, b1 = z0["block"], z1["block"]
+    assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == 15 and 0 < b0[1] < 15 and b0[1] % 3 != 0, "the split should fall inside a family"
+    for k in ("allele", "sure", "hw", "hits", "scalefactor", "haplobase", "haplocount"):
+        assert np.array_equal(z0[k], z1[k], equal_nan=True), "ranks differ in " + k
+    assert np.array_equal(z0["allele"], z["allele"])
+    assert np.array_equal(z0["hits"], z["hits"]) and z["hits"].sum() > 0
+    assert z0["scalefactor"] == z["scalefactor"]
+    for k in ("sure", "hw"):
+        np.testing.assert_allclose(z0[k], z[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    # haplobase / haplocount as left behind: a slot that is homozygous with EQUAL certainties takes no part in the HAPLOS
+    # update (cnF2freq.cpp:1224-1239 compares the two certainties for equality).  Where the two sides of an individual
+    # collect the same evidence their certainties are equal up to the order of the additions, and one ulp decides
+    # whether the slot counts: such elements are left out (their haplotype weights agree all the same, see above).
+    knife = (z["allele"][..., 0] == z["allele"][..., 1]) & np.isclose(z["sure"][..., 0], z["sure"][..., 1], rtol=1e-9, atol=0)
+    assert knife.sum() < 0.5 * knife.size
+    for k in ("haplobase", "haplocount"):
+        np.testing.assert_allclose(z0[k][~knife], z[k][~knife], rtol=1e-9, atol=1e-12, err_msg=k)
+    want = _row_blocks(one + "_rows_it1_rank0.txt")
+    got = dict(_row_blocks(two + "_rows_it1_rank0.txt"))
+    got1 = _row_blocks(two + "_rows_it1_rank1.txt")
+    assert not set(got) & set(got1)
+    got.update(got1)
+    assert got == want and len(want) == 15 * 2
