@@ -30,7 +30,7 @@ SYMBOLS = [
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
-    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
+    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
@@ -110,6 +110,7 @@ def load():
         L.cnf2_download_accumulators.argtypes = [vp, vp, vp, vp]
         L.cnf2_upload_accumulators.argtypes = [vp, vp, vp, vp]
         L.cnf2_accumulator_ptrs.argtypes = [vp, vp, vp, vp]
+        L.cnf2_update_stats.argtypes = [vp, vp]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]
@@ -384,6 +385,13 @@ class Context:
         self._chk(self.L.cnf2_update_pass(self.h, chrom, _p(ch), _p(de), a[0], a[1], a[2], scalefactor, entropyfactor,
                                           _p(hits), flags), "cnf2_update_pass")
         return int(hits[0])
+
+    def update_stats(self):
+        """Diagnostics of the last update pass: dict of (flows, steps, slots, refills) for certainty / haploweight."""
+        out = np.zeros(16, np.uint64)
+        self._chk(self.L.cnf2_update_stats(self.h, _p(out)), "cnf2_update_stats")
+        return dict(certainty=tuple(int(x) for x in np.r_[out[0:4], out[8:12]]),
+                    haploweight=tuple(int(x) for x in np.r_[out[4:8], out[12:16]]))
 
     def download_accumulators(self):
         """The accumulators the context holds: dict(infprobs [R][M][2][2], haplobase [R][M], haplocount [R][M])."""

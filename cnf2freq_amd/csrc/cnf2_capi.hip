@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <chrono>
 #include <stdio.h>
 #include <string.h>
 
@@ -1068,7 +1069,16 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the weights of one job (%zu MB)", per_job >> 17);
         if (batch > jobs.size()) batch = jobs.size();
         if (batch > 1000000) batch = 1000000;
-        if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
+        {
+            // CNF2_TIMING: the first call of a run allocates the batch buffer (up to half the free memory) -- seconds
+            const bool timing = getenv("CNF2_TIMING") != nullptr && ctx->wbuf_cap < batch * per_job;
+            const auto t0 = std::chrono::steady_clock::now();
+            if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
+            if (timing)
+                fprintf(stderr, "  [sweep_accumulate] batch buffer of %.1f GB allocated in %.3f s (%zu jobs per batch of %zu)\n",
+                        batch * per_job * 8 / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), batch,
+                        jobs.size());
+        }
 
         KernelParams p;
         base_params(ctx, &p);
@@ -1426,10 +1436,11 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     u.entropyfactor = entropyfactor;
     u.hits = ctx->d_hits;
     if (!(flags & CNF2_UPDATE_PLAIN)) {
-        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 2 * sizeof(unsigned long long)));
+        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 26 * sizeof(unsigned long long)));
         if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)(u.last - u.first + 1) * 4))) return rc;
         u.flow_next = ctx->d_flow_next;
         u.flow_out = ctx->d_flow_out;
+        u.stats = ctx->d_flow_next + 2;
     }
     launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
@@ -1486,6 +1497,19 @@ int cnf2_upload_accumulators(cnf2_ctx* ctx, const double* infprobs, const double
     if (infprobs) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_inf, infprobs, R * M * 4 * sizeof(double), hipMemcpyHostToDevice));
     if (haplobase) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_hb, haplobase, R * M * sizeof(double), hipMemcpyHostToDevice));
     if (haplocount) HIP_TRY(ctx, hipMemcpy(ctx->d_acc_hc, haplocount, R * M * sizeof(double), hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
+int cnf2_update_stats(cnf2_ctx* ctx, uint64_t* out16)
+{
+    if (!ctx || !out16) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (!ctx->d_flow_next) return fail(ctx, CNF2_ERR_STATE, "no update pass has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t raw[24];
+    HIP_TRY(ctx, hipMemcpy(raw, ctx->d_flow_next + 2, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) out16[i] = raw[i];
+
     return CNF2_OK;
 }
 

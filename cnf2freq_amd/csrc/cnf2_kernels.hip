@@ -2277,13 +2277,37 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
 }
 
 // ---- the same two updates as persistent flow kernels ----------------------------------------------------------
-// A flow (cnf2_update.h) takes between 1 and 51 bisection steps of 16 gradient evaluations each, and the few per cent
-// that run into their cap always take all 51: with one thread per element nearly every wavefront waits for a lane like
-// that.  Here a wavefront runs ONE step of 64 independent flows at a time and hands a lane the next flow from a global
-// counter when its own has ended (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else is
-// running, because the set-up of a flow -- loads, the prior's logarithms, the gradient at the start -- is executed by the
-// whole wave).  Every wave ends when the counter has passed the last item and its lanes have drained.
+// A flow (cnf2_update.h) takes between 1 and 51 bisection steps, a step one gradient evaluation (the midpoint's sign
+// settles it, or the bound of flow_time_under does) or sixteen (a 15-point quadrature), and flows of either kind sit
+// next to each other: with one thread per element nearly every wavefront waits for its longest lane.  Here a wavefront
+// holds 64 flows as machines that ask for ONE gradient evaluation per round (FlowRun): every lane executes the
+// expensive part together, whatever its flow is going to do with the value, and a lane whose flow has ended takes the
+// next one from a global counter (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else
+// is running, because the set-up of a flow -- loads, the prior's logarithms, the gradient at the start -- is executed
+// by the whole wave).  Flows that are pinned to their clamp need no evaluation at all and end during the refill.
+// Every wave ends when the counter has passed the last item and its lanes have drained.
 #define FLOW_REFILL 16
+
+// diagnostics: stats[0..3] += flows, bisection steps of the flows that are not pinned, step rounds x 64 lanes offered to
+// them, pinned flows (FlowState::pinned: no gradient evaluation beyond the first)
+__device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned flows, unsigned steps, unsigned rounds, unsigned pinned)
+{
+    if (!stats) return;
+    unsigned long long a = flows, b = steps, c = pinned, d = rounds;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+        d += __shfl_xor(d, o);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + 0, a);
+        atomicAdd(stats + 1, b);
+        atomicAdd(stats + 2, d);
+        atomicAdd(stats + 3, c);
+    }
+}
 
 // next items for the free lanes of the wave; returns false when the counter has passed n_items (wave-uniform)
 __device__ __forceinline__ bool flow_take(unsigned long long* next, unsigned long long n_items, bool want,
@@ -2312,9 +2336,12 @@ __global__ __launch_bounds__(64) void certainty_flow_kernel(UpdateParams u, unsi
     bool               have = false, more = true;
     unsigned long long item = 0;
     CertaintyFlow      c;
-    FlowState          f;
+    FlowRun            run;
+    SlopeTerms         st;
     int                hits = 0;
+    unsigned           n_flows = 0, n_evals = 0, n_rounds = 0, n_pinned = 0, n_quads = 0, n_why1 = 0, n_why2 = 0, n_why3 = 0;    // diagnostics
     auto grad = [&](double x) { return certainty_rgradient(c, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); };
     for (;;) {
         const int busy = __popcll(__ballot(have));
         if (more && (busy <= 64 - FLOW_REFILL)) {
@@ -2337,8 +2364,17 @@ __global__ __launch_bounds__(64) void certainty_flow_kernel(UpdateParams u, unsi
                 s.prior_allele = side ? (pap >> 4) : (pap & 15);
                 s.prior_sure = side ? psu.y : psu.x;
                 if (certainty_flow_setup(pair, v, s, u.children[r], sc, &c)) {
-                    flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
-                    have = true;
+                    flow_begin(&run.f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+                    run.phase = 0;
+                    st = certainty_slope(c);
+                    n_flows++;
+                    if (run.f.pinned) {         // no gradient evaluations left: finished on the spot, the lane asks again
+                        while (flow_advance(&run.f, grad, sc.scalefactor)) {}
+                        flow_out[item] = flow_end(run.f, sc.scalefactor, &hits, false);
+                        n_pinned++;
+                    } else {
+                        have = true;
+                    }
                 } else {
                     flow_out[item] = 0.0;
                 }
@@ -2346,12 +2382,26 @@ __global__ __launch_bounds__(64) void certainty_flow_kernel(UpdateParams u, unsi
             continue;                       // lanes whose item held no flow ask again
         }
         if (busy == 0) break;               // nothing running and nothing left
-        if (have && !flow_advance(&f, grad, sc.scalefactor)) {
-            flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
-            have = false;
+        // one round = one gradient evaluation for every flow of the wavefront, wherever it is in its bisection
+        n_rounds++;
+        if (have) {
+            double v;
+            if (flow_want(&run, sc.scalefactor, &v)) {
+                n_evals++;
+                flow_feed(&run, grad(v), sc.scalefactor, bound);
+            } else {
+                flow_out[item] = flow_end(run.f, sc.scalefactor, &hits, false);
+                have = false;
+                n_quads += run.f.quads;
+                n_why1 += run.f.why == 1;
+                n_why2 += run.f.it;
+                n_why3 += run.f.spared;
+            }
         }
     }
     if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats, n_flows, n_evals, n_rounds, n_pinned);
+    flow_stats(u.stats ? u.stats + 8 : nullptr, n_quads, n_why1, n_why2, n_why3);
 }
 
 // one thread per (record, marker of the chromosome): cnF2freq.cpp:4292-4322 from the flows' results
@@ -2403,9 +2453,12 @@ __global__ __launch_bounds__(64) void haploweight_flow_kernel(UpdateParams u, un
     unsigned long long item = 0;
     size_t             row_i = 0;
     HaploFlow          h;
-    FlowState          f;
+    FlowRun            run;
+    SlopeTerms         st;
     int                hits = 0;
+    unsigned           n_flows = 0, n_evals = 0, n_rounds = 0, n_pinned = 0, n_quads = 0, n_why1 = 0, n_why2 = 0, n_why3 = 0;
     auto grad = [&](double x) { return haplo_rgradient(h, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); };
     for (;;) {
         const int busy = __popcll(__ballot(have));
         if (more && (busy <= 64 - FLOW_REFILL)) {
@@ -2426,19 +2479,41 @@ __global__ __launch_bounds__(64) void haploweight_flow_kernel(UpdateParams u, un
                                      &h);
                     u.acc_hb[k] = hb;
                     u.acc_hc[k] = hcv;
-                    flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
-                    have = true;
+                    flow_begin(&run.f, grad, hw, h.epsilon, sc.scalefactor, false);
+                    run.phase = 0;
+                    st = haplo_slope(h);
+                    n_flows++;
+                    if (run.f.pinned) {
+                        while (flow_advance(&run.f, grad, sc.scalefactor)) {}
+                        u.hw[row_i] = flow_end(run.f, sc.scalefactor, &hits, false);
+                        n_pinned++;
+                    } else {
+                        have = true;
+                    }
                 }
             }
             continue;
         }
         if (busy == 0) break;
-        if (have && !flow_advance(&f, grad, sc.scalefactor)) {
-            u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
-            have = false;
+        n_rounds++;
+        if (have) {
+            double v;
+            if (flow_want(&run, sc.scalefactor, &v)) {
+                n_evals++;
+                flow_feed(&run, grad(v), sc.scalefactor, bound);
+            } else {
+                u.hw[row_i] = flow_end(run.f, sc.scalefactor, &hits, false);
+                have = false;
+                n_quads += run.f.quads;
+                n_why1 += run.f.why == 1;
+                n_why2 += run.f.why == 2;
+                n_why3 += run.f.why == 3;
+            }
         }
     }
     if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, n_evals, n_rounds, n_pinned);
+    flow_stats(u.stats ? u.stats + 12 : nullptr, n_quads, n_why1, n_why2, n_why3);
 }
 
 void launch_update_pass(const UpdateParams& u, hipStream_t stream)
@@ -2454,7 +2529,7 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         return;
     }
     const size_t resident = (size_t)256 * 16;                 // wavefronts the chip holds at 4 per SIMD
-    (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+    (void)hipMemsetAsync(u.flow_next, 0, 26 * sizeof(unsigned long long), stream);    // 2 counters + 24 statistics
     const size_t w1 = (n1 * 4 + 63) / 64, w3 = (n3 + 63) / 64;
     hipLaunchKernelGGL(certainty_flow_kernel, dim3((unsigned)(w1 < resident ? w1 : resident)), dim3(64), 0, stream, u,
                        u.flow_next, u.flow_out);

@@ -96,6 +96,15 @@ CNF2_UHD double gauss15(F&& f, double a, double b)
     return half * acc;
 }
 
+// the same rule on a constant integrand c, in the same order of operations (see FlowState::pinned)
+CNF2_UHD double gauss15_const(double c, double a, double b)
+{
+    const double half = (b - a) * 0.5;
+    double acc = c * gl15_weight(0);
+    for (int i = 1; i < 8; i++) acc += (c + c) * gl15_weight(i);
+    return half * acc;
+}
+
 // ------------------------------------------------------------------ cap on one iteration's move
 // caplogitchange (cnF2freq.cpp:4006-4038) with nnn = 3: a value may rise by at most 2p(1-p)/(1+2p) and fall by at
 // most 2p(1-p)/(3-2p); a capped move that stays on the far side of 1/2 counts as a "hit" (the step-size control of
@@ -124,11 +133,22 @@ CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits
 // callers form the reciprocal of their gradient as ONE quotient).  The bisection is kept as data (FlowState) with
 // begin / advance / end, so that the device kernels can run one step of 64 independent flows per wavefront and hand a
 // lane the next flow as soon as its own has ended (flows take between 1 and 51 steps); flow_step() is the plain loop.
+// pinned: a value that sits on the clamp (epsilon or 1 - epsilon: a genotype that is as certain as it may get, a
+// resolved phase) and is pushed further out.  Every position the bisection then asks about -- the midpoints and all 15
+// nodes of every quadrature lie between the start and the bracket's outer end -- is clamped back onto the start, so the
+// integrand is the constant g0 = 1 / gradient(start): the whole flow needs no gradient evaluation beyond the first, and
+// its (up to 51) steps are a dozen instructions each.  In the steady state of a run most flows are of this kind.
 struct FlowState {
     double orig, epsilon, lolim, hilim, lo, hi;
+    double g0;            // dt/dp at the (clamped) starting point
+    double mid, qa, qb;   // the step in flight: its midpoint, and the interval of its quadrature (flow_try -> flow_quadrature)
     int    it;            // steps taken so far
+    int    quads;         // steps that needed the quadrature (diagnostics)
+    int    spared;        // steps whose quadrature the bound made unnecessary (diagnostics)
+    int    why;           // how the bisection ended: 1 tolerance met, 2 interval under 1e-10, 3 steps used up / out of bounds (diagnostics)
     bool   falling;       // the gradient at the starting point is negative
     bool   live;          // more steps to take
+    bool   pinned;
 };
 template <class G>
 CNF2_UHD double flow_pace(G&& rgradient, double v, double epsilon)      // dt/dp at the clamped position
@@ -155,50 +175,204 @@ CNF2_UHD void flow_begin(FlowState* f, G&& rgradient, double orig, double epsilo
     if (f->falling) f->hi = f->orig;
     else f->lo = f->orig;
     f->it = 0;
+    f->quads = 0;
+    f->spared = 0;
+    f->why = 0;
     f->live = scalefactor != 0;
+    f->g0 = g0;
+    f->pinned = isfinite(g0) && (f->falling ? f->orig <= epsilon : f->orig >= top);
 }
-// one bisection step; returns whether another one follows
-template <class G>
-CNF2_UHD bool flow_advance(FlowState* f, G&& rgradient, double scalefactor)
+// no bound on the quadrature's value: every same-sign step runs it
+struct NoTimeBound {
+    CNF2_UHD bool operator()(double, double, double, double) const { return false; }
+};
+// One bisection step in two parts, so that a wavefront can run the cheap part for all its flows and gather the ones
+// that need a quadrature until there are enough of them to run it for (the kernels of cnf2_kernels.hip).
+//   flow_try        everything up to the quadrature: 0 = the flow has ended, 1 = the step is done and another follows,
+//                   2 = the step needs the quadrature over [f->qa, f->qb] (call flow_quadrature).
+//                   bound(xa, xb, |1 / G(mid)|, limit): is what the quadrature would report certainly under limit?
+//                   (flow_time_under).
+//   flow_quadrature the rest of such a step: 0 / 1 as above.
+CNF2_UHD int flow_decide(FlowState* f, double t, double scalefactor)
 {
-    if (!f->live) return false;
-    if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) return f->live = false;   // done / outside the true bounds
+    if (fabs(t - scalefactor) < scalefactor * 1e-3) {
+        f->why = 1;
+        f->live = false;
+        return 0;
+    }
+    if ((t < scalefactor) != f->falling) f->lo = f->mid;
+    else f->hi = f->mid;
+    return 1;
+}
+template <class G, class B = NoTimeBound>
+CNF2_UHD int flow_try(FlowState* f, G&& rgradient, double scalefactor, B&& bound = B())
+{
+    if (!f->live) return 0;
+    if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) {   // done / outside the true bounds
+        f->why = 3;
+        f->live = false;
+        return 0;
+    }
     f->it++;
     const double mid = (f->lo + f->hi) / 2;
-    const double gm = flow_pace(rgradient, mid, f->epsilon);
-    double       t;                                          // time the flow needs from orig to mid
-    if (((gm < 0) != f->falling) || !isfinite(gm)) {
-        t = (scalefactor + 0.1) * 1.1;                        // the gradient turns round before mid: too far
+    f->mid = mid;
+    const double gm = f->pinned ? f->g0 : flow_pace(rgradient, mid, f->epsilon);
+    if (((gm < 0) != f->falling) || !isfinite(gm))
+        return flow_decide(f, (scalefactor + 0.1) * 1.1, scalefactor);     // the gradient turns round before mid: too far
+    double a = f->orig, b = mid;
+    if (a > b) {
+        const double s = a;
+        a = b;
+        b = s;
+    }
+    if (b - a < 1e-10) {
+        f->why = 2;
+        f->live = false;
+        return 0;
+    }
+    // "not there yet" without the quadrature: 0 < t <= bound < the tolerance band (see flow_time_bound)
+    if (!f->pinned && a >= f->epsilon && b <= 1.0 - f->epsilon &&
+        bound(a, b, fabs(gm), scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9))) {
+        f->spared++;
+        return flow_decide(f, 0.0, scalefactor);
+    }
+    if (f->pinned) {
+        f->quads++;
+        double t = gauss15_const(f->g0, a, b);
+        if (b != mid) t = -t;
+        if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+        return flow_decide(f, t, scalefactor);
+    }
+    f->qa = a;
+    f->qb = b;
+    return 2;
+}
+template <class G>
+CNF2_UHD int flow_quadrature(FlowState* f, G&& rgradient, double scalefactor)
+{
+    f->quads++;
+    const double eps = f->epsilon;
+    double       t = gauss15([&](double v) { return flow_pace(rgradient, v, eps); }, f->qa, f->qb);
+    if (f->qb != f->mid) t = -t;
+    if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+    return flow_decide(f, t, scalefactor);
+}
+// one whole step; returns whether another one follows
+template <class G, class B = NoTimeBound>
+CNF2_UHD bool flow_advance(FlowState* f, G&& rgradient, double scalefactor, B&& bound = B())
+{
+    int r = flow_try(f, rgradient, scalefactor, bound);
+    if (r == 2) r = flow_quadrature(f, rgradient, scalefactor);
+    return r == 1;
+}
+// The same step sequence as a machine that asks for ONE gradient evaluation at a time: the form the device kernels run.
+// A wavefront holds 64 flows at different points of their bisections -- some at a midpoint, some in the middle of a
+// quadrature -- and every round each of them wants exactly one value of its gradient: all lanes execute the expensive
+// part (the gradient) together, whatever they are going to do with the value.
+//   flow_want(r, sf, &v)   the (clamped) position to evaluate next; false: the flow has ended
+//   flow_feed(r, value, sf, bound)   the reciprocal gradient there
+// Order of operations and results are those of flow_try / flow_quadrature (gauss15: centre, then the node pairs outwards).
+struct FlowRun {
+    FlowState f;
+    int       phase;      // 0: the next value is a step's midpoint; k = 1..15: it is evaluation k of the quadrature in flight
+    double    acc, fp;    // quadrature sum so far; value at the +node that waits for its partner
+    double    mc, half;   // centre and half width of the quadrature's interval
+};
+CNF2_UHD bool flow_want(FlowRun* r, double scalefactor, double* v)
+{
+    FlowState* f = &r->f;
+    double     x;
+    if (r->phase == 0) {
+        if (!f->live) return false;
+        if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) {   // done / outside the true bounds
+            f->why = 3;
+            f->live = false;
+            return false;
+        }
+        f->it++;
+        f->mid = (f->lo + f->hi) / 2;
+        x = f->mid;
+    } else if (r->phase == 1) {
+        x = r->mc;
     } else {
-        double a = f->orig, b = mid;
+        const int    i = r->phase >> 1;
+        const double z = gl15_node(i);
+        x = r->mc + r->half * ((r->phase & 1) ? -z : z);
+    }
+    const double top = 1.0 - f->epsilon;
+    *v = (x < f->epsilon) ? f->epsilon : ((top < x) ? top : x);
+    return true;
+}
+template <class B = NoTimeBound>
+CNF2_UHD void flow_feed(FlowRun* r, double value, double scalefactor, B&& bound = B())
+{
+    FlowState* f = &r->f;
+    if (r->phase == 0) {
+        const double gm = value;
+        if (((gm < 0) != f->falling) || !isfinite(gm)) {
+            flow_decide(f, (scalefactor + 0.1) * 1.1, scalefactor);     // the gradient turns round before mid: too far
+            return;
+        }
+        double a = f->orig, b = f->mid;
         if (a > b) {
             const double s = a;
             a = b;
             b = s;
         }
-        if (b - a < 1e-10) return f->live = false;
-        const double eps = f->epsilon;
-        t = gauss15([&](double v) { return flow_pace(rgradient, v, eps); }, a, b);
-        if (b != mid) t = -t;
-        if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+        if (b - a < 1e-10) {
+            f->why = 2;
+            f->live = false;
+            return;
+        }
+        if (a >= f->epsilon && b <= 1.0 - f->epsilon &&
+            bound(a, b, fabs(gm), scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9))) {
+            f->spared++;
+            flow_decide(f, 0.0, scalefactor);
+            return;
+        }
+        f->qa = a;
+        f->qb = b;
+        f->quads++;
+        r->mc = (a + b) * 0.5;
+        r->half = (b - a) * 0.5;
+        r->phase = 1;
+        return;
     }
-    if (fabs(t - scalefactor) < scalefactor * 1e-3) return f->live = false;
-    if ((t < scalefactor) != f->falling) f->lo = mid;
-    else f->hi = mid;
-    return true;
+    if (r->phase == 1) {
+        r->acc = value * gl15_weight(0);
+        r->phase = 2;
+        return;
+    }
+    if (!(r->phase & 1)) {
+        r->fp = value;
+        r->phase++;
+        return;
+    }
+    r->acc += (r->fp + value) * gl15_weight(r->phase >> 1);
+    if (r->phase < 15) {
+        r->phase++;
+        return;
+    }
+    double t = r->half * r->acc;
+    if (f->qb != f->mid) t = -t;
+    if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+    r->phase = 0;
+    flow_decide(f, t, scalefactor);
 }
+
 CNF2_UHD double flow_end(const FlowState& f, double scalefactor, int* hits, bool breakathalf)
 {
     double lo = f.lo, hi = f.hi;
     if (!scalefactor) lo = hi = f.orig;
     return cap_step((lo + hi) / 2, f.orig, f.epsilon, hits, breakathalf);
 }
-template <class G>
-CNF2_UHD double flow_step(G&& rgradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf)
+template <class G, class B = NoTimeBound>
+CNF2_UHD double flow_step(G&& rgradient, double orig, double epsilon, double scalefactor, int* hits, bool breakathalf,
+                          B&& bound = B())
 {
     FlowState f;
     flow_begin(&f, rgradient, orig, epsilon, scalefactor, breakathalf);
-    while (flow_advance(&f, rgradient, scalefactor)) {}
+    while (flow_advance(&f, rgradient, scalefactor, bound)) {}
     return flow_end(f, scalefactor, hits, breakathalf);
 }
 
@@ -266,6 +440,73 @@ CNF2_UHD double evidence_slope(double y, double g, double h, double x)
     return evidence_slope(evidence_terms(y, g, h), x, logit(x));
 }
 
+// ------------------------------------------------------------------ a bound that spares most quadratures
+// Both gradients have the form  G(x) = D(x) - e L(x) + d W(x) + const,  D the data term above, L = logit,
+// W(x) = (pr - x) / (x (1 - x)) the phase-consistency term (d = 0 for the certainties), e, d >= 0.  With u = x (1 - x):
+//     -G'(x) = e / u - a b / (u Q^2) + (a - b)^2 / Q^2 + 2 a b (a - b) L / Q^3 + d ((x - pr)^2 + pr (1 - pr)) / u^2 .
+// In the steady state of a run most values sit next to a root x* of G that attracts them (near 0 or 1 the entropy term
+// e / u is in the hundreds), the time to reach it is infinite, and the bisection of flow_advance() closes in on x* from
+// both sides until its 51 steps are used up; on the near side every step costs a 15-point quadrature whose only message
+// is "not there yet".  That message can be had from the interval [orig, mid] alone: if s1 > 0 is a lower bound of -G' on
+// it (interval arithmetic on the expression above: u is concave, Q linear, L monotone), G is strictly monotone there,
+// has no root inside, and |G(x)| >= |G(mid)| + s1 |mid - x| =: l(x).  The rule has positive weights and, for the
+// reciprocal of a linear function, never exceeds the integral (its error term has the sign of the 30th derivative), so
+//     t = |rule[1 / G]| <= rule[1 / l] <= integral of 1 / l = log(1 + s1 |mid - orig| / |G(mid)|) / s1 .
+// When that is under the tolerance band the decision of the step is known -- identical to the literal one, not an
+// approximation of it -- for well under a hundred instructions instead of 1 300.  No bound (s1 <= 0, the interval touching
+// the clamp, a NaN anywhere): the quadrature runs as before.
+struct SlopeTerms {
+    Evidence ev;
+    double   e;        // coefficient of -logit: entropyfactor (certainties), (1 - similarity) entropyfactor (weights)
+    double   d, pr;    // descendants and phase ratio of the weights' third term; d = 0: none
+};
+// Is the time the rule reports over [xa, xb] certainly under `limit`?  (one end of the interval is the flow's start, the
+// other the midpoint, where |1 / G| = pace; xa < xb, both inside the clamp.)  false = not known.
+// The test is log(1 + z) < limit s1 with z = s1 (xb - xa) pace; log(1 + z) <= z settles most cases without a logarithm,
+// and for limit s1 >= 44 any z below 1e19 does.
+CNF2_UHD bool flow_time_under(const SlopeTerms& s, double xa, double xb, double pace, double limit)
+{
+    const double ua = xa * (1.0 - xa), ub = xb * (1.0 - xb);
+    const double ulo = ua < ub ? ua : ub;
+    const double uhi = (xa <= 0.5 && 0.5 <= xb) ? 0.25 : (ua < ub ? ub : ua);
+    const double qa = s.ev.b * (1.0 - xa) + s.ev.a * xa, qb = s.ev.b * (1.0 - xb) + s.ev.a * xb;
+    const double qlo = qa < qb ? qa : qb, qhi = qa < qb ? qb : qa;
+    if (!(ulo > 0.0) || !(qlo > 0.0) || !(s.e >= 0.0) || !(s.d >= 0.0)) return false;
+    // |logit(x)| <= 1 / min(x, 1 - x) on the interval: crude, but the term it bounds is small where the bound matters
+    const double edge = xa < 1.0 - xb ? xa : 1.0 - xb;
+    const double amb = s.ev.amb < 0 ? -s.ev.amb : s.ev.amb;
+    const double r_uhi = upd_div(1.0, uhi), r_qlo = upd_div(1.0, qlo), r_qhi = upd_div(1.0, qhi);
+    // -G' >= e / uhi - (a b / ulo + 2 a b |a - b| / (edge qlo)) / qlo^2 + (a - b)^2 / qhi^2 + d num / uhi^2
+    double s1 = s.e * r_uhi - s.ev.ab * (upd_div(1.0, ulo) + 2.0 * amb * r_qlo * upd_div(1.0, edge)) * (r_qlo * r_qlo) +
+                (s.ev.amb * r_qhi) * (s.ev.amb * r_qhi);
+    if (s.d != 0.0) {
+        const double dist = s.pr < xa ? xa - s.pr : (s.pr > xb ? s.pr - xb : 0.0);
+        const double num = dist * dist + s.pr * (1.0 - s.pr);      // >= 0 for a ratio in [0, 1]
+        s1 += s.d * (num >= 0.0 ? num * (r_uhi * r_uhi) : num * upd_div(1.0, ulo * ulo));
+    }
+    s1 *= 1.0 - 1e-9;                                        // the bound itself is rounded
+    if (!(s1 > 0.0) || !(pace > 0.0)) return false;
+    const double z = s1 * (xb - xa) * pace, ls = limit * s1;
+    if (z < ls) return true;                                 // log(1 + z) <= z
+    if (ls >= 44.0 && z < 1e19) return true;                 // log(1 + 1e19) < 44
+    if (!(z < 1e300)) return false;
+    return log1p(z) < ls;
+}
+// the bound itself (tests): log(1 + s1 (xb - xa) pace) / s1 as an upper bound of the rule's value, +infinity when there is none
+CNF2_UHD double flow_time_bound(const SlopeTerms& s, double xa, double xb, double pace)
+{
+    // bisect on the limit: flow_time_under is monotone in it
+    if (!flow_time_under(s, xa, xb, pace, 1e300)) return HUGE_VAL;
+    double lo = 0.0, hi = 1.0;
+    while (!flow_time_under(s, xa, xb, pace, hi) && hi < 1e300) hi *= 2.0;
+    for (int i = 0; i < 200; i++) {
+        const double mid = 0.5 * (lo + hi);
+        if (flow_time_under(s, xa, xb, pace, mid)) hi = mid;
+        else lo = mid;
+    }
+    return hi;
+}
+
 // ------------------------------------------------------------------ genotype certainties (processinfprobs)
 // One side (allele index) of one individual at one marker.  inf[v-1] = accumulated evidence for allele value v
 // (moveinfprobs, cnF2freq.cpp:3577-3597); an entry takes part if it is > 0 (the reference iterates a map that
@@ -313,6 +554,15 @@ CNF2_UHD bool certainty_flow_setup(const double inf[2], int v, const SideState& 
     c->epsilon = clamp_distance(children);
     return true;
 }
+CNF2_UHD SlopeTerms certainty_slope(const CertaintyFlow& c)
+{
+    SlopeTerms s;
+    s.ev = c.ev;
+    s.e = c.ef;
+    s.d = 0.0;
+    s.pr = 0.0;
+    return s;
+}
 CNF2_UHD double certainty_rgradient(const CertaintyFlow& c, double x)
 {
     const double lg = logit(x);
@@ -347,8 +597,9 @@ CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side
     for (int v = 0; v < 2; v++) {
         CertaintyFlow c;
         if (!certainty_flow_setup(inf, v, s, children, sc, &c)) continue;
+        const SlopeTerms st = certainty_slope(c);
         out[v] = flow_step([&](double x) { return certainty_rgradient(c, x); }, c.curprob, c.epsilon, sc.scalefactor, hits,
-                           false);
+                           false, [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); });
     }
     return certainty_pick(inf, out, side, empty, has_prior, new_allele, new_sure);
 }
@@ -433,6 +684,15 @@ CNF2_UHD void haplo_flow_setup(double hw, double* haplobase, double* haplocount,
     h->descendants = descendants;
     h->epsilon = clamp_distance(children);
 }
+CNF2_UHD SlopeTerms haplo_slope(const HaploFlow& h)
+{
+    SlopeTerms s;
+    s.ev = h.ev;
+    s.e = h.ent;
+    s.d = h.descendants;
+    s.pr = h.phaseratio;
+    return s;
+}
 // gradient = data + phase consistency + entropy = (N + Q^2 E) / Q^2; its reciprocal as one quotient
 CNF2_UHD double haplo_rgradient(const HaploFlow& h, double x)
 {
@@ -447,7 +707,9 @@ CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haploco
 {
     HaploFlow h;
     haplo_flow_setup(hw, haplobase, haplocount, a0, a1, sure0, sure1, phaseratio, children, descendants, sc, &h);
-    return flow_step([&](double x) { return haplo_rgradient(h, x); }, hw, h.epsilon, sc.scalefactor, hits, breakathalf);
+    const SlopeTerms st = haplo_slope(h);
+    return flow_step([&](double x) { return haplo_rgradient(h, x); }, hw, h.epsilon, sc.scalefactor, hits, breakathalf,
+                     [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); });
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).

@@ -542,7 +542,7 @@ void Engine::iteration(FILE* out)
             for (int r = 0; r < R; r++) fprintf(out, "FIRST PASS: %d\n", P.inds[r].n);
         int hits = 0;
         check(cnf2_update_pass(ctx, c, children_.data(), desc.data(), nullptr, nullptr, nullptr, scalefactor_, entropyfactor_,
-                               &hits, 0),
+                               &hits, getenv("CNF2_UPDATE_PLAIN") ? CNF2_UPDATE_PLAIN : 0),      // A/B switch (tuning aid)
               "cnf2_update_pass");
         if (opt.print_rows)
             for (int r = 0; r < R; r++) fprintf(out, "SKEWNESS PASS: %d\n", P.inds[r].n);

@@ -266,6 +266,13 @@ int cnf2_update_pass(cnf2_ctx *ctx, int chrom, const int32_t *children, const in
                      double *haplobase, double *haplocount, double scalefactor, double entropyfactor, int *hits_out,
                      uint32_t flags);
 int cnf2_download_rows(cnf2_ctx *ctx, int row0, int n, uint8_t *allele, double *sure, double *hw);
+/* Diagnostics of the last cnf2_update_pass (flow kernels).  out16[0..3] for the genotype certainties, out16[4..7] for the
+ * haplotype weights: flows run; gradient evaluations of the flows that are not pinned; lane slots offered to them (every
+ * round of a wavefront offers 64: evaluations / slots = lane utilisation); pinned flows (values that sit on their clamp and
+ * are pushed further out: no gradient evaluation beyond the first, see cnf2_update.h).  out16[8..11] / out16[12..15] for the
+ * same two kernels: quadratures run (15 evaluations each; the bound of flow_time_under spares the others), and how many
+ * flows ended because the tolerance was met / the interval fell under 1e-10 / the 51 steps were used up or the bounds left. */
+int cnf2_update_stats(cnf2_ctx *ctx, uint64_t *out16);
 /* The accumulators the context holds (what cnf2_sweep_accumulate left and cnf2_update_pass rewrote when they were called
  * with NULL accumulator pointers): host copies infprobs[n_rec][M][2][2], haplobase / haplocount[n_rec][M]; any pointer may
  * be NULL.  cnf2_upload_accumulators is the reverse (a multi-process driver whose transport moves host memory sums the

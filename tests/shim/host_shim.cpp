@@ -2,6 +2,7 @@
 // (tests/test_host_emission.py).  Compiled with g++ from the same headers the HIP
 // kernels include; contains no algorithmic code of its own beyond the lane loop.
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "cnf2_lane.h"
@@ -407,6 +408,132 @@ void shim_update_haploweights(int n_chrom, const int* chromstarts, double* hw, d
                                              false, hits);
         }
     }
+}
+// Step log of one certainty flow (tuning aid, tools/analyse_flows.py): log[step][4] = mid, kind (0 sign-only, 1 quadrature),
+// t / scalefactor (quadrature steps), 1 / gradient at mid; returns the number of steps, *why as FlowState::why, *result the
+// new probability.  Absent value: returns -1.
+int shim_certainty_flow_trace(const double* inf, int v, int allele, double sure, int prior_allele, double prior_sure,
+                              int children, double scalefactor, double* log, int* why, double* result, double* g_orig)
+{
+    cnf2::SideState s = {allele, sure, prior_allele, prior_sure};
+    cnf2::StepControl sc = {scalefactor, 1.0};
+    cnf2::CertaintyFlow c;
+    if (!cnf2::certainty_flow_setup(inf, v, s, children, sc, &c)) return -1;
+    auto grad = [&](double x) { return cnf2::certainty_rgradient(c, x); };
+    cnf2::FlowState f;
+    cnf2::flow_begin(&f, grad, c.curprob, c.epsilon, scalefactor, false);
+    *g_orig = f.g0;
+    int n = 0;
+    for (;;) {
+        const double lo = f.lo, hi = f.hi;
+        const int    q0 = f.quads;
+        if (!f.live || f.it >= 51 || lo > f.hilim || hi < f.lolim) {
+            cnf2::flow_advance(&f, grad, scalefactor);
+            break;
+        }
+        const double mid = (lo + hi) / 2;
+        const double gm = cnf2::flow_pace(grad, mid, f.epsilon);
+        double       t = 0;
+        double a = f.orig, b = mid;
+        if (a > b) std::swap(a, b);
+        if (isfinite(gm) && ((gm < 0) == f.falling) && b - a >= 1e-10) {
+            const double eps = f.epsilon;
+            t = cnf2::gauss15([&](double x) { return cnf2::flow_pace(grad, x, eps); }, a, b);
+            if (b != mid) t = -t;
+        }
+        const bool more = cnf2::flow_advance(&f, grad, scalefactor);
+        log[n * 4 + 0] = mid;
+        log[n * 4 + 1] = f.quads - q0;
+        log[n * 4 + 2] = t / scalefactor;
+        log[n * 4 + 3] = gm;
+        n++;
+        if (!more) break;
+    }
+    int hits = 0;
+    *why = f.why;
+    *result = cnf2::flow_end(f, scalefactor, &hits, false);
+    return n;
+}
+// One flow with or without the time bound (flow_time_bound): kind 0 = certainty (a, b from the evidence g of h at belief y;
+// e = entropy factor, c0 = prior term), kind 1 = haplotype weight (e = entropy coefficient, d = descendants, pr = phase
+// ratio).  out[4] = result, quadrature steps, spared steps, hits.
+void shim_flow(int kind, double y, double g, double h, double e, double c0, double d, double pr, double epsilon,
+               double scalefactor, int screened, double* out)
+{
+    cnf2::SlopeTerms st;
+    st.ev = cnf2::evidence_terms(y, g, h);
+    st.e = e;
+    st.d = d;
+    st.pr = pr;
+    cnf2::CertaintyFlow c;
+    c.ev = st.ev;
+    c.ef = e;
+    c.priord = c0;
+    cnf2::HaploFlow hf;
+    hf.ev = st.ev;
+    hf.ent = e;
+    hf.phaseratio = pr;
+    hf.descendants = d;
+    auto grad = [&](double x) { return kind == 0 ? cnf2::certainty_rgradient(c, x) : cnf2::haplo_rgradient(hf, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) { return screened ? cnf2::flow_time_under(st, xa, xb, pc, lim) : false; };
+    cnf2::FlowState f;
+    cnf2::flow_begin(&f, grad, y, epsilon, scalefactor, false);
+    if (screened == 2 && !f.pinned) {
+        // the one-evaluation-at-a-time machine the kernels run
+        cnf2::FlowRun r;
+        r.f = f;
+        r.phase = 0;
+        double v;
+        auto   b1 = [&](double xa, double xb, double pc, double lim) { return cnf2::flow_time_under(st, xa, xb, pc, lim); };
+        while (cnf2::flow_want(&r, scalefactor, &v)) cnf2::flow_feed(&r, grad(v), scalefactor, b1);
+        f = r.f;
+    } else {
+        while (cnf2::flow_advance(&f, grad, scalefactor, bound)) {}
+    }
+    int hits = 0;
+    out[0] = cnf2::flow_end(f, scalefactor, &hits, false);
+    out[1] = f.quads;
+    out[2] = f.spared;
+    out[3] = hits;
+    out[4] = f.it;
+}
+// flow_time_bound against what the rule really reports over [xa, xb] (xa or xb = the flow's start, sign of G constant):
+// out[0] = bound, out[1] = |rule|, out[2] = min over 200 sample points of -G' by central differences, out[3] = the
+// slope bound s1 the time bound used (recovered from the bound: 0 when it is infinite)
+void shim_time_bound(int kind, double y, double g, double h, double e, double c0, double d, double pr, double xa, double xb,
+                     int mid_is_b, double* out)
+{
+    cnf2::SlopeTerms st;
+    st.ev = cnf2::evidence_terms(y, g, h);
+    st.e = e;
+    st.d = d;
+    st.pr = pr;
+    cnf2::CertaintyFlow c;
+    c.ev = st.ev;
+    c.ef = e;
+    c.priord = c0;
+    cnf2::HaploFlow hf;
+    hf.ev = st.ev;
+    hf.ent = e;
+    hf.phaseratio = pr;
+    hf.descendants = d;
+    auto rg = [&](double x) { return kind == 0 ? cnf2::certainty_rgradient(c, x) : cnf2::haplo_rgradient(hf, x); };
+    const double xm = mid_is_b ? xb : xa;
+    out[0] = cnf2::flow_time_bound(st, xa, xb, fabs(rg(xm)));
+    out[1] = fabs(cnf2::gauss15(rg, xa, xb));
+    double smin = HUGE_VAL;
+    bool   sign_const = true;
+    const double g_first = 1.0 / rg(xa);
+    for (int i = 0; i <= 200; i++) {
+        const double x = xa + (xb - xa) * i / 200.0, hstep = 1e-6 * (x < 1 - x ? x : 1 - x);
+        const double gp = 1.0 / rg(x + hstep), gm = 1.0 / rg(x - hstep);
+        smin = std::min(smin, -(gp - gm) / (2 * hstep));
+        sign_const = sign_const && ((1.0 / rg(x) < 0) == (g_first < 0));
+    }
+    out[2] = smin;
+    out[3] = sign_const ? 1.0 : 0.0;
+    out[4] = ((1.0 / rg(xa) < 0) == (1.0 / rg(xb) < 0)) ? 1.0 : 0.0;     // the caller's precondition: same sign at both ends
+    out[5] = 1.0 / rg(mid_is_b ? xa : xb);                                 // gradient at the flow's start (its sign is the direction)
 }
 double shim_adapt_scalefactor(double scalefactor, int hits, int* old, int n_analysed)
 {

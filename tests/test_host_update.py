@@ -37,6 +37,8 @@ def shim():
     L.shim_phase_ratio.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.shim_update_haploweights.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, D, D, IP]
+    L.shim_flow.argtypes = [C.c_int, D, D, D, D, D, D, D, D, D, C.c_int, C.c_void_p]
+    L.shim_time_bound.argtypes = [C.c_int, D, D, D, D, D, D, D, D, D, C.c_int, C.c_void_p]
     L.shim_adapt_scalefactor.argtypes = [D, C.c_int, C.c_void_p, C.c_int]
     L.shim_adapt_scalefactor.restype = D
     return L
@@ -230,3 +232,66 @@ def test_haploweight_update_matches_the_reference_goldens(shim):
         np.testing.assert_allclose(hb, want[:, 1], rtol=1e-9, atol=1e-12, equal_nan=True)
         np.testing.assert_allclose(hc, want[:, 2], rtol=1e-9, atol=1e-12, equal_nan=True)
         assert hits.value == int(want_hits)
+
+
+def _random_flow(rs):
+    """Parameters of a flow in the regimes a run visits: beliefs near 0 / 1 / anywhere, evidence near or far from the belief."""
+    kind = int(rs.randint(2))
+    y = float(rs.choice([rs.uniform(0.02, 0.98), 10 ** rs.uniform(-5, -1.5), 1 - 10 ** rs.uniform(-5, -1.5)]))
+    h = float(10 ** rs.uniform(-2, 2))
+    share = float(np.clip(rs.choice([y * 10 ** rs.uniform(-0.5, 0.5), rs.uniform(0, 1), y]), 1e-9, 1 - 1e-9))
+    g = h * share
+    if kind == 0:
+        e, c0, d, pr = float(rs.choice([1.0, 0.5])), float(rs.choice([0.0, rs.normal() * 3, np.log(0.02 / 0.98), np.log(0.98 / 0.02)])), 0.0, 0.0
+    else:
+        e, c0 = float(rs.choice([5.0068e-6, 0.04, 0.5, 1.0])), 0.0
+        d, pr = float(rs.randint(1, 9)), float(np.clip(rs.choice([y, rs.uniform(0, 1), y + rs.normal() * 1e-3]), 0, 1))
+    return kind, y, g, h, e, c0, d, pr
+
+
+def test_time_bound_is_a_bound(shim):
+    """flow_time_bound: whenever it reports a finite value for an interval, (a) the gradient is monotone there with at least
+    the slope the bound assumes (checked by differences at 200 points) and keeps its sign, and (b) the 15-point rule over
+    the interval does not exceed it."""
+    rs = np.random.RandomState(11)
+    out = np.zeros(6)
+    finite = tight = 0
+    for _ in range(30000):
+        kind, y, g, h, e, c0, d, pr = _random_flow(rs)
+        width = 10 ** rs.uniform(-12, -0.3) * min(y, 1 - y)
+        lo = int(rs.randint(2))
+        xa, xb = (y - width, y) if lo else (y, y + width)
+        if xa <= 1e-6 or xb >= 1 - 1e-6:
+            continue
+        shim.shim_time_bound(kind, y, g, h, e, c0, d, pr, xa, xb, 0 if lo else 1, _p(out))
+        # flow_advance asks only when both ends have the same sign, and a flow moves down exactly when its gradient is negative
+        if not np.isfinite(out[0]) or out[4] != 1.0 or (out[5] < 0) != bool(lo):
+            continue
+        finite += 1
+        assert out[3] == 1.0, "the gradient changes sign inside an interval the bound accepted"
+        assert out[2] > 0, "the gradient is not monotone on an interval the bound accepted"
+        assert out[1] <= out[0] * (1 + 1e-9), (kind, y, g, h, e, c0, d, pr, xa, xb, out)
+        tight += int(out[1] > 0.2 * out[0])
+    assert finite > 5000 and tight > 500
+
+
+def test_flows_with_the_bound_equal_flows_without(shim):
+    """The bound only spares quadratures whose verdict it knows: results and hit counts are identical to the bit."""
+    rs = np.random.RandomState(12)
+    a, b, m = np.zeros(4), np.zeros(4), np.zeros(4)
+    spared = quads = 0
+    for _ in range(20000):
+        kind, y, g, h, e, c0, d, pr = _random_flow(rs)
+        eps = 5e-6 / rs.randint(1, 4)
+        y = float(np.clip(y, eps, 1 - eps))
+        sf = float(rs.choice([0.013, 0.05, 0.2, 0.4]))
+        shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 1, _p(a))
+        shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 0, _p(b))
+        assert a[0] == b[0] and a[3] == b[3], (kind, y, g, h, e, c0, d, pr, eps, sf, a, b)
+        assert a[1] + a[2] == b[1]
+        # the kernels' form of the same steps: one gradient evaluation at a time (FlowRun)
+        shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 2, _p(m))
+        assert np.array_equal(m, a), (kind, y, g, h, e, c0, d, pr, eps, sf, a, m)
+        spared += a[2]
+        quads += b[1]
+    assert spared > 0.2 * quads

@@ -1,0 +1,44 @@
+"""Tuning aid: what the persistent flow kernels of the update pass do in the steady state of a haplotyping run
+(config 5's shape): per iteration the time and, for the last chromosome's pass, flows, bisection steps per flow and lane
+utilisation (cnf2_update_stats).
+usage: python tools/flow_stats.py [families=500] [snps_per_chrom=2500] [chroms=4] [iterations=30]"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: before libcnf2hip.so)
+
+from cnf2freq_amd import capi, host, synth
+
+fams = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+snps = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
+chroms = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
+run = host.Run(ped)
+run.postmarkerdata()
+L = capi.load()
+for it in range(iters):
+    t = time.time()
+    run.iteration(None)
+    dt = time.time() - t
+    out = np.zeros(16, np.uint64)
+    L.cnf2_update_stats(run.context(), out.ctypes.data_as(C.c_void_p))
+    st = run.L.cnf2h_get_state  # noqa: F841
+    sf = C.c_double(0)
+    hits = C.c_int(0)
+    run.L.cnf2h_get_state(run.h, None, None, None, None, None, None, C.byref(sf), C.byref(hits))
+    c, h = out[:4].astype(float), out[4:8].astype(float)
+    cq, hq = out[8:12].astype(float), out[12:16].astype(float)
+    print("it %2d  %.3f s  sf %.4f hits %8d | certainty: %.3g flows, %.0f%% pinned, %.1f evaluations per other flow, lanes %.2f | "
+          "haploweight: %.3g flows, %.0f%% pinned, %.1f evaluations per other flow, lanes %.2f"
+          % (it + 1, dt, sf.value, hits.value, c[0], 100 * c[3] / max(c[0], 1), c[1] / max(c[0] - c[3], 1), c[1] / max(c[2], 1),
+             h[0], 100 * h[3] / max(h[0], 1), h[1] / max(h[0] - h[3], 1), h[1] / max(h[2], 1)), flush=True)
+    print("       certainty: %.2f quadratures per flow; ended by tolerance %.0f%%, by interval < 1e-10 %.0f%%, by 51 steps / bounds %.0f%%"
+          " | haploweight: %.2f; %.0f%% / %.0f%% / %.0f%%"
+          % (cq[0] / max(c[0] - c[3], 1), 100 * cq[1] / max(c[0] - c[3], 1), 100 * cq[2] / max(c[0] - c[3], 1), 100 * cq[3] / max(c[0] - c[3], 1),
+             hq[0] / max(h[0] - h[3], 1), 100 * hq[1] / max(h[0] - h[3], 1), 100 * hq[2] / max(h[0] - h[3], 1), 100 * hq[3] / max(h[0] - h[3], 1)), flush=True)
+run.close()

@@ -1,7 +1,7 @@
 """Measurement aid: one haplotyping iteration of BASELINE config 5's shape (3-generation outbred, 20 % missing) on one
 GPU, through the C ABI with everything device-resident: plain sweep, sweep + HOT LOOP 2 accumulators
 (cnf2_sweep_accumulate), the update passes of every chromosome.
-usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations] [scalefactor]"""
+usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations] [scalefactor] [flow|plain]"""
 import ctypes as C
 import os
 import sys
@@ -65,6 +65,7 @@ print("turn scan          %.3f s for %d individuals  %.3g units/s (%.1f x sweep 
       % (t_turn, nt, nt * M / t_turn, (t_turn / (nt * M)) / (t_sweep / units), float(lse[0, 0, 0].item())), flush=True)
 del lse
 sf = float(sys.argv[5]) if len(sys.argv) > 5 else 0.013
+upd_flags = capi.ACC_DEVICE | (capi.UPDATE_PLAIN if len(sys.argv) > 6 and sys.argv[6] == "plain" else 0)
 for it in range(iters):
     t = time.time()
     ctx.sweep_accumulate_device(desc, 0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(), inf.data_ptr(),
@@ -77,7 +78,7 @@ for it in range(iters):
         hits = np.zeros(1, np.int32)
         ctx._chk(ctx.L.cnf2_update_pass(ctx.h, c, children.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p),
                                         C.c_void_p(inf.data_ptr()), C.c_void_p(hb.data_ptr()), C.c_void_p(hc.data_ptr()),
-                                        sf, 1.0, hits.ctypes.data_as(C.c_void_p), capi.ACC_DEVICE), "cnf2_update_pass")
+                                        sf, 1.0, hits.ctypes.data_as(C.c_void_p), upd_flags), "cnf2_update_pass")
         hits_total += int(hits[0])
     t_upd = time.time() - t
     print("iteration %d: sweep+accumulate %.3f s (%.2f x sweep, %.3g units/s)   update passes %.3f s   hits %d   "
