@@ -390,8 +390,9 @@ class Context:
         """Diagnostics of the last update pass: dict of (flows, steps, slots, refills) for certainty / haploweight."""
         out = np.zeros(16, np.uint64)
         self._chk(self.L.cnf2_update_stats(self.h, _p(out)), "cnf2_update_stats")
-        return dict(certainty=tuple(int(x) for x in np.r_[out[0:4], out[8:12]]),
-                    haploweight=tuple(int(x) for x in np.r_[out[4:8], out[12:16]]))
+        names = ("flows", "scout_evaluations", "ended_in_scout", "pinned", "finish_steps", "finish_slots", "quadratures", "ended_by_tolerance")
+        return dict(certainty=dict(zip(names, (int(x) for x in np.r_[out[0:4], out[8:12]]))),
+                    haploweight=dict(zip(names, (int(x) for x in np.r_[out[4:8], out[12:16]]))))
 
     def download_accumulators(self):
         """The accumulators the context holds: dict(infprobs [R][M][2][2], haplobase [R][M], haplocount [R][M])."""

@@ -92,6 +92,8 @@ struct cnf2_ctx {
     int*     d_hits = nullptr;
     unsigned long long* d_flow_next = nullptr;
     double*  d_flow_out = nullptr;
+    double*  d_todo = nullptr;            // flows set aside by the scouts (3 doubles each)
+    size_t   todo_cap = 0;
     double*  d_part = nullptr;            // CNF2_DETERMINISTIC rows
     size_t   part_cap = 0;
     int32_t* d_gather = nullptr;          // rec_start [n_rec + 1] followed by the list
@@ -223,6 +225,7 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_flow_next);
     (void)hipFree(ctx->d_flow_out);
+    (void)hipFree(ctx->d_todo);
     (void)hipFree(ctx->d_part);
     (void)hipFree(ctx->d_gather);
     (void)hipFree(ctx->d_scanwin);
@@ -1438,9 +1441,14 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     if (!(flags & CNF2_UPDATE_PLAIN)) {
         if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 26 * sizeof(unsigned long long)));
         if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)(u.last - u.first + 1) * 4))) return rc;
+        // the scouts work through their flows in chunks; a chunk's worth of set-aside entries (24 bytes each)
+        const size_t chunk = (size_t)1 << 27;
+        if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, chunk * 3))) return rc;
         u.flow_next = ctx->d_flow_next;
         u.flow_out = ctx->d_flow_out;
-        u.stats = ctx->d_flow_next + 2;
+        u.stats = getenv("CNF2_UPDATE_STATS") ? ctx->d_flow_next + 2 : nullptr;     // diagnostics cost a few atomics per wavefront
+        u.todo = ctx->d_todo;
+        u.todo_cap = chunk;
     }
     launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
@@ -1506,10 +1514,7 @@ int cnf2_update_stats(cnf2_ctx* ctx, uint64_t* out16)
     if (!ctx->d_flow_next) return fail(ctx, CNF2_ERR_STATE, "no update pass has run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t raw[24];
-    HIP_TRY(ctx, hipMemcpy(raw, ctx->d_flow_next + 2, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 16; i++) out16[i] = raw[i];
-
+    HIP_TRY(ctx, hipMemcpy(out16, ctx->d_flow_next + 2, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CNF2_OK;
 }
 

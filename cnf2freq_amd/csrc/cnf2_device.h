@@ -124,7 +124,9 @@ struct UpdateParams {
     double         scalefactor, entropyfactor;
     int*           hits;          // device counter
     unsigned long long* flow_next;   // [2] item counters of the persistent flow kernels; null = one thread per element
-    unsigned long long* stats;       // [8] diagnostics of the two flow kernels (flow_stats), may be null
+    unsigned long long* stats;       // [24] diagnostics of the flow kernels (cnf2_update_stats), may be null
+    void*          todo;          // flows the scouts set aside for the finish kernels (24 bytes each)
+    size_t         todo_cap;      // flows per chunk of a scout = entries of todo
     double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);

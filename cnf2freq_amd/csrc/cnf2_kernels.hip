@@ -2151,6 +2151,7 @@ void launch_variance_closed(const KernelParams& p, int n_windows, double* out, h
 // Per-iteration parameter updates on the device (cnf2_update.h; processinfprobs / updatehaploweights,
 // cnF2freq.cpp:4179-4323, 4533-4734), after the sweep of chromosome `chrom` has been accounted for.
 // ---------------------------------------------------------------------------------------------------
+// CNF2_UPDATE_PLAIN -- the literal form: every same-sign step runs its quadrature, as the reference's cappedgd does.
 // One thread per (record, marker of the chromosome): both sides in order (side 1 sees side 0's result only through
 // the accumulators, which are per side), then the record's evidence at the marker is cleared.
 __global__ __launch_bounds__(256) void certainty_update_kernel(UpdateParams u)
@@ -2178,7 +2179,7 @@ __global__ __launch_bounds__(256) void certainty_update_kernel(UpdateParams u)
         s.prior_sure = side ? psu.y : psu.x;
         int    na;
         double ns;
-        if (update_certainty(inf + side * 2, s, side, empty, has_prior, u.children[r], sc, &hits, &na, &ns)) {
+        if (update_certainty(inf + side * 2, s, side, empty, has_prior, u.children[r], sc, &hits, &na, &ns, true)) {
             if (side) {
                 ap = (uint8_t)((ap & 15) | (na << 4));
                 su.y = ns;
@@ -2269,31 +2270,47 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
     const StepControl sc = {u.scalefactor, u.entropyfactor};
     int hits = 0;
     const double nw = update_haploweight(hw, &hb, &hcv, ap & 15, ap >> 4, su.x, su.y, u.ratio[k], u.children[r],
-                                         u.descendants[r], sc, false, &hits);
+                                         u.descendants[r], sc, false, &hits, true);
     u.acc_hb[k] = hb;
     u.acc_hc[k] = hcv;
     u.hw[i] = nw;
     if (hits) atomicAdd(u.hits, hits);
 }
 
-// ---- the same two updates as persistent flow kernels ----------------------------------------------------------
-// A flow (cnf2_update.h) takes between 1 and 51 bisection steps, a step one gradient evaluation (the midpoint's sign
-// settles it, or the bound of flow_time_under does) or sixteen (a 15-point quadrature), and flows of either kind sit
-// next to each other: with one thread per element nearly every wavefront waits for its longest lane.  Here a wavefront
-// holds 64 flows as machines that ask for ONE gradient evaluation per round (FlowRun): every lane executes the
-// expensive part together, whatever its flow is going to do with the value, and a lane whose flow has ended takes the
-// next one from a global counter (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else
-// is running, because the set-up of a flow -- loads, the prior's logarithms, the gradient at the start -- is executed
-// by the whole wave).  Flows that are pinned to their clamp need no evaluation at all and end during the refill.
-// Every wave ends when the counter has passed the last item and its lanes have drained.
+// ---- the same two updates as flow kernels --------------------------------------------------------------------
+// A flow (cnf2_update.h) takes between 1 and 51 bisection steps, a step one gradient evaluation or none (the midpoint's
+// sign settles it, or a bound does) or sixteen (a 15-point quadrature); with one thread per element nearly every
+// wavefront waits for its longest lane, and most of the evaluations locate a root by bisection.  Two passes instead:
+//   scout   one thread per flow (flow_scout): set-up, the flows pinned to their clamp, and every step that needs no
+//           quadrature -- with the gradient shown monotone the root is found superlinearly and the bisection's own
+//           midpoints are answered from what is known about it.  In the steady state of a run three flows in four
+//           end here, after ~20 evaluations instead of ~65.  A flow that reaches a quadrature is set aside: its item,
+//           the number of steps it has completed and their decisions (16 or 24 bytes).
+//   finish  the flows set aside, as a persistent kernel: a wavefront runs ONE literal step (flow_advance: midpoint, the
+//           bound, the quadrature) of 64 independent flows per round and hands a lane the next flow from a global counter
+//           when its own has ended (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else
+//           is running, because taking a flow up -- loads, the prior's logarithms, the gradient at the start, the replay
+//           of its decisions -- is executed by the whole wave).  These flows spend their steps in quadratures, so the
+//           lanes of a wave stay in step.
+// Both passes make the decisions of the literal algorithm (CNF2_UPDATE_PLAIN); what differs is how much is computed.
+#ifndef FLOW_REFILL
 #define FLOW_REFILL 16
+#endif
 
-// diagnostics: stats[0..3] += flows, bisection steps of the flows that are not pinned, step rounds x 64 lanes offered to
-// them, pinned flows (FlowState::pinned: no gradient evaluation beyond the first)
-__device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned flows, unsigned steps, unsigned rounds, unsigned pinned)
+struct FlowTodo {
+    unsigned long long item_steps;   // item << 6 | steps completed
+    unsigned long long path;         // their decisions (FlowState::path)
+};
+struct HaploTodo {
+    unsigned long long item_steps, path;
+    double             similarity;   // what haplo_rewrite returned in the scout (the rewrite is not repeated)
+};
+
+// diagnostics: stats[0..3] += a, b, c, d summed over the wavefront
+__device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned a_, unsigned b_, unsigned c_, unsigned d_)
 {
     if (!stats) return;
-    unsigned long long a = flows, b = steps, c = pinned, d = rounds;
+    unsigned long long a = a_, b = b_, c = c_, d = d_;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o);
@@ -2301,107 +2318,190 @@ __device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned f
         c += __shfl_xor(c, o);
         d += __shfl_xor(d, o);
     }
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {
         atomicAdd(stats + 0, a);
         atomicAdd(stats + 1, b);
-        atomicAdd(stats + 2, d);
-        atomicAdd(stats + 3, c);
+        atomicAdd(stats + 2, c);
+        atomicAdd(stats + 3, d);
     }
 }
 
-// next items for the free lanes of the wave; returns false when the counter has passed n_items (wave-uniform)
-__device__ __forceinline__ bool flow_take(unsigned long long* next, unsigned long long n_items, bool want,
-                                          unsigned long long* item, bool* got)
+// the hit counter: one atomic per wavefront that has any
+__device__ __forceinline__ void flow_hits(int* counter, int hits)
+{
+    int h = hits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(counter, h);
+}
+
+// The flows the scout set aside reach the lanes of a finish wavefront through a queue of the wave's own in LDS: the wave
+// reserves FLOW_CHUNK slots of the scout's list at a time (an atomic on one address costs tens of nanoseconds across the
+// 8 XCDs: a counter bumped once per refill was most of the run time of these kernels), reads them 64 at a time -- one
+// coalesced load -- and queues the entries that hold a flow.  Free lanes take from the queue.
+#define FLOW_CHUNK 4096ull
+#define FLOW_QUEUE 128          /* entries: at most 63 left over plus 64 from one read */
+template <class Entry>
+struct FlowSupply {
+    unsigned long long pos, end;      // the wave's reservation in the scout's list
+    int                count;         // entries queued
+    bool               more;          // the list has slots the wave has not read
+};
+// tops the queue up to at least `wanted` entries (or until the list is exhausted)
+template <class Entry>
+__device__ __forceinline__ void flow_supply(FlowSupply<Entry>* q, Entry* queue, unsigned long long* next, const Entry* todo,
+                                            unsigned long long n_items, int wanted)
+{
+    const int lane = threadIdx.x & 63;
+    while (q->more && q->count < wanted) {
+        if (q->pos >= q->end) {                              // reservation used up: a new one
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(next, FLOW_CHUNK);
+            base = __shfl(base, 0);
+            if (base >= n_items) {
+                q->more = false;
+                break;
+            }
+            q->pos = base;
+            q->end = base + FLOW_CHUNK < n_items ? base + FLOW_CHUNK : n_items;
+        }
+        const unsigned long long slot = q->pos + lane;
+        Entry e;
+        e.item_steps = ~0ull;
+        if (slot < q->end) e = todo[slot];
+        const bool               holds = e.item_steps != ~0ull;
+        const unsigned long long mask = __ballot(holds);
+        if (holds) queue[q->count + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+        q->count += __popcll(mask);
+        q->pos = q->pos + 64 < q->end ? q->pos + 64 : q->end;
+        wave_lds_fence();
+    }
+}
+// entries for the lanes that want one: the last `n` queued, n = min(lanes that want, queued)
+template <class Entry>
+__device__ __forceinline__ bool flow_pop(FlowSupply<Entry>* q, const Entry* queue, bool want, Entry* e)
 {
     const unsigned long long need = __ballot(want);
-    const int                cnt = __popcll(need), leader = __ffsll((long long)need) - 1;
-    unsigned long long       base = 0;
-    if ((int)threadIdx.x == leader) base = atomicAdd(next, (unsigned long long)cnt);
-    base = __shfl(base, leader);
-    *got = false;
-    if (want) {
-        *item = base + (unsigned)__popcll(need & ((1ull << threadIdx.x) - 1ull));
-        *got = *item < n_items;
-    }
-    return base + (unsigned)cnt < n_items;
+    const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1ull)), n = __popcll(need);
+    const int take = n < q->count ? n : q->count;
+    const bool got = want && rank < take;
+    if (got) *e = queue[q->count - 1 - rank];
+    wave_lds_fence();
+    q->count -= take;
+    return got;
 }
 
 // item = ((r * len + mi) * 2 + side) * 2 + v: the flow of value v + 1 on one side of (record, marker);
 // flow_out[item] = its new probability (0 where the value has no evidence)
-__global__ __launch_bounds__(64) void certainty_flow_kernel(UpdateParams u, unsigned long long* next, double* flow_out)
+__device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c)
 {
-    const int                len = u.last - u.first + 1;
-    const unsigned long long n_items = (unsigned long long)u.n_rec * len * 4;
+    const int          len = u.last - u.first + 1;
+    const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
+    const unsigned long long e = item >> 2;
+    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
+    const double       pair[2] = {inf[0], inf[1]};
+    const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool         has_prior = u.has_prior[r] != 0;
+    const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
+    const double2      su = u.sure[i];
+    const double2      psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
+    SideState s;
+    s.allele = side ? (ap >> 4) : (ap & 15);
+    s.sure = side ? su.y : su.x;
+    s.prior_allele = side ? (pap >> 4) : (pap & 15);
+    s.prior_sure = side ? psu.y : psu.x;
+    return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
+}
+
+__global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+                                                              double* flow_out, FlowTodo* todo)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
-    bool               have = false, more = true;
-    unsigned long long item = 0;
-    CertaintyFlow      c;
-    FlowRun            run;
-    SlopeTerms         st;
-    int                hits = 0;
-    unsigned           n_flows = 0, n_evals = 0, n_rounds = 0, n_pinned = 0, n_quads = 0, n_why1 = 0, n_why2 = 0, n_why3 = 0;    // diagnostics
-    auto grad = [&](double x) { return certainty_rgradient(c, x); };
-    auto bound = [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); };
-    for (;;) {
-        const int busy = __popcll(__ballot(have));
-        if (more && (busy <= 64 - FLOW_REFILL)) {
-            bool got;
-            more = flow_take(next, n_items, !have, &item, &got);
-            if (got) {
-                const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
-                const unsigned long long e = item >> 2;
-                const int          r = (int)(e / len), m = u.first + (int)(e % len);
-                const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
-                const double       pair[2] = {inf[0], inf[1]};
-                const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
-                const bool         has_prior = u.has_prior[r] != 0;
-                const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
-                const double2      su = u.sure[i];
-                const double2      psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
-                SideState s;
-                s.allele = side ? (ap >> 4) : (ap & 15);
-                s.sure = side ? su.y : su.x;
-                s.prior_allele = side ? (pap >> 4) : (pap & 15);
-                s.prior_sure = side ? psu.y : psu.x;
-                if (certainty_flow_setup(pair, v, s, u.children[r], sc, &c)) {
-                    flow_begin(&run.f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
-                    run.phase = 0;
-                    st = certainty_slope(c);
-                    n_flows++;
-                    if (run.f.pinned) {         // no gradient evaluations left: finished on the spot, the lane asks again
-                        while (flow_advance(&run.f, grad, sc.scalefactor)) {}
-                        flow_out[item] = flow_end(run.f, sc.scalefactor, &hits, false);
-                        n_pinned++;
-                    } else {
-                        have = true;
-                    }
+    int      hits = 0, evals = 0;
+    unsigned n_flows = 0, n_pinned = 0, n_done = 0;
+    bool     aside = false;
+    FlowTodo e;
+    if (t < n_items) {
+        const unsigned long long item = item0 + t;
+        CertaintyFlow c;
+        if (!certainty_item(u, item, sc, &c)) {
+            flow_out[item] = 0.0;
+        } else {
+            FlowState f;
+            auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
+            flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+            n_flows = 1;
+            if (f.pinned) {                 // no gradient evaluations left
+                while (flow_advance(&f, grad, sc.scalefactor)) {}
+                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                n_pinned = 1;
+            } else {
+                const SlopeTerms st = certainty_slope(c);
+                if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                    flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                    n_done = 1;
                 } else {
-                    flow_out[item] = 0.0;
+                    aside = true;
+                    e.item_steps = (item << 6) | (unsigned long long)f.it;
+                    e.path = f.path;
                 }
             }
-            continue;                       // lanes whose item held no flow ask again
+        }
+    }
+    if (t < n_items) {
+        if (!aside) e.item_steps = ~0ull;                     // nothing set aside in this slot
+        todo[t] = e;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+__global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
+                                                              unsigned long long n_items, double* flow_out)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ FlowTodo  queue[FLOW_QUEUE];
+    FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
+    bool               have = false;
+    unsigned long long item = 0;
+    CertaintyFlow      c;
+    FlowState          f;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_steps = 0, n_rounds = 0, n_quads = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) CNF2_LI { return flow_time_under(st, xa, xb, pc, lim); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            FlowTodo e;
+            if (flow_pop(&q, queue, !have, &e)) {
+                item = e.item_steps >> 6;
+                certainty_item(u, item, sc, &c);
+                flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+                flow_replay(&f, e.path, (int)(e.item_steps & 63));
+                st = certainty_slope(c);
+                have = true;
+            }
+            continue;
         }
         if (busy == 0) break;               // nothing running and nothing left
-        // one round = one gradient evaluation for every flow of the wavefront, wherever it is in its bisection
         n_rounds++;
         if (have) {
-            double v;
-            if (flow_want(&run, sc.scalefactor, &v)) {
-                n_evals++;
-                flow_feed(&run, grad(v), sc.scalefactor, bound);
-            } else {
-                flow_out[item] = flow_end(run.f, sc.scalefactor, &hits, false);
+            n_steps++;
+            if (!flow_advance(&f, grad, sc.scalefactor, bound)) {
+                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
                 have = false;
-                n_quads += run.f.quads;
-                n_why1 += run.f.why == 1;
-                n_why2 += run.f.it;
-                n_why3 += run.f.spared;
+                n_quads += f.quads;
+                n_why1 += f.why == 1;
             }
         }
     }
     if (hits) atomicAdd(u.hits, hits);
-    flow_stats(u.stats, n_flows, n_evals, n_rounds, n_pinned);
-    flow_stats(u.stats ? u.stats + 8 : nullptr, n_quads, n_why1, n_why2, n_why3);
+    flow_stats(u.stats ? u.stats + 8 : nullptr, n_steps, n_rounds, n_quads, n_why1);
 }
 
 // one thread per (record, marker of the chromosome): cnF2freq.cpp:4292-4322 from the flows' results
@@ -2443,77 +2543,117 @@ __global__ __launch_bounds__(256) void certainty_pick_kernel(UpdateParams u, con
     }
 }
 
-// item = r * upto + m over the markers of the chromosomes <= chrom
-__global__ __launch_bounds__(64) void haploweight_flow_kernel(UpdateParams u, unsigned long long* next)
+// item = r * upto + m over the markers of the chromosomes <= chrom.  false: nothing to update there
+__device__ __forceinline__ bool haplo_item(const UpdateParams& u, unsigned long long item, size_t* row_i, size_t* k, int* r_out)
 {
-    const int                upto = u.chromstarts_host_upto;
-    const unsigned long long n_items = (unsigned long long)u.n_rec * upto;
+    const int upto = u.chromstarts_host_upto;
+    const int r = (int)(item / upto), m = (int)(item % upto);
+    int       c = 0;
+    while (m >= u.chromstarts[c + 1]) c++;
+    *row_i = (size_t)u.row_of[r] * u.n_markers + m;
+    *k = (size_t)r * u.n_markers + m;
+    *r_out = r;
+    const double hw = u.hw[*row_i];
+    return u.anyinfo[(size_t)r * u.n_chrom + c] && hw != 0.0 && hw != 1.0 && u.row_of[r] != 0;          // cnF2freq.cpp:4591
+}
+
+__global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+                                                                HaploTodo* todo)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
-    bool               have = false, more = true;
-    unsigned long long item = 0;
+    int      hits = 0, evals = 0;
+    unsigned n_flows = 0, n_pinned = 0, n_done = 0;
+    size_t   row_i, k;
+    int      r;
+    bool      aside = false;
+    HaploTodo e;
+    if (t < n_items && haplo_item(u, item0 + t, &row_i, &k, &r)) {
+        const double  hw = u.hw[row_i];
+        const uint8_t ap = u.allele8[row_i];
+        const double2 su = u.sure[row_i];
+        double hb = u.acc_hb[k], hcv = u.acc_hc[k];
+        const double similarity = haplo_rewrite(hw, &hb, &hcv, haplo_similarity(ap & 15, ap >> 4, su.x, su.y));
+        u.acc_hb[k] = hb;
+        u.acc_hc[k] = hcv;
+        HaploFlow h;
+        haplo_flow_terms(hw, hb, hcv, similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+        FlowState f;
+        auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+        flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+        n_flows = 1;
+        if (f.pinned) {
+            while (flow_advance(&f, grad, sc.scalefactor)) {}
+            u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+            n_pinned = 1;
+        } else {
+            const SlopeTerms st = haplo_slope(h);
+            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+                n_done = 1;
+            } else {
+                aside = true;
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it;
+                e.path = f.path;
+                e.similarity = similarity;
+            }
+        }
+    }
+    if (t < n_items) {
+        if (!aside) e.item_steps = ~0ull;                     // nothing set aside in this slot
+        todo[t] = e;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+__global__ __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
+                                                                unsigned long long n_items)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ HaploTodo  queue[FLOW_QUEUE];
+    FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
+    bool               have = false;
     size_t             row_i = 0;
     HaploFlow          h;
-    FlowRun            run;
+    FlowState          f;
     SlopeTerms         st;
     int                hits = 0;
-    unsigned           n_flows = 0, n_evals = 0, n_rounds = 0, n_pinned = 0, n_quads = 0, n_why1 = 0, n_why2 = 0, n_why3 = 0;
-    auto grad = [&](double x) { return haplo_rgradient(h, x); };
-    auto bound = [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); };
+    unsigned           n_steps = 0, n_rounds = 0, n_quads = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) CNF2_LI { return flow_time_under(st, xa, xb, pc, lim); };
     for (;;) {
         const int busy = __popcll(__ballot(have));
-        if (more && (busy <= 64 - FLOW_REFILL)) {
-            bool got;
-            more = flow_take(next, n_items, !have, &item, &got);
-            if (got) {
-                const int r = (int)(item / upto), m = (int)(item % upto);
-                int       c = 0;
-                while (m >= u.chromstarts[c + 1]) c++;
-                row_i = (size_t)u.row_of[r] * u.n_markers + m;
+        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            HaploTodo e;
+            if (flow_pop(&q, queue, !have, &e)) {
+                size_t k;
+                int    r;
+                haplo_item(u, e.item_steps >> 6, &row_i, &k, &r);
                 const double hw = u.hw[row_i];
-                if (u.anyinfo[(size_t)r * u.n_chrom + c] && hw != 0.0 && hw != 1.0 && u.row_of[r] != 0) {   // cnF2freq.cpp:4591
-                    const uint8_t ap = u.allele8[row_i];
-                    const double2 su = u.sure[row_i];
-                    const size_t  k = (size_t)r * u.n_markers + m;
-                    double hb = u.acc_hb[k], hcv = u.acc_hc[k];
-                    haplo_flow_setup(hw, &hb, &hcv, ap & 15, ap >> 4, su.x, su.y, u.ratio[k], u.children[r], u.descendants[r], sc,
-                                     &h);
-                    u.acc_hb[k] = hb;
-                    u.acc_hc[k] = hcv;
-                    flow_begin(&run.f, grad, hw, h.epsilon, sc.scalefactor, false);
-                    run.phase = 0;
-                    st = haplo_slope(h);
-                    n_flows++;
-                    if (run.f.pinned) {
-                        while (flow_advance(&run.f, grad, sc.scalefactor)) {}
-                        u.hw[row_i] = flow_end(run.f, sc.scalefactor, &hits, false);
-                        n_pinned++;
-                    } else {
-                        have = true;
-                    }
-                }
+                haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+                flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+                flow_replay(&f, e.path, (int)(e.item_steps & 63));
+                st = haplo_slope(h);
+                have = true;
             }
             continue;
         }
         if (busy == 0) break;
         n_rounds++;
         if (have) {
-            double v;
-            if (flow_want(&run, sc.scalefactor, &v)) {
-                n_evals++;
-                flow_feed(&run, grad(v), sc.scalefactor, bound);
-            } else {
-                u.hw[row_i] = flow_end(run.f, sc.scalefactor, &hits, false);
+            n_steps++;
+            if (!flow_advance(&f, grad, sc.scalefactor, bound)) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 have = false;
-                n_quads += run.f.quads;
-                n_why1 += run.f.why == 1;
-                n_why2 += run.f.why == 2;
-                n_why3 += run.f.why == 3;
+                n_quads += f.quads;
+                n_why1 += f.why == 1;
             }
         }
     }
     if (hits) atomicAdd(u.hits, hits);
-    flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, n_evals, n_rounds, n_pinned);
-    flow_stats(u.stats ? u.stats + 12 : nullptr, n_quads, n_why1, n_why2, n_why3);
+    flow_stats(u.stats ? u.stats + 12 : nullptr, n_steps, n_rounds, n_quads, n_why1);
 }
 
 void launch_update_pass(const UpdateParams& u, hipStream_t stream)
@@ -2522,21 +2662,37 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     const size_t n1 = (size_t)u.n_rec * len;
     const int    n2 = u.n_rec * (u.chrom + 1);
     const size_t n3 = (size_t)u.n_rec * u.chromstarts_host_upto;
-    if (!u.flow_next) {                                       // CNF2_UPDATE_PLAIN: one thread per element
+    if (!u.flow_next) {                                       // CNF2_UPDATE_PLAIN: one thread per element, the literal steps
         hipLaunchKernelGGL(certainty_update_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u);
         hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
         hipLaunchKernelGGL(haploweight_update_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream, u);
         return;
     }
     const size_t resident = (size_t)256 * 16;                 // wavefronts the chip holds at 4 per SIMD
-    (void)hipMemsetAsync(u.flow_next, 0, 26 * sizeof(unsigned long long), stream);    // 2 counters + 24 statistics
-    const size_t w1 = (n1 * 4 + 63) / 64, w3 = (n3 + 63) / 64;
-    hipLaunchKernelGGL(certainty_flow_kernel, dim3((unsigned)(w1 < resident ? w1 : resident)), dim3(64), 0, stream, u,
-                       u.flow_next, u.flow_out);
+    // counters: [0] finish kernel's next slot, [1] flows set aside; then 24 statistics.  The scouts run in chunks of
+    // todo_cap flows so that the list of flows set aside stays bounded.
+    (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
+    const size_t cap = u.todo_cap;
+    for (size_t i0 = 0; i0 < n1 * 4; i0 += cap) {
+        const size_t n = n1 * 4 - i0 < cap ? n1 * 4 - i0 : cap;
+        (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+        hipLaunchKernelGGL(certainty_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                           (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
+        const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                           (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+    }
     hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
     hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
-    hipLaunchKernelGGL(haploweight_flow_kernel, dim3((unsigned)(w3 < resident ? w3 : resident)), dim3(64), 0, stream, u,
-                       u.flow_next + 1);
+    for (size_t i0 = 0; i0 < n3; i0 += cap) {
+        const size_t n = n3 - i0 < cap ? n3 - i0 : cap;
+        (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+        hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                           (unsigned long long)n, (HaploTodo*)u.todo);
+        const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                           (const HaploTodo*)u.todo, (unsigned long long)n);
+    }
 }
 
 // =====================================================================================

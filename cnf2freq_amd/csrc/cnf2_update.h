@@ -21,9 +21,21 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define CNF2_UHD __host__ __device__ inline
+// forced: a call inside the flow kernels' loops costs a register save / restore through scratch memory
+#define CNF2_UHD __host__ __device__ __forceinline__
+#define CNF2_LI __attribute__((always_inline))     /* on a lambda: its call operator is inlined as well */
 #else
+#define CNF2_LI
 #define CNF2_UHD inline
+#endif
+
+// Floating-point contraction: the device compiler's default fuses multiply-adds ACROSS statements, differently in every
+// context a function is inlined into, so the same gradient evaluated in two kernels could differ in its last bit -- and
+// where a gradient is rounding noise (oracle/pyiter.py: "ill-conditioned elements") that decides the result.  Within this
+// header a multiply-add is fused where the source writes it as one expression, nowhere else: every kernel that inlines
+// these functions computes the same bits (restored to the default at the end of the file).
+#if defined(__clang__)
+#pragma clang fp contract(on)
 #endif
 
 namespace cnf2 {
@@ -96,13 +108,13 @@ CNF2_UHD double gauss15(F&& f, double a, double b)
     return half * acc;
 }
 
-// the same rule on a constant integrand c, in the same order of operations (see FlowState::pinned)
-CNF2_UHD double gauss15_const(double c, double a, double b)
+// the same rule on a constant integrand c, in the same order of operations (see FlowState::pinned): the sum does not
+// depend on the interval, so a pinned flow forms it once
+CNF2_UHD double gauss15_const_sum(double c)
 {
-    const double half = (b - a) * 0.5;
     double acc = c * gl15_weight(0);
     for (int i = 1; i < 8; i++) acc += (c + c) * gl15_weight(i);
-    return half * acc;
+    return acc;
 }
 
 // ------------------------------------------------------------------ cap on one iteration's move
@@ -141,7 +153,9 @@ CNF2_UHD double cap_step(double intended, double orig, double epsilon, int* hits
 struct FlowState {
     double orig, epsilon, lolim, hilim, lo, hi;
     double g0;            // dt/dp at the (clamped) starting point
+    double csum;          // pinned: the quadrature rule's sum on the constant g0
     double mid, qa, qb;   // the step in flight: its midpoint, and the interval of its quadrature (flow_try -> flow_quadrature)
+    unsigned long long path;   // the decisions so far, oldest in the highest used bit: 1 = the lower end moved up to the midpoint
     int    it;            // steps taken so far
     int    quads;         // steps that needed the quadrature (diagnostics)
     int    spared;        // steps whose quadrature the bound made unnecessary (diagnostics)
@@ -175,12 +189,14 @@ CNF2_UHD void flow_begin(FlowState* f, G&& rgradient, double orig, double epsilo
     if (f->falling) f->hi = f->orig;
     else f->lo = f->orig;
     f->it = 0;
+    f->path = 0;
     f->quads = 0;
     f->spared = 0;
     f->why = 0;
     f->live = scalefactor != 0;
     f->g0 = g0;
     f->pinned = isfinite(g0) && (f->falling ? f->orig <= epsilon : f->orig >= top);
+    f->csum = f->pinned ? gauss15_const_sum(g0) : 0.0;
 }
 // no bound on the quadrature's value: every same-sign step runs it
 struct NoTimeBound {
@@ -200,9 +216,23 @@ CNF2_UHD int flow_decide(FlowState* f, double t, double scalefactor)
         f->live = false;
         return 0;
     }
-    if ((t < scalefactor) != f->falling) f->lo = f->mid;
+    const bool up = (t < scalefactor) != f->falling;
+    if (up) f->lo = f->mid;
     else f->hi = f->mid;
+    f->path = (f->path << 1) | (up ? 1ull : 0ull);
     return 1;
+}
+// the bracket after `steps` completed steps with the decisions `path` (flow_decide), from a freshly begun flow: how a flow
+// that was set aside is taken up again without its state having been stored
+CNF2_UHD void flow_replay(FlowState* f, unsigned long long path, int steps)
+{
+    for (int k = steps - 1; k >= 0; k--) {
+        const double mid = (f->lo + f->hi) / 2;
+        if ((path >> k) & 1ull) f->lo = mid;
+        else f->hi = mid;
+    }
+    f->it = steps;
+    f->path = path;
 }
 template <class G, class B = NoTimeBound>
 CNF2_UHD int flow_try(FlowState* f, G&& rgradient, double scalefactor, B&& bound = B())
@@ -238,7 +268,7 @@ CNF2_UHD int flow_try(FlowState* f, G&& rgradient, double scalefactor, B&& bound
     }
     if (f->pinned) {
         f->quads++;
-        double t = gauss15_const(f->g0, a, b);
+        double t = ((b - a) * 0.5) * f->csum;
         if (b != mid) t = -t;
         if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
         return flow_decide(f, t, scalefactor);
@@ -252,7 +282,7 @@ CNF2_UHD int flow_quadrature(FlowState* f, G&& rgradient, double scalefactor)
 {
     f->quads++;
     const double eps = f->epsilon;
-    double       t = gauss15([&](double v) { return flow_pace(rgradient, v, eps); }, f->qa, f->qb);
+    double       t = gauss15([&](double v) CNF2_LI { return flow_pace(rgradient, v, eps); }, f->qa, f->qb);
     if (f->qb != f->mid) t = -t;
     if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
     return flow_decide(f, t, scalefactor);
@@ -440,8 +470,8 @@ CNF2_UHD double evidence_slope(double y, double g, double h, double x)
     return evidence_slope(evidence_terms(y, g, h), x, logit(x));
 }
 
-// ------------------------------------------------------------------ a bound that spares most quadratures
-// Both gradients have the form  G(x) = D(x) - e L(x) + d W(x) + const,  D the data term above, L = logit,
+// ------------------------------------------------------------------ bounds that spare most quadratures
+// Both gradients have the form  G(x) = D(x) - e L(x) + d W(x) + c0,  D the data term above, L = logit,
 // W(x) = (pr - x) / (x (1 - x)) the phase-consistency term (d = 0 for the certainties), e, d >= 0.  With u = x (1 - x):
 //     -G'(x) = e / u - a b / (u Q^2) + (a - b)^2 / Q^2 + 2 a b (a - b) L / Q^3 + d ((x - pr)^2 + pr (1 - pr)) / u^2 .
 // In the steady state of a run most values sit next to a root x* of G that attracts them (near 0 or 1 the entropy term
@@ -451,51 +481,92 @@ CNF2_UHD double evidence_slope(double y, double g, double h, double x)
 // it (interval arithmetic on the expression above: u is concave, Q linear, L monotone), G is strictly monotone there,
 // has no root inside, and |G(x)| >= |G(mid)| + s1 |mid - x| =: l(x).  The rule has positive weights and, for the
 // reciprocal of a linear function, never exceeds the integral (its error term has the sign of the 30th derivative), so
-//     t = |rule[1 / G]| <= rule[1 / l] <= integral of 1 / l = log(1 + s1 |mid - orig| / |G(mid)|) / s1 .
-// When that is under the tolerance band the decision of the step is known -- identical to the literal one, not an
-// approximation of it -- for well under a hundred instructions instead of 1 300.  No bound (s1 <= 0, the interval touching
-// the clamp, a NaN anywhere): the quadrature runs as before.
+//     t = |rule[1 / G]| <= rule[1 / l] <= integral of 1 / l = log(1 + s1 |mid - orig| / |G(mid)|) / s1 ,
+// and because the node nearest to mid keeps 0.6 % of the interval's length away from it, even G(mid) = 0 gives
+//     t <= rule[1 / (s1 |mid - x|)] = C15 / s1,   C15 = sum of w_i / (1 - z_i) = 6.636...
+// When one of the two is under the tolerance band the decision of the step is known -- identical to the literal one,
+// not an approximation of it -- for well under a hundred instructions instead of 1 300.  No bound (s1 <= 0, the
+// interval touching the clamp, a NaN anywhere): the quadrature runs as before.
+// Rounding: a computed gradient value is its true value up to `noise` (1e-14 times the magnitude of its terms, bounded
+// over the interval like the slope); a value only counts where it stands clear of that, and the nodes of a rule must.
 struct SlopeTerms {
     Evidence ev;
     double   e;        // coefficient of -logit: entropyfactor (certainties), (1 - similarity) entropyfactor (weights)
     double   d, pr;    // descendants and phase ratio of the weights' third term; d = 0: none
+    double   c0;       // constant term: entropyfactor x prior (certainties)
 };
-// Is the time the rule reports over [xa, xb] certainly under `limit`?  (one end of the interval is the flow's start, the
-// other the midpoint, where |1 / G| = pace; xa < xb, both inside the clamp.)  false = not known.
-// The test is log(1 + z) < limit s1 with z = s1 (xb - xa) pace; log(1 + z) <= z settles most cases without a logarithm,
-// and for limit s1 >= 44 any z below 1e19 does.
-CNF2_UHD bool flow_time_under(const SlopeTerms& s, double xa, double xb, double pace, double limit)
+#define CNF2_GL15_C 6.636457986458086      /* sum of w_i / (1 - z_i) over the 15 nodes */
+struct IntervalFacts {
+    double s1;         // lower bound of -G' on the interval; <= 0 or NaN: none
+    double noise;      // bound of the rounding error of a computed G on the interval
+};
+// fine: the bound of |logit| is a logarithm (once per flow); else 1 / min(x, 1 - x) (per step: crude, but the terms it
+// enters are small where the bounds matter)
+CNF2_UHD IntervalFacts flow_interval(const SlopeTerms& s, double xa, double xb, bool fine)
 {
+    IntervalFacts F;
+    F.s1 = 0.0;
+    F.noise = HUGE_VAL;
     const double ua = xa * (1.0 - xa), ub = xb * (1.0 - xb);
     const double ulo = ua < ub ? ua : ub;
     const double uhi = (xa <= 0.5 && 0.5 <= xb) ? 0.25 : (ua < ub ? ub : ua);
     const double qa = s.ev.b * (1.0 - xa) + s.ev.a * xa, qb = s.ev.b * (1.0 - xb) + s.ev.a * xb;
     const double qlo = qa < qb ? qa : qb, qhi = qa < qb ? qb : qa;
-    if (!(ulo > 0.0) || !(qlo > 0.0) || !(s.e >= 0.0) || !(s.d >= 0.0)) return false;
-    // |logit(x)| <= 1 / min(x, 1 - x) on the interval: crude, but the term it bounds is small where the bound matters
+    if (!(ulo > 0.0) || !(qlo > 0.0) || !(s.e >= 0.0) || !(s.d >= 0.0)) return F;
     const double edge = xa < 1.0 - xb ? xa : 1.0 - xb;
+    // |logit(x)| <= -log(min(x, 1 - x)) <= 1 / min(x, 1 - x); and -log(m 2^k) <= -k log 2 for a mantissa m in [1, 2)
+    double lmax;
+    if (fine) {
+        int k;
+        (void)frexp(edge, &k);                               // edge = m' 2^k with m' in [1/2, 1): edge >= 2^(k - 1)
+        lmax = (double)(1 - k) * 0.69314718055994530942;
+    } else {
+        lmax = upd_div(1.0, edge);
+    }
     const double amb = s.ev.amb < 0 ? -s.ev.amb : s.ev.amb;
-    const double r_uhi = upd_div(1.0, uhi), r_qlo = upd_div(1.0, qlo), r_qhi = upd_div(1.0, qhi);
-    // -G' >= e / uhi - (a b / ulo + 2 a b |a - b| / (edge qlo)) / qlo^2 + (a - b)^2 / qhi^2 + d num / uhi^2
-    double s1 = s.e * r_uhi - s.ev.ab * (upd_div(1.0, ulo) + 2.0 * amb * r_qlo * upd_div(1.0, edge)) * (r_qlo * r_qlo) +
-                (s.ev.amb * r_qhi) * (s.ev.amb * r_qhi);
+    const double r_uhi = upd_div(1.0, uhi), r_ulo = upd_div(1.0, ulo), r_qlo = upd_div(1.0, qlo), r_qhi = upd_div(1.0, qhi);
+    // -G' >= e / uhi - (a b / ulo + 2 a b |a - b| lmax / qlo) / qlo^2 + (a - b)^2 / qhi^2 + d num / uhi^2
+    double s1 = s.e * r_uhi - s.ev.ab * (r_ulo + 2.0 * amb * r_qlo * lmax) * (r_qlo * r_qlo) + (s.ev.amb * r_qhi) * (s.ev.amb * r_qhi);
+    double mag = (s.ev.ab * lmax + amb * qhi) * (r_qlo * r_qlo) + s.e * lmax + fabs(s.c0);
     if (s.d != 0.0) {
         const double dist = s.pr < xa ? xa - s.pr : (s.pr > xb ? s.pr - xb : 0.0);
         const double num = dist * dist + s.pr * (1.0 - s.pr);      // >= 0 for a ratio in [0, 1]
-        s1 += s.d * (num >= 0.0 ? num * (r_uhi * r_uhi) : num * upd_div(1.0, ulo * ulo));
+        s1 += s.d * (num >= 0.0 ? num * (r_uhi * r_uhi) : num * (r_ulo * r_ulo));
+        const double fa = fabs(s.pr - xa), fb = fabs(s.pr - xb);
+        mag += s.d * (fa > fb ? fa : fb) * r_ulo;
     }
-    s1 *= 1.0 - 1e-9;                                        // the bound itself is rounded
-    if (!(s1 > 0.0) || !(pace > 0.0)) return false;
-    const double z = s1 * (xb - xa) * pace, ls = limit * s1;
+    F.s1 = s1 * (1.0 - 1e-9);                               // the bound itself is rounded
+    F.noise = 1e-14 * mag;
+    return F;
+}
+// Is what the rule reports over [xa, xb] certainly under `limit`?  One end of the interval is the flow's start, the other
+// the midpoint, where the COMPUTED reciprocal gradient is pace (same sign as at the start); xa < xb, both inside the
+// clamp.  false = not known.
+CNF2_UHD bool flow_under(const IntervalFacts& F, double width, double pace, double limit)
+{
+    if (!(F.s1 > 0.0) || !(F.noise < HUGE_VAL)) return false;
+    // the true root may lie before the midpoint by the noise; the nodes must be clear of it
+    if (!(0.006 * width * F.s1 > 8.0 * F.noise)) return false;
+    const double ls = limit * F.s1;
+    if (ls > 1.02 * CNF2_GL15_C) return true;                // the rule cannot report more than C15 / s1
+    const double g = upd_div(1.0, pace);                     // |G(mid)| as computed
+    if (!(g > 4.0 * F.noise)) return false;
+    const double z = F.s1 * width * upd_div(1.0, g - 2.0 * F.noise);
     if (z < ls) return true;                                 // log(1 + z) <= z
-    if (ls >= 44.0 && z < 1e19) return true;                 // log(1 + 1e19) < 44
+#if defined(__HIP_DEVICE_COMPILE__)
+    return false;                                            // the logarithm costs the device more than the quadratures it would spare
+#else
     if (!(z < 1e300)) return false;
     return log1p(z) < ls;
+#endif
 }
-// the bound itself (tests): log(1 + s1 (xb - xa) pace) / s1 as an upper bound of the rule's value, +infinity when there is none
+CNF2_UHD bool flow_time_under(const SlopeTerms& s, double xa, double xb, double pace, double limit)
+{
+    return flow_under(flow_interval(s, xa, xb, false), xb - xa, pace, limit);
+}
+// the bound itself (tests): the smallest limit flow_time_under accepts, +infinity when there is none
 CNF2_UHD double flow_time_bound(const SlopeTerms& s, double xa, double xb, double pace)
 {
-    // bisect on the limit: flow_time_under is monotone in it
     if (!flow_time_under(s, xa, xb, pace, 1e300)) return HUGE_VAL;
     double lo = 0.0, hi = 1.0;
     while (!flow_time_under(s, xa, xb, pace, hi) && hi < 1e300) hi *= 2.0;
@@ -505,6 +576,162 @@ CNF2_UHD double flow_time_bound(const SlopeTerms& s, double xa, double xb, doubl
         else lo = mid;
     }
     return hi;
+}
+
+// ------------------------------------------------------------------ the scout: steps without quadratures, cheaply
+// Most flows of a run in its steady state never need a quadrature: they close in on a root of their gradient (or find it
+// within 1e-10 of their start), and every step is settled by a sign or by the bounds above.  Settled that way a flow
+// still pays one gradient evaluation per step, up to 51 of them, to locate the root by bisection.  Where the gradient has
+// been shown strictly monotone on the whole bracket (flow_interval over [lo, hi] and the start), every evaluation is a
+// fact about ONE root: a point whose value has the start's sign -- by more than the rounding noise -- has the root
+// beyond it, and so has every point before it; a point with the other sign has it before.  The scout keeps the two
+// innermost such points and answers a midpoint's sign from them when it can; between them it closes in on the root
+// superlinearly (false position with the Illinois modification; each of its evaluations is a fact of the same kind),
+// so that the bisection's own midpoints need an evaluation only in the last few steps, inside the band where computed
+// signs are noise and only the evaluation itself says what the literal algorithm sees.  The step sequence, and with it
+// the result, is the literal one; what changes is how much of it is computed.
+// flow_scout runs a begun flow until it ends (returns 0) or a step needs a quadrature (returns 2: the steps completed
+// and their decisions are in f->it and f->path; flow_replay + flow_advance take it from there).
+// Written for wavefronts that run 64 scouts in lock step (all start at step 0): what costs instructions -- the attempt
+// to show the gradient monotone, the closing in on the root -- happens at fixed step numbers, the same for every lane,
+// and a same-sign step that the constant bound C15 / s1 does not settle ends the scout (the finish pass has the finer
+// bound and the quadrature).
+template <class G>
+CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations)
+{
+    const double eps = f->epsilon, top = 1.0 - f->epsilon;
+    const double limit = scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9);
+    IntervalFacts B;                   // facts about the bracket once the gradient is known to be monotone on it
+    B.s1 = 0.0;
+    B.noise = HUGE_VAL;
+    bool          mono = false, refined = false, settles = false;
+    double        zmax = 0.0;                       // exp(limit s1) - 1
+    double        near_d = 0.0, far_d = HUGE_VAL;   // distance from the start of the farthest point solidly on its side of the root, of the nearest solidly beyond
+    double        near_g = 0.0, far_g = 0.0;        // computed gradients there (near_g at distance 0: the start's, when solid)
+    int           evals = 0;
+    const double  dir = f->falling ? -1.0 : 1.0;    // the flow moves towards orig + dir d
+    auto too_far = [&](double gm) CNF2_LI { return ((gm < 0) != f->falling) || !isfinite(gm); };    // the literal test of a step
+    auto note = [&](double d, double gm) CNF2_LI {  // an evaluation at distance d > 0 is a fact about the root, if it is solid
+        const double g = 1.0 / gm;
+        const bool   solid = isfinite(gm) && gm != 0.0 && fabs(g) > 2.0 * B.noise;
+        const bool   beyond = too_far(gm);
+        const bool   new_far = solid && beyond && d < far_d, new_near = solid && !beyond && d > near_d;
+        far_d = new_far ? d : far_d;
+        far_g = new_far ? g : far_g;
+        near_d = new_near ? d : near_d;
+        near_g = new_near ? g : near_g;
+    };
+    for (int step = 0;; step++) {
+        *evaluations = evals;
+        if (!f->live) return 0;
+        if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) {
+            f->why = 3;
+            f->live = false;
+            return 0;
+        }
+        // is the gradient monotone on the bracket (and on the way from the start)?  Tried while the bracket shrinks.
+        if (step == 0 || step == 1 || step == 2 || step == 4 || step == 7 || step == 11 || step == 16) {
+            if (!mono && f->lo >= eps && f->hi <= top) {
+                const double xa = f->lo < f->orig ? f->lo : f->orig, xb = f->hi > f->orig ? f->hi : f->orig;
+                B = flow_interval(st, xa, xb, true);
+                if (B.s1 > 0.0 && B.noise < HUGE_VAL) {
+                    mono = true;
+                    settles = limit * B.s1 > 1.02 * CNF2_GL15_C;       // the rule cannot report more than C15 / s1
+                    const double ls = limit * B.s1;
+                    zmax = (ls < 700.0 ? exp(ls) : 1e300) - 1.0;
+                    const double g_start = 1.0 / f->g0;
+                    if (fabs(g_start) > 2.0 * B.noise) near_g = g_start;       // the start itself (distance 0) is a solid point
+                }
+            }
+        }
+        // the root is bracketed by two solid facts: close in on it (false position, Illinois), each evaluation one more
+        if ((step == 3 || step == 6 || step == 10 || step == 15 || step == 21) && mono && !refined && far_d < HUGE_VAL &&
+            near_g != 0.0) {
+            refined = true;
+            double dn = near_d, df = far_d, fn = near_g, ff = far_g;
+            int    side = 0;
+            for (int k = 0; k < 16; k++) {
+                double dp = (dn * ff - df * fn) / (ff - fn);
+                if (!(dp > dn && dp < df)) dp = 0.5 * (dn + df);
+                const double xp = f->orig + dir * dp;
+                const double dd = (xp - f->orig) * dir;              // the distance as the steps will measure it
+                if (!(xp >= eps && xp <= top) || !(dd > dn && dd < df)) break;
+                const double gp = flow_pace(rgradient, xp, eps);
+                evals++;
+                if (!isfinite(gp) || gp == 0.0 || !(fabs(1.0 / gp) > 2.0 * B.noise)) break;    // inside the noise band: as close as facts get
+                note(dd, gp);
+                if (too_far(gp)) {
+                    df = dd;
+                    ff = 1.0 / gp;
+                    if (side == 1) fn *= 0.5;
+                    side = 1;
+                } else {
+                    dn = dd;
+                    fn = 1.0 / gp;
+                    if (side == -1) ff *= 0.5;
+                    side = -1;
+                }
+            }
+        }
+        f->it++;
+        const double mid = (f->lo + f->hi) / 2;
+        f->mid = mid;
+        const double d = (mid - f->orig) * dir;
+        bool   far, have_gm = false;
+        double gm = 0.0;
+        if (mono && d > 0.0 && d >= far_d) far = true;
+        else if (mono && d > 0.0 && d <= near_d) far = false;
+        else {
+            gm = flow_pace(rgradient, mid, eps);
+            evals++;
+            have_gm = true;
+            far = too_far(gm);
+            if (mono && d > 0.0) note(d, gm);
+        }
+        if (far) {
+            flow_decide(f, (scalefactor + 0.1) * 1.1, scalefactor);
+            continue;
+        }
+        double a = f->orig, b = mid;
+        if (a > b) {
+            const double t = a;
+            a = b;
+            b = t;
+        }
+        if (b - a < 1e-10) {
+            f->why = 2;
+            f->live = false;
+            *evaluations = evals;
+            return 0;
+        }
+        // "not there yet" from the slope bound of the whole bracket (the nodes of the rule must be clear of the noise):
+        // the constant form C15 / s1 where that is under the band; else log(1 + s1 d / |G(mid)|) / s1 < limit, i.e.
+        // s1 d / |G(mid)| < exp(limit s1) - 1 =: zmax, with |G(mid)| >= |G| at the farthest same-sign point known
+        // (the midpoint lies before it and |G| falls towards the root), or with the midpoint's own value
+        bool spared = false;
+        if (mono && a >= eps && b <= top && 0.006 * (b - a) * B.s1 > 8.0 * B.noise) {
+            spared = settles;
+            if (!spared && d <= near_d && fabs(near_g) > 4.0 * B.noise)
+                spared = B.s1 * d < zmax * (fabs(near_g) - 2.0 * B.noise);
+            if (!spared) {
+                if (!have_gm) {
+                    gm = flow_pace(rgradient, mid, eps);
+                    evals++;
+                    have_gm = true;
+                    note(d, gm);
+                }
+                const double g = fabs(1.0 / gm);
+                if (!too_far(gm) && g > 4.0 * B.noise) spared = B.s1 * d < zmax * (g - 2.0 * B.noise);
+            }
+        }
+        if (!spared) {
+            f->it--;                   // this step is for the finish pass: hand the flow over as it stood before it
+            *evaluations = evals;
+            return 2;
+        }
+        f->spared++;
+        flow_decide(f, 0.0, scalefactor);
+    }
 }
 
 // ------------------------------------------------------------------ genotype certainties (processinfprobs)
@@ -561,6 +788,7 @@ CNF2_UHD SlopeTerms certainty_slope(const CertaintyFlow& c)
     s.e = c.ef;
     s.d = 0.0;
     s.pr = 0.0;
+    s.c0 = c.ef * c.priord;
     return s;
 }
 CNF2_UHD double certainty_rgradient(const CertaintyFlow& c, double x)
@@ -590,16 +818,20 @@ CNF2_UHD bool certainty_pick(const double inf[2], const double out[2], int side,
     }
     return false;
 }
+// literal: every same-sign step runs its quadrature, as the reference's cappedgd does (the yardstick of the other forms)
 CNF2_UHD bool update_certainty(const double inf[2], const SideState& s, int side, bool empty, bool has_prior,
-                               int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure)
+                               int children, const StepControl& sc, int* hits, int* new_allele, double* new_sure,
+                               bool literal = false)
 {
     double out[2] = {0, 0};
     for (int v = 0; v < 2; v++) {
         CertaintyFlow c;
         if (!certainty_flow_setup(inf, v, s, children, sc, &c)) continue;
         const SlopeTerms st = certainty_slope(c);
-        out[v] = flow_step([&](double x) { return certainty_rgradient(c, x); }, c.curprob, c.epsilon, sc.scalefactor, hits,
-                           false, [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); });
+        out[v] = flow_step([&](double x) CNF2_LI { return certainty_rgradient(c, x); }, c.curprob, c.epsilon, sc.scalefactor, hits,
+                           false, [&](double xa, double xb, double pc, double lim) CNF2_LI {
+                               return !literal && flow_time_under(st, xa, xb, pc, lim);
+                           });
     }
     return certainty_pick(inf, out, side, empty, has_prior, new_allele, new_sure);
 }
@@ -657,14 +889,17 @@ struct HaploFlow {
     double   ent, phaseratio, descendants;
     double   epsilon;
 };
-// rewrites haplobase / haplocount (cnF2freq.cpp:4660-4677) and forms the gradient's data
-CNF2_UHD void haplo_flow_setup(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0, double sure1,
-                               double phaseratio, int children, int descendants, const StepControl& sc, HaploFlow* h)
+// similarity of the two sides of a genotype (cnF2freq.cpp:4643-4658) and the rewrite of haplobase / haplocount with it
+// (cnF2freq.cpp:4660-4677); returns the similarity the entropy term uses
+CNF2_UHD double haplo_similarity(int a0, int a1, double sure0, double sure1)
 {
     const double scorea = 1.0 - sure0;
     double       scoreb = 1.0 - sure1;
     if (a0 != a1) scoreb = 1 - scoreb;
-    double similarity = scorea * scoreb + (1 - scorea) * (1 - scoreb);
+    return scorea * scoreb + (1 - scorea) * (1 - scoreb);
+}
+CNF2_UHD double haplo_rewrite(double hw, double* haplobase, double* haplocount, double similarity)
+{
     if (!*haplocount || similarity == 1.0) {
         *haplocount = (*haplocount < 1.0) ? 1.0 : *haplocount;
         *haplobase  = hw * *haplocount;
@@ -678,11 +913,23 @@ CNF2_UHD void haplo_flow_setup(double hw, double* haplobase, double* haplocount,
         if (*haplobase < 0) *haplobase = 0;
         if (*haplobase >= *haplocount) *haplobase = *haplocount;
     }
-    h->ev = evidence_terms(hw, *haplobase, *haplocount);
+    return similarity;
+}
+// the gradient's data from the REWRITTEN haplobase / haplocount and the similarity haplo_rewrite returned
+CNF2_UHD void haplo_flow_terms(double hw, double haplobase, double haplocount, double similarity, double phaseratio,
+                               int children, int descendants, const StepControl& sc, HaploFlow* h)
+{
+    h->ev = evidence_terms(hw, haplobase, haplocount);
     h->ent = (1 - similarity) * sc.entropyfactor;
     h->phaseratio = phaseratio;
     h->descendants = descendants;
     h->epsilon = clamp_distance(children);
+}
+CNF2_UHD void haplo_flow_setup(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0, double sure1,
+                               double phaseratio, int children, int descendants, const StepControl& sc, HaploFlow* h)
+{
+    const double similarity = haplo_rewrite(hw, haplobase, haplocount, haplo_similarity(a0, a1, sure0, sure1));
+    haplo_flow_terms(hw, *haplobase, *haplocount, similarity, phaseratio, children, descendants, sc, h);
 }
 CNF2_UHD SlopeTerms haplo_slope(const HaploFlow& h)
 {
@@ -691,6 +938,7 @@ CNF2_UHD SlopeTerms haplo_slope(const HaploFlow& h)
     s.e = h.ent;
     s.d = h.descendants;
     s.pr = h.phaseratio;
+    s.c0 = 0.0;
     return s;
 }
 // gradient = data + phase consistency + entropy = (N + Q^2 E) / Q^2; its reciprocal as one quotient
@@ -703,13 +951,15 @@ CNF2_UHD double haplo_rgradient(const HaploFlow& h, double x)
 }
 CNF2_UHD double update_haploweight(double hw, double* haplobase, double* haplocount, int a0, int a1, double sure0,
                                    double sure1, double phaseratio, int children, int descendants,
-                                   const StepControl& sc, bool breakathalf, int* hits)
+                                   const StepControl& sc, bool breakathalf, int* hits, bool literal = false)
 {
     HaploFlow h;
     haplo_flow_setup(hw, haplobase, haplocount, a0, a1, sure0, sure1, phaseratio, children, descendants, sc, &h);
     const SlopeTerms st = haplo_slope(h);
-    return flow_step([&](double x) { return haplo_rgradient(h, x); }, hw, h.epsilon, sc.scalefactor, hits, breakathalf,
-                     [&](double xa, double xb, double pc, double lim) { return flow_time_under(st, xa, xb, pc, lim); });
+    return flow_step([&](double x) CNF2_LI { return haplo_rgradient(h, x); }, hw, h.epsilon, sc.scalefactor, hits, breakathalf,
+                     [&](double xa, double xb, double pc, double lim) CNF2_LI {
+                         return !literal && flow_time_under(st, xa, xb, pc, lim);
+                     });
 }
 
 // Step-size control after an update pass (cnF2freq.cpp:6373-6392; `any` is false without the inversion machinery).
@@ -731,4 +981,7 @@ CNF2_UHD void adapt_scalefactor(StepControl* sc, StepHistory* h, int hits, int n
 }
 
 } // namespace cnf2
+#if defined(__clang__) && defined(__HIPCC__)
+#pragma clang fp contract(fast)
+#endif
 #endif

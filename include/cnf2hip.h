@@ -73,9 +73,10 @@ enum {
                                     windows with tie groups always take) instead of the tile form; A/B and cross-check */
     CNF2_TIES_GENERAL = 1u << 12, /* cnf2_sweep, cnf2_sweep_accumulate, cnf2_sweep_turn_scan: windows with tie groups through the general kernel (one lane per table entry, producer
                                     per marker) instead of the tile-producer kernel's pass per tie combination; cross-check */
-    CNF2_UPDATE_PLAIN = 1u << 13, /* cnf2_update_pass: one thread per (record, marker) instead of the persistent flow kernels
-                                    (a wavefront steps 64 independent flows and refills lanes as flows end); same arithmetic,
-                                    same results -- cross-check and A/B */
+    CNF2_UPDATE_PLAIN = 1u << 13, /* cnf2_update_pass: the literal form -- one thread per (record, marker), every bisection step with its
+                                    quadrature as the reference's cappedgd runs it -- instead of the scout / finish kernels, which
+                                    make the same decisions with a fraction of the gradient evaluations (cnf2_update.h).  Same
+                                    results to the bit: the yardstick of the fast form, and an A/B switch */
     CNF2_DETERMINISTIC = 1u << 14, /* cnf2_sweep_accumulate: every analysed individual writes what its window members receive at a
                                     locus into a row of its own (336 B per individual x marker, allocated for the whole
                                     range) and one more kernel adds the rows of every record in ascending order of the
@@ -266,12 +267,11 @@ int cnf2_update_pass(cnf2_ctx *ctx, int chrom, const int32_t *children, const in
                      double *haplobase, double *haplocount, double scalefactor, double entropyfactor, int *hits_out,
                      uint32_t flags);
 int cnf2_download_rows(cnf2_ctx *ctx, int row0, int n, uint8_t *allele, double *sure, double *hw);
-/* Diagnostics of the last cnf2_update_pass (flow kernels).  out16[0..3] for the genotype certainties, out16[4..7] for the
- * haplotype weights: flows run; gradient evaluations of the flows that are not pinned; lane slots offered to them (every
- * round of a wavefront offers 64: evaluations / slots = lane utilisation); pinned flows (values that sit on their clamp and
- * are pushed further out: no gradient evaluation beyond the first, see cnf2_update.h).  out16[8..11] / out16[12..15] for the
- * same two kernels: quadratures run (15 evaluations each; the bound of flow_time_under spares the others), and how many
- * flows ended because the tolerance was met / the interval fell under 1e-10 / the 51 steps were used up or the bounds left. */
+/* Diagnostics of the last cnf2_update_pass (flow kernels; see cnf2_kernels.hip).  out16[0..3] for the genotype
+ * certainties, out16[4..7] for the haplotype weights: flows; gradient evaluations the scout spent on them; flows that ended
+ * in the scout; flows pinned to their clamp (no evaluation beyond the first).  out16[8..11] / out16[12..15] for the flows the
+ * scout set aside: steps taken in the finish kernel; lane slots offered (steps / slots = lane utilisation); quadratures;
+ * flows that ended because the tolerance was met.  Collected only when the environment holds CNF2_UPDATE_STATS. */
 int cnf2_update_stats(cnf2_ctx *ctx, uint64_t *out16);
 /* The accumulators the context holds (what cnf2_sweep_accumulate left and cnf2_update_pass rewrote when they were called
  * with NULL accumulator pointers): host copies infprobs[n_rec][M][2][2], haplobase / haplocount[n_rec][M]; any pointer may

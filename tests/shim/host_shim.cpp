@@ -465,6 +465,7 @@ void shim_flow(int kind, double y, double g, double h, double e, double c0, doub
     st.e = e;
     st.d = d;
     st.pr = pr;
+    st.c0 = kind == 0 ? e * c0 : 0.0;
     cnf2::CertaintyFlow c;
     c.ev = st.ev;
     c.ef = e;
@@ -478,7 +479,25 @@ void shim_flow(int kind, double y, double g, double h, double e, double c0, doub
     auto bound = [&](double xa, double xb, double pc, double lim) { return screened ? cnf2::flow_time_under(st, xa, xb, pc, lim) : false; };
     cnf2::FlowState f;
     cnf2::flow_begin(&f, grad, y, epsilon, scalefactor, false);
-    if (screened == 2 && !f.pinned) {
+    if (screened == 3 && !f.pinned) {
+        // what the device does: the scout, and where it stops at a quadrature a second pass that begins the flow anew,
+        // replays the scout's decisions and goes on literally (with the bound)
+        int evals = 0;
+        const int rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals);
+        out[5] = evals;
+        out[6] = rc;
+        if (rc == 2) {
+            const unsigned long long path = f.path;
+            const int                steps = f.it, spared = f.spared;
+            cnf2::FlowState g2;
+            cnf2::flow_begin(&g2, grad, y, epsilon, scalefactor, false);
+            cnf2::flow_replay(&g2, path, steps);
+            auto b1 = [&](double xa, double xb, double pc, double lim) { return cnf2::flow_time_under(st, xa, xb, pc, lim); };
+            while (cnf2::flow_advance(&g2, grad, scalefactor, b1)) {}
+            g2.spared += spared;
+            f = g2;
+        }
+    } else if (screened == 2 && !f.pinned) {
         // the one-evaluation-at-a-time machine the kernels run
         cnf2::FlowRun r;
         r.f = f;
@@ -508,6 +527,7 @@ void shim_time_bound(int kind, double y, double g, double h, double e, double c0
     st.e = e;
     st.d = d;
     st.pr = pr;
+    st.c0 = kind == 0 ? e * c0 : 0.0;
     cnf2::CertaintyFlow c;
     c.ev = st.ev;
     c.ef = e;

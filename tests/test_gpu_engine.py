@@ -202,8 +202,10 @@ def test_iterations_follow_the_reference_trajectory(libs, case):
 
 
 def test_flow_kernels_equal_one_thread_per_element(libs):
-    """cnf2_update_pass: the persistent flow kernels (a wavefront steps 64 flows and refills its lanes) against
-    CNF2_UPDATE_PLAIN (one thread per record x marker): the same arithmetic per flow, so the same bits."""
+    """cnf2_update_pass: the scout / finish kernels (root memo, bounds that spare quadratures, flows replayed from their
+    decisions) against CNF2_UPDATE_PLAIN (one thread per record x marker, the literal bisection with every quadrature):
+    the same decisions per flow, so the same bits -- over four rounds of sweep + update passes at a large scale factor,
+    through which the state moves from "everything far from equilibrium" towards the steady state of a run."""
     capi, _ = libs
     ped = synth.make_outbred3(5, 4, 37, 2, seed=8, missing=0.2)
     a, s, h = ped.dense()
@@ -212,26 +214,35 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     ped.row_of = np.arange(1, ped.n_rec + 1, dtype=np.int32)
     rs = np.random.RandomState(2)
     ped.hw[1:] = np.where(rs.rand(*ped.hw[1:].shape) < 0.2, 0.5, 0.05 + 0.9 * rs.rand(*ped.hw[1:].shape))
-    out = {}
-    for name, flags in (("flow", 0), ("plain", capi.UPDATE_PLAIN)):
+    ctxs = {}
+    for name in ("flow", "plain"):
         ctx = capi.Context(0)
         ctx.upload(ped)
         ctx.snapshot_priors((1 - ped.empty).astype(np.uint8))
-        desc = ctx.descendants()
-        children = np.zeros(ped.n_rec, np.int32)
-        for r in ped.dous:
-            for k in range(2):
-                if ped.par[r, k] >= 0:
-                    children[ped.par[r, k]] += 1
-        acc = ctx.sweep_accumulate(desc, deterministic=True)
-        hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
-        out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
+        ctxs[name] = ctx
+    desc = ctxs["flow"].descendants()
+    children = np.zeros(ped.n_rec, np.int32)
+    for r in ped.dous:
+        for k in range(2):
+            if ped.par[r, k] >= 0:
+                children[ped.par[r, k]] += 1
+    total_hits = 0
+    for rnd in range(4):
+        out = {}
+        for name, flags in (("flow", 0), ("plain", capi.UPDATE_PLAIN)):
+            ctx = ctxs[name]
+            acc = ctx.sweep_accumulate(desc, deterministic=True)
+            hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
+            out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
+        assert out["flow"][0] == out["plain"][0], rnd
+        total_hits += sum(out["flow"][0])
+        for x, y in zip(out["flow"][1], out["plain"][1]):
+            assert np.array_equal(x, y), rnd
+        for k in ("infprobs", "haplobase", "haplocount"):
+            assert np.array_equal(out["flow"][2][k], out["plain"][2][k], equal_nan=True), (rnd, k)
+    assert total_hits > 0
+    for ctx in ctxs.values():
         ctx.close()
-    assert out["flow"][0] == out["plain"][0] and sum(out["flow"][0]) > 0
-    for x, y in zip(out["flow"][1], out["plain"][1]):
-        assert np.array_equal(x, y)
-    for k in ("infprobs", "haplobase", "haplocount"):
-        assert np.array_equal(out["flow"][2][k], out["plain"][2][k], equal_nan=True), k
 
 
 def test_deterministic_iterations_are_byte_identical(libs, tmp_path):

@@ -272,14 +272,14 @@ def test_time_bound_is_a_bound(shim):
         assert out[2] > 0, "the gradient is not monotone on an interval the bound accepted"
         assert out[1] <= out[0] * (1 + 1e-9), (kind, y, g, h, e, c0, d, pr, xa, xb, out)
         tight += int(out[1] > 0.2 * out[0])
-    assert finite > 5000 and tight > 500
+    assert finite > 3000 and tight > 300
 
 
 def test_flows_with_the_bound_equal_flows_without(shim):
     """The bound only spares quadratures whose verdict it knows: results and hit counts are identical to the bit."""
     rs = np.random.RandomState(12)
-    a, b, m = np.zeros(4), np.zeros(4), np.zeros(4)
-    spared = quads = 0
+    a, b, m = np.zeros(8), np.zeros(8), np.zeros(8)
+    spared = quads = scout_evals = scout_done = literal_evals = 0
     for _ in range(20000):
         kind, y, g, h, e, c0, d, pr = _random_flow(rs)
         eps = 5e-6 / rs.randint(1, 4)
@@ -289,9 +289,16 @@ def test_flows_with_the_bound_equal_flows_without(shim):
         shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 0, _p(b))
         assert a[0] == b[0] and a[3] == b[3], (kind, y, g, h, e, c0, d, pr, eps, sf, a, b)
         assert a[1] + a[2] == b[1]
-        # the kernels' form of the same steps: one gradient evaluation at a time (FlowRun)
+        # the same steps one gradient evaluation at a time (FlowRun)
         shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 2, _p(m))
-        assert np.array_equal(m, a), (kind, y, g, h, e, c0, d, pr, eps, sf, a, m)
+        assert np.array_equal(m[:5], a[:5]), (kind, y, g, h, e, c0, d, pr, eps, sf, a, m)
+        # the kernels' form: the scout (root memo, one certificate for the spared steps), then replay + literal steps
+        shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, 3, _p(m))
+        assert m[0] == b[0] and m[3] == b[3] and m[4] == b[4], (kind, y, g, h, e, c0, d, pr, eps, sf, b, m)
+        scout_evals += m[5]
+        scout_done += int(m[6] == 0)
+        literal_evals += b[4] + 15 * b[1]
         spared += a[2]
         quads += b[1]
     assert spared > 0.2 * quads
+    assert scout_done > 4000, scout_done

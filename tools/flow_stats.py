@@ -8,6 +8,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if not os.environ.get("CNF2_NO_STATS"):
+    os.environ.setdefault("CNF2_UPDATE_STATS", "1")       # the kernels' diagnostics (a few atomics per wavefront)
 import numpy as np
 import torch  # noqa: F401  (one HIP runtime per process: before libcnf2hip.so)
 
@@ -33,12 +35,11 @@ for it in range(iters):
     run.L.cnf2h_get_state(run.h, None, None, None, None, None, None, C.byref(sf), C.byref(hits))
     c, h = out[:4].astype(float), out[4:8].astype(float)
     cq, hq = out[8:12].astype(float), out[12:16].astype(float)
-    print("it %2d  %.3f s  sf %.4f hits %8d | certainty: %.3g flows, %.0f%% pinned, %.1f evaluations per other flow, lanes %.2f | "
-          "haploweight: %.3g flows, %.0f%% pinned, %.1f evaluations per other flow, lanes %.2f"
-          % (it + 1, dt, sf.value, hits.value, c[0], 100 * c[3] / max(c[0], 1), c[1] / max(c[0] - c[3], 1), c[1] / max(c[2], 1),
-             h[0], 100 * h[3] / max(h[0], 1), h[1] / max(h[0] - h[3], 1), h[1] / max(h[2], 1)), flush=True)
-    print("       certainty: %.2f quadratures per flow; ended by tolerance %.0f%%, by interval < 1e-10 %.0f%%, by 51 steps / bounds %.0f%%"
-          " | haploweight: %.2f; %.0f%% / %.0f%% / %.0f%%"
-          % (cq[0] / max(c[0] - c[3], 1), 100 * cq[1] / max(c[0] - c[3], 1), 100 * cq[2] / max(c[0] - c[3], 1), 100 * cq[3] / max(c[0] - c[3], 1),
-             hq[0] / max(h[0] - h[3], 1), 100 * hq[1] / max(h[0] - h[3], 1), 100 * hq[2] / max(h[0] - h[3], 1), 100 * hq[3] / max(h[0] - h[3], 1)), flush=True)
+    print("it %2d  %.3f s  sf %.4f hits %8d" % (it + 1, dt, sf.value, hits.value), flush=True)
+    for name, a, b in (("certainty  ", c, cq), ("haploweight", h, hq)):
+        flows, todo = a[0], a[0] - a[2] - a[3]
+        print("       %s: %.3g flows: %.0f%% pinned, %.0f%% ended in the scout (%.1f evaluations per scouted flow), %.0f%% set aside: "
+              "%.1f steps and %.2f quadratures each, lanes %.2f, %.0f%% ended by the tolerance"
+              % (name, flows, 100 * a[3] / max(flows, 1), 100 * a[2] / max(flows, 1), a[1] / max(flows - a[3], 1), 100 * todo / max(flows, 1),
+                 b[0] / max(todo, 1), b[2] / max(todo, 1), b[0] / max(b[1], 1), 100 * b[3] / max(todo, 1)), flush=True)
 run.close()
