@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--workload", default="f2", choices=["f2", "ail", "outbred"],
                     help="f2 = BASELINE configs 2/4 (headline); ail = config 3 (advanced intercross, 2 founders + 64 F1 + "
                          "8 generations, tied windows); outbred = config 5's shape (3-generation outbred, 20 %% missing)")
+    ap.add_argument("--iterations", type=int, default=0,
+                    help="with --workload outbred: time that many HAPLOTYPING ITERATIONS (BASELINE config 5: sweep + HOT LOOP 2 "
+                         "accumulators on the rank's block of individuals, one all-reduce of the accumulators, the update passes) "
+                         "instead of plain sweeps; --inds = analysed individuals in all (not per GPU: iterations do not shard, "
+                         "individuals do)")
     return ap.parse_args()
 
 
@@ -207,8 +212,87 @@ def cpu_baseline(sample_packed, pos, starts, args):
                       % (k, mc, dt, what)}
 
 
+def main_iterations(args):
+    """BASELINE config 5's unit of work: haplotyping iterations of one pedigree, the analysed individuals split over the ranks
+    (work-balanced blocks), the per-record accumulators summed by one all-reduce per iteration (RCCL), every rank running the
+    same update passes.  Strong scaling (the pedigree is fixed).  One JSON line from rank 0 with the time of every iteration."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback")
+    torch.cuda.set_device(local)
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    from cnf2freq_amd import synth
+    from cnf2freq_amd import dist as cdist
+    chroms = 4 if args.chroms == 20 else args.chroms
+    fams = 2500 if args.inds == 10000 else max(1, args.inds // 4)
+    ped = synth.make_outbred3(fams, 4, args.snps_per_chrom, chroms, seed=2, missing=0.2)      # the same pedigree on every rank
+    n, M, R = len(ped.dous), ped.n_markers, ped.n_rec
+    t0 = time.perf_counter()
+    run = cdist.start_iterations(ped, device=local)
+    t_setup = time.perf_counter() - t0
+    before = synth.dosage_accuracy(ped, run.state()) if rank == 0 else None
+    for _ in range(args.warmup):
+        run.iteration()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per_it = []
+    t0 = time.perf_counter()
+    for _ in range(args.iterations):
+        t1 = time.perf_counter()
+        run.iteration()
+        per_it.append(time.perf_counter() - t1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    staged = world > 1 and args.backend == "gloo"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if staged or world == 1 else torch.device("cuda", local))
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        st = run.state()
+        out = {
+            "metric": "haplotyping iterations/s (BASELINE config 5: sweep + accumulators + update passes per iteration)",
+            "value": args.iterations / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.iterations, "warmup": args.warmup,
+            "ms_per_step": dt / args.iterations * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-generation outbred pedigree (BASELINE config 5): %d families = %d individuals, %d analysed, "
+                                   "20%% of genotypes missing, %d chromosomes x %d SNPs (+1 dummy each)"
+                                   % (fams, R, n, chroms, args.snps_per_chrom),
+                       "analysed_individuals": n, "markers": M,
+                       "parallelism": "analysed individuals in %d work-balanced block(s), one all-reduce (sum) of the accumulator "
+                                      "slabs per iteration, update passes replicated" % world},
+            "units_per_s": float(n) * M * args.iterations / dt,
+            "iteration_s": per_it, "block": list(run.block), "setup_s": t_setup,
+            "scalefactor": st["scalefactor"], "last_hits": st["hits"],
+            "withheld_genotypes_before": before, "withheld_genotypes_after": synth.dosage_accuracy(ped, st),
+        }
+        print(json.dumps(out), flush=True)
+    run.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.iterations > 0:
+        if args.workload != "outbred":
+            raise SystemExit("--iterations goes with --workload outbred (BASELINE config 5)")
+        return main_iterations(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -268,6 +352,9 @@ def main():
         ctx = capi.Context(local)
         ctx.upload(ped)
         del ped
+    # the kernels a step launches: windows without tie groups on the plain instantiation, the others beside it
+    n_tied = sum(1 for j in range(n) if (ctx.window_info(j)["tie"] >= 0).any()) if args.workload == "ail" else 0
+    kernels = ["cnf2::fb_fast_kernel<true, 0, false, false>"] + (["cnf2::fb_fast_kernel<true, 0, false, true> (%d windows with tie groups)" % n_tied] if n_tied else [])
 
     factors = torch.empty((n, args.chroms, 8), dtype=torch.float64, device=device)
     do_gather = world > 1 and not args.no_gather
@@ -416,6 +503,19 @@ def main():
                                   "homozygous everywhere are swept once; all 8 modes are output"}
             del rows_h, ll_h
 
+        # the shader clock this device runs at under a vector load (boxes differ by several per cent and the sweep is
+        # issue-bound, so its time tracks the clock); VALU instructions per unit from the SQ counters where they were
+        # measured for these kernel sources (profiles/hbm_traffic.json)
+        clock_mhz = ctx.clock_probe()
+        valu_per_unit = None
+        try:
+            tj = json.load(open(args.traffic_file))
+            if tj.get("kernel_src_sha") == src_sha and args.workload == "f2":
+                valu_per_unit = tj.get("valu_per_unit")
+        except Exception:
+            pass
+        n_simd = 256 * 4
+        valu_issue_frac = (valu_per_unit * float(n) * M / n_simd * 4.0 / (k_ms * 1e-3 * clock_mhz * 1e6)) if valu_per_unit else None
         out = {
             "metric": "individual*marker fwd-bwd steps/sec (all 8 shift modes, forward+backward, dosage rows)",
             "value": value, "unit": "individual*marker/s", "n_gpus": world, "steps": args.steps,
@@ -434,8 +534,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "frac_physical": (traffic / (k_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                         "kernel": "cnf2::fb_fast_kernel<true>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha},
+                         "kernel": " + ".join(kernels), "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha,
+                         "effective_clock_mhz": clock_mhz, "frac_at_2400_mhz": achieved * 1e9 / HBM_PEAK * 2400.0 / clock_mhz,
+                         "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
             "checks": checks,
             "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,

@@ -753,6 +753,30 @@ int cnf2_last_kernel_ms(cnf2_ctx* ctx, float* kernel_ms, int n)
     return CNF2_OK;
 }
 
+int cnf2_clock_probe(cnf2_ctx* ctx, double* mhz_out)
+{
+    if (!ctx || !mhz_out) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)8);
+    if (rc) return rc;
+    const int iters = 1 << 20;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    launch_clock_probe(ctx->n_cu, 1 << 14, ctx->d_scratch, ctx->stream);            // warm up
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    launch_clock_probe(ctx->n_cu, iters, ctx->d_scratch, ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // per SIMD: 4 waves x 8 FMAs x iters, one wave-wide f64 FMA per 4 cycles
+    *mhz_out = 4.0 * 8.0 * (double)iters * 4.0 / ((double)ms * 1e-3) / 1e6;
+    return CNF2_OK;
+}
+
 size_t cnf2_workspace_bytes(cnf2_ctx* ctx)
 {
     if (!ctx) return 0;

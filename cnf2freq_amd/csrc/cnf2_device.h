@@ -130,6 +130,7 @@ struct UpdateParams {
     double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);
+void launch_clock_probe(int n_cu, int iters, double* sink, hipStream_t stream);
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream);

@@ -3989,6 +3989,33 @@ void launch_xor_selftest(double* out, hipStream_t stream)
     hipLaunchKernelGGL(xor_selftest_kernel, dim3(1), dim3(64), 0, stream, out);
 }
 
+// Clock probe: every SIMD of the chip gets 4 wavefronts that each issue `iters` x 8 independent double-precision FMAs and
+// nothing else: a SIMD issues one wave-wide f64 FMA per 4 cycles, so the kernel lasts 4 x 8 x iters x 4 cycles and its
+// duration gives the shader clock the device actually runs at under a vector-ALU load (boxes differ by several per cent,
+// and an issue-bound kernel like the sweep tracks it).
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, double* sink)
+{
+    double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 1.0000001, c = 1e-9;
+    for (int i = 0; i < iters; i++) {
+        a0 = fma(a0, m, c);
+        a1 = fma(a1, m, c);
+        a2 = fma(a2, m, c);
+        a3 = fma(a3, m, c);
+        a4 = fma(a4, m, c);
+        a5 = fma(a5, m, c);
+        a6 = fma(a6, m, c);
+        a7 = fma(a7, m, c);
+    }
+    const double v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (v == 12345.678) sink[0] = v;         // never true: keeps the chain alive
+}
+void launch_clock_probe(int n_cu, int iters, double* sink, hipStream_t stream)
+{
+    // 4 SIMDs x 4 waves = 16 waves = 4 blocks of 256 threads per CU
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(n_cu * 4), dim3(256), 0, stream, iters, sink);
+}
+
 int fb_blocks_per_cu()
 {
     int n = 0;

@@ -46,6 +46,7 @@ class Pedigree:
     chromstarts: np.ndarray  # int32 [C+1]
     dous: np.ndarray         # int32 [N] analysed records (gen >= 2)
     founder: np.ndarray = field(default=None)  # uint8 [R], filled by founder_flags()
+    truth: np.ndarray = field(default=None)    # uint8 [R,M] true allele-2 dosage where the generator knows it (make_outbred3)
 
     @property
     def n_rec(self):
@@ -283,7 +284,29 @@ def make_outbred3(n_fam, kids_per_fam, markers_per_chrom, n_chrom=1, seed=777, m
     ped = Pedigree(names, par, gen, empty, row_of, allele, sr, hw, pos, starts,
                    np.array(dous, np.int32))
     ped.founder_flags()
+    ped.truth = d.astype(np.uint8)
     return ped
+
+
+def dosage_accuracy(ped, state, mask=None):
+    """How well a run's state (cnf2freq_amd.host.Run.state(): allele [R][M][2], sure [R][M][2]) recovers the generator's true
+    allele-2 dosage on the genotypes that were withheld (read as missing), or on `mask` [R][M].  Expected dosage of a side =
+    P(allele 2) = 1 - sure for a called 2, sure for a called 1, 1/2 for an unknown allele.  Returns dict(n, called = fraction
+    with both alleles called, concordance = of those the fraction whose called dosage is the truth, mae = mean absolute
+    error of the expected dosage)."""
+    a, s = np.asarray(state["allele"]), np.asarray(state["sure"])
+    if mask is None:
+        mask = (ped.dense()[0] == 0).all(axis=2) & (np.asarray(ped.empty)[:, None] == 0)
+    p2 = np.where(a == 2, 1.0 - s, np.where(a == 1, s, 0.5))
+    expect = p2.sum(axis=2)
+    both = (a != 0).all(axis=2)
+    hard = (a == 2).sum(axis=2)
+    t = ped.truth.astype(np.float64)
+    n = int(mask.sum())
+    called = mask & both
+    return dict(n=n, called=float(called.sum()) / max(n, 1),
+                concordance=float((hard[called] == ped.truth[called]).mean()) if called.any() else float("nan"),
+                mae=float(np.abs(expect - t)[mask].mean()) if n else float("nan"))
 
 
 def make_random_windows(n_windows, n_markers, seed=4242):

@@ -305,6 +305,10 @@ int    cnf2_last_kernel_ms(cnf2_ctx *ctx, float *kernel_ms, int n);
  * with CNF2_TIES_GENERAL or CNF2_FULL_SPILL).  Test support: the specialisations are exact shortcuts and must all be exercised. */
 int    cnf2_last_paths(cnf2_ctx *ctx, int32_t *paths_out, int n);
 size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
+/* Shader clock the device runs at under a double-precision vector load, MHz (a loop of independent FMAs on every SIMD:
+ * one wave-wide FMA issues per 4 cycles).  Boxes of the same model differ by several per cent; an issue-bound kernel
+ * tracks this clock, so bench.py reports it next to the roofline fraction. */
+int    cnf2_clock_probe(cnf2_ctx *ctx, double *mhz_out);
 void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
 /* The sweep kernels are persistent (one resident wave per job in flight) and normally fill every
  * workgroup slot of the GPU.  Leaving `blocks` slots free lets another kernel -- the RCCL gather of

@@ -329,6 +329,30 @@ def test_exchange_callback_sees_the_device_slabs(libs):
     assert np.abs(states[1]["hw"] - s0["hw"]).max() < np.abs(states[0]["hw"] - s0["hw"]).max()
 
 
+def test_iterations_do_not_lose_the_withheld_genotypes(libs):
+    """BASELINE config 5 scaled down (125 families = 500 analysed individuals x 2 x 1 000 markers, 20 % of the genotypes
+    withheld, 10 haplotyping iterations): the run's picture of the withheld genotypes -- expected allele dosage against the
+    generator's truth -- must not get worse over the iterations, and what postmarkerdata had already inferred from relatives
+    must still be called."""
+    capi, host = libs
+    ped = synth.make_outbred3(125, 4, 1000, 2, seed=2, missing=0.2)
+    run = host.Run(ped)
+    run.postmarkerdata()
+    before = synth.dosage_accuracy(ped, run.state())
+    for _ in range(10):
+        run.iteration()
+    after = synth.dosage_accuracy(ped, run.state())
+    run.close()
+    assert before["n"] > 100000
+    assert after["mae"] <= before["mae"] + 1e-3, (before, after)
+    assert after["called"] >= before["called"] - 1e-3, (before, after)
+    assert after["concordance"] >= before["concordance"] - 5e-3, (before, after)
+    record = os.path.join(ROOT, "gpurun_out", "withheld_genotypes_500x2000.txt")
+    os.makedirs(os.path.dirname(record), exist_ok=True)
+    with open(record, "w") as f:
+        f.write("before %s\nafter  %s\n" % (before, after))
+
+
 def test_iterations_move_parameters_and_round_trip_through_deserialize(libs, tmp_path):
     """--count 3 semantics through the engine: two haplotyping iterations change haplotype weights and certainties,
     the dump of the state re-loads into a fresh run (deserialize, cnF2freq.cpp:7757-7832) to the printed precision, and

@@ -67,5 +67,17 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
 done
 python3 $R/profiles/pmc_summarize.py $out/sq1 $out/sq2 $out/sq3 $out/sq4 --units $((2000*50020)) --kernel fb_fast \
     > $out/${tag}_pmc_sq_summary_2000inds.txt
+# VALU instructions per unit into the traffic file: bench.py turns them into valu_issue_frac with the clock it measures
+python3 - "$out" "$tag" <<'PY'
+import json, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+txt = open("%s/%s_pmc_sq_summary_2000inds.txt" % (out, tag)).read()
+m = re.search(r"SQ_INSTS_VALU\s+\S+ \(dispatch rows \d+\)\s+per unit (\S+)", txt)
+f = "%s/%s_hbm_traffic.json" % (out, tag)
+j = json.load(open(f))
+j["valu_per_unit"] = float(m.group(1)) if m else None
+json.dump(j, open(f, "w"), indent=1)
+print("valu_per_unit", j["valu_per_unit"])
+PY
 cat $out/${tag}_pmc_sq_summary_2000inds.txt
 ls $out

@@ -32,6 +32,8 @@ run.postmarkerdata()
 t_pm = time.time() - t
 print("upload %.1f s, postmarkerdata %.1f s" % (t_up, t_pm), flush=True)
 s0 = run.state()
+acc0 = synth.dosage_accuracy(ped, s0)          # the withheld genotypes against the generator's truth, before any iteration
+print("withheld genotypes before the iterations: %s" % json.dumps(acc0), flush=True)
 locked = int(((s0["hw"] == 0) | (s0["hw"] == 1)).sum())
 t_it = []
 for it in range(iters):
@@ -59,6 +61,9 @@ out = {
     "phased_fraction": float((np.abs(s1["hw"][free] - 0.5) > 0.4).mean()),
     "genotypes_imputed": int(((s0["allele"] == 0) & (s1["allele"] != 0)).sum()),
     "scalefactor_end": s1["scalefactor"],
+    # the 20 % of genotypes withheld from the input, against the generator's truth: after postmarkerdata (inference from
+    # relatives only) and after the iterations
+    "withheld_before": acc0, "withheld_after": synth.dosage_accuracy(ped, s1),
 }
 print(json.dumps(out), flush=True)
 run.close()
