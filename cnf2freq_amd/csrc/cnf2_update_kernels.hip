@@ -1,0 +1,596 @@
+// cnf2_update_kernels.hip -- the per-iteration parameter updates on the device and the clock
+// probe: kernels over cnf2_update.h.  Kept apart from cnf2_kernels.hip (the sweep and its consumers) so that the
+// identity bench.py takes of the sweep kernels' sources does not change when these do.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cnf2_device.h"
+#include "cnf2_update.h"
+
+namespace cnf2 {
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // producer lanes -> consumer lanes of the SAME wave: order the LDS write before the reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-iteration parameter updates on the device (cnf2_update.h; processinfprobs / updatehaploweights,
+// cnF2freq.cpp:4179-4323, 4533-4734), after the sweep of chromosome `chrom` has been accounted for.
+// ---------------------------------------------------------------------------------------------------
+// CNF2_UPDATE_PLAIN -- the literal form: every same-sign step runs its quadrature, as the reference's cappedgd does.
+// One thread per (record, marker of the chromosome): both sides in order (side 1 sees side 0's result only through
+// the accumulators, which are per side), then the record's evidence at the marker is cleared.
+__global__ __launch_bounds__(256) void certainty_update_kernel(UpdateParams u)
+{
+    const int len = u.last - u.first + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * len) return;
+    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool   has_prior = u.has_prior[r] != 0, empty = u.rec_empty[r] != 0;
+    uint8_t ap = u.allele8[i];
+    double2 su = u.sure[i];
+    const uint8_t pap = has_prior ? u.prior_allele8[i] : 0;
+    const double2 psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
+    const StepControl sc = {u.scalefactor, u.entropyfactor};
+    int  hits = 0;
+    bool changed = false;
+    for (int side = 0; side < 2; side++) {
+        if (!(inf[side * 2] > 0) && !(inf[side * 2 + 1] > 0)) continue;
+        SideState s;
+        s.allele = side ? (ap >> 4) : (ap & 15);
+        s.sure = side ? su.y : su.x;
+        s.prior_allele = side ? (pap >> 4) : (pap & 15);
+        s.prior_sure = side ? psu.y : psu.x;
+        int    na;
+        double ns;
+        if (update_certainty(inf + side * 2, s, side, empty, has_prior, u.children[r], sc, &hits, &na, &ns, true)) {
+            if (side) {
+                ap = (uint8_t)((ap & 15) | (na << 4));
+                su.y = ns;
+            } else {
+                ap = (uint8_t)((ap & 0xF0) | na);
+                su.x = ns;
+            }
+            changed = true;
+        }
+    }
+    inf[0] = inf[1] = inf[2] = inf[3] = 0.0;                  // infprobs[j][side].clear() (cnF2freq.cpp:4315)
+    if (changed) {
+        u.allele8[i] = ap;
+        u.sure[i] = su;
+    }
+    if (hits) atomicAdd(u.hits, hits);
+}
+
+// One thread per (record, chromosome <= chrom): does the chromosome hold any information (haplocount != 0), and if
+// so the phase-consistency ratio of every marker (relskewhmm; relhaplo is the constant the PlantImpute path keeps).
+__global__ __launch_bounds__(64) void phase_ratio_kernel(UpdateParams u)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= u.n_rec * (u.chrom + 1)) return;
+    const int r = t / (u.chrom + 1), c = t % (u.chrom + 1);
+    const int c0 = u.chromstarts[c], c1 = u.chromstarts[c + 1];
+    const double* hc = u.acc_hc + (size_t)r * u.n_markers;
+    bool any = false;
+    for (int k = c0; k < c1 && !any; k++) any = hc[k] != 0.0;
+    u.anyinfo[(size_t)r * u.n_chrom + c] = any ? 1 : 0;
+    if (!any) return;
+    const double* hw = u.hw + (size_t)u.row_of[r] * u.n_markers;
+    double* fw = u.fw + ((size_t)r * u.n_markers + c0) * 2;
+    double* ratio = u.ratio + (size_t)r * u.n_markers + c0;
+    // phase_ratio() of cnf2_update.h with a constant relhaplo
+    double s0 = 0.5, s1 = 0.5;
+    const double n = u.relhaplo, nb = 1 - n;
+    for (int m = c0; m < c1; m++) {
+        const double w = hw[m];
+        s0 *= fabs(1 - w);
+        s1 *= fabs(0 - w);
+        fw[(m - c0) * 2] = s0;
+        fw[(m - c0) * 2 + 1] = s1;
+        if (s0 + s1 < 1e-10) {
+            s0 *= 1e20;
+            s1 *= 1e20;
+        }
+        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+        s0 = t0;
+        s1 = t1;
+    }
+    s0 = s1 = 0.5;
+    const int last = c1 - c0 - 1;
+    ratio[last] = fw[last * 2 + 1] / (fw[last * 2] + fw[last * 2 + 1]);
+    for (int m = c1 - 2; m >= c0; m--) {
+        const double w = hw[m + 1];
+        s0 *= fabs(1 - w);
+        s1 *= fabs(0 - w);
+        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+        s0 = t0;
+        s1 = t1;
+        if (s0 + s1 < 1e-10) {
+            s0 *= 1e20;
+            s1 *= 1e20;
+        }
+        const double r0 = s0 * fw[(m - c0) * 2], r1 = s1 * fw[(m - c0) * 2 + 1];
+        ratio[m - c0] = r1 / (r0 + r1);
+    }
+}
+
+// One thread per (record, marker of the chromosomes <= chrom)
+__global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
+{
+    const int    upto = u.chromstarts[u.chrom + 1];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * upto) return;
+    const int r = (int)(t / upto), m = (int)(t % upto);
+    int c = 0;
+    while (m >= u.chromstarts[c + 1]) c++;
+    if (!u.anyinfo[(size_t)r * u.n_chrom + c]) return;
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const double hw = u.hw[i];
+    if (!(hw != 0.0 && hw != 1.0) || u.row_of[r] == 0) return;              // cnF2freq.cpp:4591; the shared blank row is never written
+    const uint8_t ap = u.allele8[i];
+    const double2 su = u.sure[i];
+    const size_t  k = (size_t)r * u.n_markers + m;
+    double hb = u.acc_hb[k], hcv = u.acc_hc[k];
+    const StepControl sc = {u.scalefactor, u.entropyfactor};
+    int hits = 0;
+    const double nw = update_haploweight(hw, &hb, &hcv, ap & 15, ap >> 4, su.x, su.y, u.ratio[k], u.children[r],
+                                         u.descendants[r], sc, false, &hits, true);
+    u.acc_hb[k] = hb;
+    u.acc_hc[k] = hcv;
+    u.hw[i] = nw;
+    if (hits) atomicAdd(u.hits, hits);
+}
+
+// ---- the same two updates as flow kernels --------------------------------------------------------------------
+// A flow (cnf2_update.h) takes between 1 and 51 bisection steps, a step one gradient evaluation or none (the midpoint's
+// sign settles it, or a bound does) or sixteen (a 15-point quadrature); with one thread per element nearly every
+// wavefront waits for its longest lane, and most of the evaluations locate a root by bisection.  Two passes instead:
+//   scout   one thread per flow (flow_scout): set-up, the flows pinned to their clamp, and every step that needs no
+//           quadrature -- with the gradient shown monotone the root is found superlinearly and the bisection's own
+//           midpoints are answered from what is known about it.  In the steady state of a run three flows in four
+//           end here, after ~20 evaluations instead of ~65.  A flow that reaches a quadrature is set aside: its item,
+//           the number of steps it has completed and their decisions (16 or 24 bytes).
+//   finish  the flows set aside, as a persistent kernel: a wavefront runs ONE literal step (flow_advance: midpoint, the
+//           bound, the quadrature) of 64 independent flows per round and hands a lane the next flow from a global counter
+//           when its own has ended (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else
+//           is running, because taking a flow up -- loads, the prior's logarithms, the gradient at the start, the replay
+//           of its decisions -- is executed by the whole wave).  These flows spend their steps in quadratures, so the
+//           lanes of a wave stay in step.
+// Both passes make the decisions of the literal algorithm (CNF2_UPDATE_PLAIN); what differs is how much is computed.
+#ifndef FLOW_REFILL
+#define FLOW_REFILL 16
+#endif
+
+struct FlowTodo {
+    unsigned long long item_steps;   // item << 6 | steps completed
+    unsigned long long path;         // their decisions (FlowState::path)
+};
+struct HaploTodo {
+    unsigned long long item_steps, path;
+    double             similarity;   // what haplo_rewrite returned in the scout (the rewrite is not repeated)
+};
+
+// diagnostics: stats[0..3] += a, b, c, d summed over the wavefront
+__device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned a_, unsigned b_, unsigned c_, unsigned d_)
+{
+    if (!stats) return;
+    unsigned long long a = a_, b = b_, c = c_, d = d_;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+        d += __shfl_xor(d, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, a);
+        atomicAdd(stats + 1, b);
+        atomicAdd(stats + 2, c);
+        atomicAdd(stats + 3, d);
+    }
+}
+
+// the hit counter: one atomic per wavefront that has any
+__device__ __forceinline__ void flow_hits(int* counter, int hits)
+{
+    int h = hits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(counter, h);
+}
+
+// The flows the scout set aside reach the lanes of a finish wavefront through a queue of the wave's own in LDS: the wave
+// reserves FLOW_CHUNK slots of the scout's list at a time (an atomic on one address costs tens of nanoseconds across the
+// 8 XCDs: a counter bumped once per refill was most of the run time of these kernels), reads them 64 at a time -- one
+// coalesced load -- and queues the entries that hold a flow.  Free lanes take from the queue.
+#define FLOW_CHUNK 4096ull
+#define FLOW_QUEUE 128          /* entries: at most 63 left over plus 64 from one read */
+template <class Entry>
+struct FlowSupply {
+    unsigned long long pos, end;      // the wave's reservation in the scout's list
+    int                count;         // entries queued
+    bool               more;          // the list has slots the wave has not read
+};
+// tops the queue up to at least `wanted` entries (or until the list is exhausted)
+template <class Entry>
+__device__ __forceinline__ void flow_supply(FlowSupply<Entry>* q, Entry* queue, unsigned long long* next, const Entry* todo,
+                                            unsigned long long n_items, int wanted)
+{
+    const int lane = threadIdx.x & 63;
+    while (q->more && q->count < wanted) {
+        if (q->pos >= q->end) {                              // reservation used up: a new one
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(next, FLOW_CHUNK);
+            base = __shfl(base, 0);
+            if (base >= n_items) {
+                q->more = false;
+                break;
+            }
+            q->pos = base;
+            q->end = base + FLOW_CHUNK < n_items ? base + FLOW_CHUNK : n_items;
+        }
+        const unsigned long long slot = q->pos + lane;
+        Entry e;
+        e.item_steps = ~0ull;
+        if (slot < q->end) e = todo[slot];
+        const bool               holds = e.item_steps != ~0ull;
+        const unsigned long long mask = __ballot(holds);
+        if (holds) queue[q->count + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+        q->count += __popcll(mask);
+        q->pos = q->pos + 64 < q->end ? q->pos + 64 : q->end;
+        wave_lds_fence();
+    }
+}
+// entries for the lanes that want one: the last `n` queued, n = min(lanes that want, queued)
+template <class Entry>
+__device__ __forceinline__ bool flow_pop(FlowSupply<Entry>* q, const Entry* queue, bool want, Entry* e)
+{
+    const unsigned long long need = __ballot(want);
+    const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1ull)), n = __popcll(need);
+    const int take = n < q->count ? n : q->count;
+    const bool got = want && rank < take;
+    if (got) *e = queue[q->count - 1 - rank];
+    wave_lds_fence();
+    q->count -= take;
+    return got;
+}
+
+// item = ((r * len + mi) * 2 + side) * 2 + v: the flow of value v + 1 on one side of (record, marker);
+// flow_out[item] = its new probability (0 where the value has no evidence)
+__device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c)
+{
+    const int          len = u.last - u.first + 1;
+    const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
+    const unsigned long long e = item >> 2;
+    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
+    const double       pair[2] = {inf[0], inf[1]};
+    const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool         has_prior = u.has_prior[r] != 0;
+    const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
+    const double2      su = u.sure[i];
+    const double2      psu = has_prior ? u.prior_sure[i] : make_double2(0.0, 0.0);
+    SideState s;
+    s.allele = side ? (ap >> 4) : (ap & 15);
+    s.sure = side ? su.y : su.x;
+    s.prior_allele = side ? (pap >> 4) : (pap & 15);
+    s.prior_sure = side ? psu.y : psu.x;
+    return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
+}
+
+__global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+                                                              double* flow_out, FlowTodo* todo)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    int      hits = 0, evals = 0;
+    unsigned n_flows = 0, n_pinned = 0, n_done = 0;
+    bool     aside = false;
+    FlowTodo e;
+    if (t < n_items) {
+        const unsigned long long item = item0 + t;
+        CertaintyFlow c;
+        if (!certainty_item(u, item, sc, &c)) {
+            flow_out[item] = 0.0;
+        } else {
+            FlowState f;
+            auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
+            flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+            n_flows = 1;
+            if (f.pinned) {                 // no gradient evaluations left
+                while (flow_advance(&f, grad, sc.scalefactor)) {}
+                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                n_pinned = 1;
+            } else {
+                const SlopeTerms st = certainty_slope(c);
+                if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                    flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                    n_done = 1;
+                } else {
+                    aside = true;
+                    e.item_steps = (item << 6) | (unsigned long long)f.it;
+                    e.path = f.path;
+                }
+            }
+        }
+    }
+    if (t < n_items) {
+        if (!aside) e.item_steps = ~0ull;                     // nothing set aside in this slot
+        todo[t] = e;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+__global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
+                                                              unsigned long long n_items, double* flow_out)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ FlowTodo  queue[FLOW_QUEUE];
+    FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
+    bool               have = false;
+    unsigned long long item = 0;
+    CertaintyFlow      c;
+    FlowState          f;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_steps = 0, n_rounds = 0, n_quads = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) CNF2_LI { return flow_time_under(st, xa, xb, pc, lim); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            FlowTodo e;
+            if (flow_pop(&q, queue, !have, &e)) {
+                item = e.item_steps >> 6;
+                certainty_item(u, item, sc, &c);
+                flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+                flow_replay(&f, e.path, (int)(e.item_steps & 63));
+                st = certainty_slope(c);
+                have = true;
+            }
+            continue;
+        }
+        if (busy == 0) break;               // nothing running and nothing left
+        n_rounds++;
+        if (have) {
+            n_steps++;
+            if (!flow_advance(&f, grad, sc.scalefactor, bound)) {
+                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                have = false;
+                n_quads += f.quads;
+                n_why1 += f.why == 1;
+            }
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 8 : nullptr, n_steps, n_rounds, n_quads, n_why1);
+}
+
+// one thread per (record, marker of the chromosome): cnF2freq.cpp:4292-4322 from the flows' results
+__global__ __launch_bounds__(256) void certainty_pick_kernel(UpdateParams u, const double* flow_out)
+{
+    const int    len = u.last - u.first + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)u.n_rec * len) return;
+    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
+    const double4 a = *(const double4*)inf, o = *(const double4*)(flow_out + t * 4);
+    if (a.x == 0.0 && a.y == 0.0 && a.z == 0.0 && a.w == 0.0) return;          // nothing was added, nothing to clear
+    const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
+    const bool   has_prior = u.has_prior[r] != 0, empty = u.rec_empty[r] != 0;
+    uint8_t ap = u.allele8[i];
+    double2 su = u.sure[i];
+    bool    changed = false;
+    const double in2[2][2] = {{a.x, a.y}, {a.z, a.w}}, out2[2][2] = {{o.x, o.y}, {o.z, o.w}};
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        int    na;
+        double ns;
+        if (!(in2[side][0] > 0) && !(in2[side][1] > 0)) continue;
+        if (certainty_pick(in2[side], out2[side], side, empty, has_prior, &na, &ns)) {
+            if (side) {
+                ap = (uint8_t)((ap & 15) | (na << 4));
+                su.y = ns;
+            } else {
+                ap = (uint8_t)((ap & 0xF0) | na);
+                su.x = ns;
+            }
+            changed = true;
+        }
+    }
+    *(double4*)inf = make_double4(0.0, 0.0, 0.0, 0.0);          // infprobs[j][side].clear() (cnF2freq.cpp:4315)
+    if (changed) {
+        u.allele8[i] = ap;
+        u.sure[i] = su;
+    }
+}
+
+// item = r * upto + m over the markers of the chromosomes <= chrom.  false: nothing to update there
+__device__ __forceinline__ bool haplo_item(const UpdateParams& u, unsigned long long item, size_t* row_i, size_t* k, int* r_out)
+{
+    const int upto = u.chromstarts_host_upto;
+    const int r = (int)(item / upto), m = (int)(item % upto);
+    int       c = 0;
+    while (m >= u.chromstarts[c + 1]) c++;
+    *row_i = (size_t)u.row_of[r] * u.n_markers + m;
+    *k = (size_t)r * u.n_markers + m;
+    *r_out = r;
+    const double hw = u.hw[*row_i];
+    return u.anyinfo[(size_t)r * u.n_chrom + c] && hw != 0.0 && hw != 1.0 && u.row_of[r] != 0;          // cnF2freq.cpp:4591
+}
+
+__global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+                                                                HaploTodo* todo)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    int      hits = 0, evals = 0;
+    unsigned n_flows = 0, n_pinned = 0, n_done = 0;
+    size_t   row_i, k;
+    int      r;
+    bool      aside = false;
+    HaploTodo e;
+    if (t < n_items && haplo_item(u, item0 + t, &row_i, &k, &r)) {
+        const double  hw = u.hw[row_i];
+        const uint8_t ap = u.allele8[row_i];
+        const double2 su = u.sure[row_i];
+        double hb = u.acc_hb[k], hcv = u.acc_hc[k];
+        const double similarity = haplo_rewrite(hw, &hb, &hcv, haplo_similarity(ap & 15, ap >> 4, su.x, su.y));
+        u.acc_hb[k] = hb;
+        u.acc_hc[k] = hcv;
+        HaploFlow h;
+        haplo_flow_terms(hw, hb, hcv, similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+        FlowState f;
+        auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+        flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+        n_flows = 1;
+        if (f.pinned) {
+            while (flow_advance(&f, grad, sc.scalefactor)) {}
+            u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+            n_pinned = 1;
+        } else {
+            const SlopeTerms st = haplo_slope(h);
+            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+                n_done = 1;
+            } else {
+                aside = true;
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it;
+                e.path = f.path;
+                e.similarity = similarity;
+            }
+        }
+    }
+    if (t < n_items) {
+        if (!aside) e.item_steps = ~0ull;                     // nothing set aside in this slot
+        todo[t] = e;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+__global__ __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
+                                                                unsigned long long n_items)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ HaploTodo  queue[FLOW_QUEUE];
+    FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
+    bool               have = false;
+    size_t             row_i = 0;
+    HaploFlow          h;
+    FlowState          f;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_steps = 0, n_rounds = 0, n_quads = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+    auto bound = [&](double xa, double xb, double pc, double lim) CNF2_LI { return flow_time_under(st, xa, xb, pc, lim); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            HaploTodo e;
+            if (flow_pop(&q, queue, !have, &e)) {
+                size_t k;
+                int    r;
+                haplo_item(u, e.item_steps >> 6, &row_i, &k, &r);
+                const double hw = u.hw[row_i];
+                haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+                flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+                flow_replay(&f, e.path, (int)(e.item_steps & 63));
+                st = haplo_slope(h);
+                have = true;
+            }
+            continue;
+        }
+        if (busy == 0) break;
+        n_rounds++;
+        if (have) {
+            n_steps++;
+            if (!flow_advance(&f, grad, sc.scalefactor, bound)) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+                have = false;
+                n_quads += f.quads;
+                n_why1 += f.why == 1;
+            }
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 12 : nullptr, n_steps, n_rounds, n_quads, n_why1);
+}
+
+void launch_update_pass(const UpdateParams& u, hipStream_t stream)
+{
+    const int    len = u.last - u.first + 1;
+    const size_t n1 = (size_t)u.n_rec * len;
+    const int    n2 = u.n_rec * (u.chrom + 1);
+    const size_t n3 = (size_t)u.n_rec * u.chromstarts_host_upto;
+    if (!u.flow_next) {                                       // CNF2_UPDATE_PLAIN: one thread per element, the literal steps
+        hipLaunchKernelGGL(certainty_update_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u);
+        hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+        hipLaunchKernelGGL(haploweight_update_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, stream, u);
+        return;
+    }
+    const size_t resident = (size_t)256 * 16;                 // wavefronts the chip holds at 4 per SIMD
+    // counters: [0] finish kernel's next slot, [1] flows set aside; then 24 statistics.  The scouts run in chunks of
+    // todo_cap flows so that the list of flows set aside stays bounded.
+    (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
+    const size_t cap = u.todo_cap;
+    for (size_t i0 = 0; i0 < n1 * 4; i0 += cap) {
+        const size_t n = n1 * 4 - i0 < cap ? n1 * 4 - i0 : cap;
+        (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+        hipLaunchKernelGGL(certainty_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                           (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
+        const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                           (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+    }
+    hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
+    hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
+    for (size_t i0 = 0; i0 < n3; i0 += cap) {
+        const size_t n = n3 - i0 < cap ? n3 - i0 : cap;
+        (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+        hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                           (unsigned long long)n, (HaploTodo*)u.todo);
+        const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                           (const HaploTodo*)u.todo, (unsigned long long)n);
+    }
+}
+
+
+// Clock probe: every SIMD of the chip gets 4 wavefronts that each issue `iters` x 8 independent double-precision FMAs and
+// nothing else: a SIMD issues one wave-wide f64 FMA per 4 cycles, so the kernel lasts 4 x 8 x iters x 4 cycles and its
+// duration gives the shader clock the device actually runs at under a vector-ALU load (boxes differ by several per cent,
+// and an issue-bound kernel like the sweep tracks it).
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, double* sink)
+{
+    double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 1.0000001, c = 1e-9;
+    for (int i = 0; i < iters; i++) {
+        a0 = fma(a0, m, c);
+        a1 = fma(a1, m, c);
+        a2 = fma(a2, m, c);
+        a3 = fma(a3, m, c);
+        a4 = fma(a4, m, c);
+        a5 = fma(a5, m, c);
+        a6 = fma(a6, m, c);
+        a7 = fma(a7, m, c);
+    }
+    const double v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (v == 12345.678) sink[0] = v;         // never true: keeps the chain alive
+}
+void launch_clock_probe(int n_cu, int iters, double* sink, hipStream_t stream)
+{
+    // 4 SIMDs x 4 waves = 16 waves = 4 blocks of 256 threads per CU
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(n_cu * 4), dim3(256), 0, stream, iters, sink);
+}
+
+} // namespace cnf2

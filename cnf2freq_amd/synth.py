@@ -304,8 +304,11 @@ def dosage_accuracy(ped, state, mask=None):
     t = ped.truth.astype(np.float64)
     n = int(mask.sum())
     called = mask & both
+    conf = called & (s.max(axis=2) < 0.1)
     return dict(n=n, called=float(called.sum()) / max(n, 1),
                 concordance=float((hard[called] == ped.truth[called]).mean()) if called.any() else float("nan"),
+                confident=float(conf.sum()) / max(n, 1),
+                concordance_confident=float((hard[conf] == ped.truth[conf]).mean()) if conf.any() else float("nan"),
                 mae=float(np.abs(expect - t)[mask].mean()) if n else float("nan"))
 
 

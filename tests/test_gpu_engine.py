@@ -338,19 +338,26 @@ def test_iterations_do_not_lose_the_withheld_genotypes(libs):
     ped = synth.make_outbred3(125, 4, 1000, 2, seed=2, missing=0.2)
     run = host.Run(ped)
     run.postmarkerdata()
-    before = synth.dosage_accuracy(ped, run.state())
+    s0 = run.state()
+    before = synth.dosage_accuracy(ped, s0)
+    withheld = (ped.dense()[0] == 0).all(axis=2) & (np.asarray(ped.empty)[:, None] == 0)
+    inferred = withheld & (np.asarray(s0["allele"]) != 0).all(axis=2)
     for _ in range(10):
         run.iteration()
-    after = synth.dosage_accuracy(ped, run.state())
+    s1 = run.state()
+    after = synth.dosage_accuracy(ped, s1)
+    kept = synth.dosage_accuracy(ped, s1, mask=inferred)
     run.close()
-    assert before["n"] > 100000
+    assert before["n"] > 100000 and inferred.sum() > 10000
     assert after["mae"] <= before["mae"] + 1e-3, (before, after)
     assert after["called"] >= before["called"] - 1e-3, (before, after)
-    assert after["concordance"] >= before["concordance"] - 5e-3, (before, after)
+    assert kept["called"] >= 1 - 1e-3 and kept["concordance"] >= 0.99, kept
+    assert after["confident"] >= before["confident"] - 1e-3, (before, after)
+    assert after["concordance_confident"] >= 0.99, after
     record = os.path.join(ROOT, "gpurun_out", "withheld_genotypes_500x2000.txt")
     os.makedirs(os.path.dirname(record), exist_ok=True)
     with open(record, "w") as f:
-        f.write("before %s\nafter  %s\n" % (before, after))
+        f.write("before %s\nafter  %s\nkept   %s\n" % (before, after, kept))
 
 
 def test_iterations_move_parameters_and_round_trip_through_deserialize(libs, tmp_path):

@@ -1,26 +1,23 @@
 #!/bin/sh
-# Register / scratch / LDS use of every gfx950 kernel in libcnf2hip.so, from the code object's metadata notes.
-# usage: tools/kernel_resources.sh [library] [name filter]
-LIB=${1:-cnf2freq_amd/libcnf2hip.so}
-FILTER=${2:-.}
-LLVM=/opt/rocm/lib/llvm/bin
+# Register / scratch / LDS use of the gfx950 kernels, from the code objects' metadata notes.
+# usage: tools/kernel_resources.sh [name filter]      (compiles the .hip files of cnf2freq_amd/csrc for the device only)
+FILTER=${1:-.}
+HERE=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d /tmp/cnf2res.XXXXXX)
 trap 'rm -rf "$TMP"' EXIT
-$LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input="$LIB" --output="$TMP/dev.co" --unbundle 2>/dev/null || {
-    # the bundle sits in the .hip_fatbin section of a shared object
-    $LLVM/llvm-objcopy -O binary --only-section=.hip_fatbin "$LIB" "$TMP/fat.bin"
-    $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input="$TMP/fat.bin" --output="$TMP/dev.co" --unbundle
-}
-$LLVM/llvm-readelf --notes "$TMP/dev.co" | python3 -c '
-import re, sys
+for f in "$HERE"/cnf2freq_amd/csrc/cnf2_kernels.hip "$HERE"/cnf2freq_amd/csrc/cnf2_update_kernels.hip; do
+    b=$(basename "$f" .hip)
+    (cd "$HERE/cnf2freq_amd/csrc" && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics --cuda-device-only \
+        --no-gpu-bundle-output -c -o "$TMP/$b.o" "$f" 2>/dev/null)
+    /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$TMP/$b.o"
+done | python3 -c '
+import re, sys, subprocess
 txt = sys.stdin.read()
 flt = re.compile(sys.argv[1])
 for blk in txt.split("- .agpr_count:")[1:]:
     get = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
-    name = get("name")
-    import subprocess
-    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["c++filt", get("name")], capture_output=True, text=True).stdout.strip()
     if not flt.search(dem): continue
     agpr = blk.split("\n")[0].strip()
-    print("%-110s vgpr %3s agpr %3s sgpr %3s spill_v %3s scratch %4s B  lds %6s B" % (dem[:110], get("vgpr_count"), agpr, get("sgpr_count"), get("vgpr_spill_count"), get("private_segment_fixed_size"), get("group_segment_fixed_size")))
+    print("%-100s vgpr %3s agpr %3s sgpr %3s spill_v %3s scratch %4s B  lds %6s B" % (dem[:100], get("vgpr_count"), agpr, get("sgpr_count"), get("vgpr_spill_count"), get("private_segment_fixed_size"), get("group_segment_fixed_size")))
 ' "$FILTER"
