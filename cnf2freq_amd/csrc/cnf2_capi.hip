@@ -1267,7 +1267,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
         ctx->spill_bytes = capd * sizeof(double);
         if (rc) return rc;
     }
-    const size_t per_job = (size_t)mlen * 1040;
+    const size_t per_job = (size_t)mlen * CNF2_TURN_ROW;
     size_t       batch = (free_b - (size_t)grid_cap * per_blk) / 2 / (per_job * sizeof(double));
     if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the alpha/beta rows of one job");
     if (batch > jobs.size()) batch = jobs.size();

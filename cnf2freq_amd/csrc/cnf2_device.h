@@ -139,6 +139,10 @@ void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream);
 // Inputs of the batched turn scan (turn_rows_kernel): what a turn-scan sweep (STOREW == 2) left in kp.wbuf
+// Row of the turn-scan mode's batch buffer (doubles per job and marker): A = alphaminus e [4][64 lanes][2], B = beta
+// likewise, then per shift mode s the scales that make them absolute as mantissa and binary exponent
+// [8][4] = (mA, eA, mB, eB): absolute A_s = A * mA * 2^eA, absolute B_s = B * mB * 2^eB.
+#define CNF2_TURN_ROW 1056
 struct TurnParams {
     KernelParams kp;
     int          n_jobs, max_len;

@@ -419,30 +419,36 @@ CNF2_HD void emtab_part(const PartCfg& c, const Slot& root, const Slot& par, con
                            [&](int kind, int e, double v) { (kind == 0 ? tot : (kind == 1 ? rtot : two))[e] = v; }, cw);
 }
 
-// Static part of a lane of the tile producer.
+// Static part of a lane of the tile producer.  The window's arrays are read with constant indices and the lane's
+// slots chosen by selects: an index that depends on the lane would put a copy of the window into scratch memory.
 CNF2_HD void make_part(const Window& w, int part, PartCfg* c, int32_t* row_par, int32_t* row_tr, int32_t* row_ot)
 {
-    const int P = part >> 2, f = (part >> 1) & 1, firstpar = part & 1;
-    const int slot_par = 1 + 3 * P;
-    const int slot_tr  = slot_par + 1 + firstpar;
-    const int slot_ot  = slot_par + 1 + (firstpar ^ 1);
+    const int  P = part >> 2, f = (part >> 1) & 1, firstpar = part & 1;
+    const bool hi = P != 0, fp = firstpar != 0;
     c->P = P;
     c->f = f;
     c->firstpar   = firstpar;
-    c->par        = w.flags[slot_par];
-    c->tr         = w.flags[slot_tr];
-    c->ot         = w.flags[slot_ot];
+    // slot_par = 1 + 3 P, slot_tr = slot_par + 1 + firstpar, slot_ot = slot_par + 1 + (firstpar ^ 1)
+    const uint32_t fa = hi ? w.flags[5] : w.flags[2], fb = hi ? w.flags[6] : w.flags[3];
+    const int32_t  ra = hi ? w.row[5] : w.row[2], rb = hi ? w.row[6] : w.row[3];
+    const int32_t  rp = hi ? w.row[4] : w.row[1];
+    c->par        = hi ? w.flags[4] : w.flags[1];
+    c->tr         = fp ? fb : fa;
+    c->ot         = fp ? fa : fb;
     c->root_attop = (w.flags[0] & SLOT_FOUNDER) != 0;
-    *row_par = w.row[slot_par] < 0 ? 0 : w.row[slot_par];
-    *row_tr  = w.row[slot_tr] < 0 ? 0 : w.row[slot_tr];
-    *row_ot  = w.row[slot_ot] < 0 ? 0 : w.row[slot_ot];
+    const int32_t rt = fp ? rb : ra, ro = fp ? ra : rb;
+    *row_par = rp < 0 ? 0 : rp;
+    *row_tr  = rt < 0 ? 0 : rt;
+    *row_ot  = ro < 0 ? 0 : ro;
 }
 
 // the forces of tie combination `combo` for the three slots of a part (cnf2_lane.h tie_force)
 CNF2_HD void part_forces(const Window& w, int part, int combo, PartCfg* c)
 {
-    const int P = part >> 2, firstpar = part & 1, slot_par = 1 + 3 * P;
-    const int8_t tp = w.tie[slot_par], tt = w.tie[slot_par + 1 + firstpar], to = w.tie[slot_par + 1 + (firstpar ^ 1)];
+    const bool   hi = (part >> 2) != 0, fp = (part & 1) != 0;
+    const int8_t tp = hi ? w.tie[4] : w.tie[1];
+    const int8_t ta = hi ? w.tie[5] : w.tie[2], tb = hi ? w.tie[6] : w.tie[3];
+    const int8_t tt = fp ? tb : ta, to = fp ? ta : tb;
     c->force_par = tp < 0 ? -1 : ((combo >> tp) & 1);
     c->force_tr  = tt < 0 ? -1 : ((combo >> tt) & 1);
     c->force_ot  = to < 0 ? -1 : ((combo >> to) & 1);

@@ -384,7 +384,7 @@ __device__ __forceinline__ double chain_normaliser(const double (&v)[8], double*
 }
 
 // STOREW: 0 = plain sweep; 1 = accumulate mode (posterior weights of every marker into p.wbuf); 2 = turn-scan mode
-// (alpha after emission and beta of every marker with their log2 scales into p.wbuf, 1040 doubles per marker)
+// (alpha after emission and beta of every marker with their scales into p.wbuf, CNF2_TURN_ROW doubles per marker)
 template <bool DEBUG_STORE, int STOREW = 0>
 __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 {
@@ -548,16 +548,21 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
                 D     = chain_sum(D);
                 if (STOREW == 2) {
                     // turn-scan mode: A = alphaminus e, B = beta (both as the normalised vectors held here) and their
-                    // log2 scales: log2 P(data, mode) = fs / ln 2 = lgA + lgB + log2 D
-                    double* wp = p.wbuf + ((size_t)job * p.wstride + (m - first)) * 1040;
-                    const double lgB = log2(bmant) + (double)bexpo;
-                    const double lgA = fs * 1.4426950408889634074 - log2(D) - lgB;
+                    // scales as mantissa and binary exponent: log2 P(data, mode) = fs / ln 2 = lgA + lgB + log2 D
+                    double* wp = p.wbuf + ((size_t)job * p.wstride + (m - first)) * CNF2_TURN_ROW;
+                    const double lgA = fs * 1.4426950408889634074 - log2(D) - (log2(bmant) + (double)bexpo);
+                    const double eA  = floor(lgA);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         *(double2*)(wp + k * 128 + lane * 2) = make_double2(sp[(2 * k) * 64] * e[2 * k], sp[(2 * k + 1) * 64] * e[2 * k + 1]);
                         *(double2*)(wp + 512 + k * 128 + lane * 2) = make_double2(b[2 * k], b[2 * k + 1]);
                     }
-                    if (c.lo == 0) *(double2*)(wp + 1024 + 2 * s) = make_double2(lgA, lgB);
+                    if (c.lo == 0) {
+                        // a chain with no likelihood at all (fs = -inf or the sentinel): scale 0, the turn scan's floor
+                        const bool none = !(lgA > -1e300);
+                        *(double2*)(wp + 1024 + 4 * s)     = make_double2(none ? 0.0 : exp2(lgA - eA), none ? 0.0 : eA);
+                        *(double2*)(wp + 1024 + 4 * s + 2) = make_double2(bmant, (double)bexpo);
+                    }
                 }
                 if (STOREW == 1) {
                     // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta = wj * ws / D
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (STOREW == 2) {
                 // turn-scan mode: A = alphaminus e and B = beta as held here, with the log2 of the scales that make them
                 // absolute (alphaminus: Fpre, and the stored normaliser of the even neighbour for a rebuilt odd marker)
-                double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 1040;
+                double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * CNF2_TURN_ROW;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const d2v va = {aw[2 * k] * e[2 * k], aw[2 * k + 1] * e[2 * k + 1]};
@@ -1150,9 +1155,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                     __builtin_nontemporal_store(vb, (d2v*)(wp + 512 + k * 128 + lane * 2));
                 }
                 if (c.lo == 0) {
-                    const double lgA = log2((ODD ? S.inv_even : 1.0) * S.fmant) + (double)S.fexpo;
-                    const double lgB = log2(S.bmant) + (double)S.bexpo;
-                    *(double2*)(wp + 1024 + 2 * s) = make_double2(lgA, lgB);
+                    *(double2*)(wp + 1024 + 4 * s)     = make_double2((ODD ? S.inv_even : 1.0) * S.fmant, (double)S.fexpo);
+                    *(double2*)(wp + 1024 + 4 * s + 2) = make_double2(S.bmant, (double)S.bexpo);
                 }
             }
             // every lane parks its three class partials in this marker's row (all of it is dead by now:
@@ -3321,99 +3325,271 @@ void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream)
 
 // =====================================================================================
 // Batched turn scan (HOT LOOP 3, cnF2freq.cpp:5686-5752): rawervals[turn][s] =
-// doanalyze<aroundturner>(turn, classicstop(q, -1)) - factor for every marker of every job of a turn-scan sweep,
-// one wavefront per (job, marker).  aroundturner(turn) XORs the states with turn & 54 and the shift mode with
+// doanalyze<aroundturner>(turn, classicstop(q, -1)) - factor for every marker of every job of a turn-scan sweep.
+// aroundturner(turn) XORs the states with turn & 54 and the shift mode with
 // (turn >> 6) | (turn & 1 ? 2 : 0) | (turn & 8 ? 4 : 0) (cnF2freq.cpp:506-511), so
 //     rawervals[turn][s] = log sum_k A_s(k ^ (turn & 54)) B_{s ^ shiftx}(k) + scales - factor:
-// 8 shift flips (B fetched from the partner chain: lane moves), 4 flips of state bits 1-2 (lanes inside a chain: DPP)
-// and 4 of state bits 4-5 (registers: free), an 8-term dot product and a chain sum each.  One logarithm per 8 turns
-// and lane (lane lo keeps the sum of the turn whose index is lo mod 8).  Outputs: the full table and / or its
-// log-sum-exp over the admissible shift modes per turn (what the clause weights of cnF2freq.cpp:5800-5817 are made of).
+// per (job, marker) 64 pairs of shift modes (s, s ^ sx) x 16 flips of state bits 1, 2, 4, 5 = 1 024 dot products of
+// 64 terms -- 131 072 flops on 8.4 KB read: the kernel is bound by the f64 FMA rate, not by HBM.
+// One wavefront per (job, marker), lane = sx << 3 | s.  The sweep's rows go through LDS once ([chain][l][j], rows
+// padded to 66 doubles so that the 8 chains a read touches sit in different banks); a lane keeps its A_s whole in
+// registers (64 doubles), streams B_{s ^ sx} from LDS (one 16-byte read per 32 FMAs) and runs 16 accumulators, one
+// per flip: the flips are register renaming (A[l ^ L(x)][j ^ J(x)] with compile-time indices), there is no
+// cross-lane sum and no multiply is done twice.  Scales are mantissa and binary exponent (CNF2_TURN_ROW), so the
+// log-sum-exp over the admissible shift modes per turn (what the clause weights of cnF2freq.cpp:5800-5817 are made of)
+// is exact scaling (frexp / ldexp), a halving exchange over the 8 lanes of a group that leaves every lane 2 of the
+// group's 16 sums, and 2 logarithms per lane.  The full table costs 16 logarithms per lane (parity / debugging).
+// Each wave walks CNF2_TURN_SPAN consecutive markers; the second wave of the SIMD computes while this one waits for its rows.
 // =====================================================================================
-__global__ __launch_bounds__(CNF2_BLOCK) void turn_rows_kernel(TurnParams q)
+// log of a positive normal double: frexp to [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) by its series to t^21
+// (|t| <= 0.1716: remainder 6e-19), reciprocal-based quotient.  About a third of the library routine's instructions;
+// absolute error of log m below 2e-16 (the turn scan is compared at 1e-9).
+__device__ __forceinline__ double log_pos(double w)
 {
+    int    e;
+    double m = frexp(w, &e);                     // [0.5, 1)
+    const bool lowhalf = m < 0.70710678118654752440;
+    m = lowhalf ? m + m : m;
+    e = lowhalf ? e - 1 : e;
+    const double n = m - 1.0, d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double t = n * r;
+    t = fma(fma(-d, t, n), r, t);
+    const double t2 = t * t;
+    double p = 1.0 / 21.0;
+    p = fma(p, t2, 1.0 / 19.0);
+    p = fma(p, t2, 1.0 / 17.0);
+    p = fma(p, t2, 1.0 / 15.0);
+    p = fma(p, t2, 1.0 / 13.0);
+    p = fma(p, t2, 1.0 / 11.0);
+    p = fma(p, t2, 1.0 / 9.0);
+    p = fma(p, t2, 1.0 / 7.0);
+    p = fma(p, t2, 1.0 / 5.0);
+    p = fma(p, t2, 1.0 / 3.0);
+    p = p * t2;                                  // log m = 2 t (1 + p)
+    const double lm = fma(t + t, p, t + t);
+    const double ed = (double)e;
+    return fma(ed, 0.69314718036912381649, fma(ed, 1.9082149292705877e-10, lm));   // ln 2 split: the high part has 21 trailing zero bits
+}
+
+// Sums over the 8 admissible shift modes of a lane group (lanes differing in bits 0-2) of acc[x] K 2^E for the 16 flips
+// x, as mantissa sums w2[i] relative to 2^e2[i]: lane s returns the flips x = (s0 s1 s2 i), i = 0, 1 (halving exchange:
+// after the step with partner lane ^ 1 a lane keeps the 8 flips whose bit 3 is its s bit 0, then bit 2 <- s bit 1,
+// bit 1 <- s bit 2).  PER_FLIP: the reference exponent is the largest E + exponent(acc[x] K) of the flip (exact for
+// any spread); otherwise the largest E of the group.
+template <bool PER_FLIP>
+__device__ __forceinline__ void turn_group_sums(const double (&acc)[16], double K, int E, bool s_ok, int s, double (&w2)[2], int (&e2)[2])
+{
+    const bool on0 = s_ok && K > 0.0;
+    double mt[16];
+    int    emax[16];
+    if (PER_FLIP) {
+#pragma unroll
+        for (int x = 0; x < 16; x++) {
+            const double kk = acc[x] * K;
+            const bool   on = on0 && kk > 0.0;
+            int          fe;
+            const double fm = frexp(kk, &fe);
+            const int    et = on ? E + fe : -(1 << 29);
+            int          mx = et;
+            mx = max(mx, __builtin_amdgcn_mov_dpp(mx, 0xB1, 0xF, 0xF, true));
+            mx = max(mx, __builtin_amdgcn_mov_dpp(mx, 0x4E, 0xF, 0xF, true));
+            mx = max(mx, __builtin_amdgcn_ds_swizzle(mx, (4 << 10) | 0x1F));
+            emax[x] = mx;
+            const int d = et - mx;
+            mt[x] = (on && d > -1100) ? ldexp(fm, d) : 0.0;
+        }
+    } else {
+        const int Ee = on0 ? E : -(1 << 29);
+        int       mx = Ee;
+        mx = max(mx, __builtin_amdgcn_mov_dpp(mx, 0xB1, 0xF, 0xF, true));
+        mx = max(mx, __builtin_amdgcn_mov_dpp(mx, 0x4E, 0xF, 0xF, true));
+        mx = max(mx, __builtin_amdgcn_ds_swizzle(mx, (4 << 10) | 0x1F));
+        const double Ke = on0 ? K : 0.0;
+        int          d  = Ee - mx;
+        d = d < -2000 ? -2000 : d;
+#pragma unroll
+        for (int x = 0; x < 16; x++) {
+            mt[x]   = ldexp(acc[x] * Ke, d);
+            emax[x] = mx;
+        }
+    }
+    const bool b0 = s & 1, b1 = s & 2, b2 = s & 4;
+    double u[8], t4[4];
+    int    eu[8], e4[4];
+    // (both candidates are read before the choice: a conditional read of an array element would put the array in scratch)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double lo = mt[i], hi = mt[8 + i];
+        const int    el = emax[i], eh = emax[8 + i];
+        u[i]  = (b0 ? hi : lo) + lane_xor1(b0 ? lo : hi);
+        eu[i] = b0 ? eh : el;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double lo = u[i], hi = u[4 + i];
+        const int    el = eu[i], eh = eu[4 + i];
+        t4[i] = (b1 ? hi : lo) + lane_xor2(b1 ? lo : hi);
+        e4[i] = b1 ? eh : el;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double lo = t4[i], hi = t4[2 + i];
+        const int    el = e4[i], eh = e4[2 + i];
+        w2[i] = (b2 ? hi : lo) + lane_xor4(b2 ? lo : hi);
+        e2[i] = b2 ? eh : el;
+    }
+}
+
+#ifndef CNF2_TURN_SPAN
+#define CNF2_TURN_SPAN 8
+#endif
+constexpr int TURN_RS = 66;
+__global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
+{
+    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][16 * TURN_RS];
     const int lane = threadIdx.x & 63;
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int job  = blockIdx.x;
-    const int ml   = blockIdx.y * CNF2_WAVES_PER_BLOCK + wib;
     const KernelParams& p = q.kp;
-    const Job jb = p.jobs[job];
-    if (ml >= jb.last - jb.first + 1) return;
-    const int    m = jb.first + ml;
+    const Job jb  = p.jobs[job];
+    const int len = jb.last - jb.first + 1;
+    const int ml0 = (blockIdx.y * CNF2_WAVES_PER_BLOCK + wib) * CNF2_TURN_SPAN;
+    if (ml0 >= len) return;
+    const int ml1 = (ml0 + CNF2_TURN_SPAN < len) ? ml0 + CNF2_TURN_SPAN : len;
     // the fast kernel's butterflies drop a constant per gap: its reported log-likelihood carries the chromosome's sum of
     // their logarithms, the stored alpha / beta do not
     const double factor = p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] - (q.scaled_transitions ? p.chrom_logk[jb.chrom] : 0.0);
-    const Window w = p.windows[jb.ind];
-    const int s = lane >> 3, lo = state_lo(lane);
-    const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 1040;
-    double A[4][8], B[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double2 va = *(const double2*)(wp + k * 128 + lane * 2);
-        const double2 vb = *(const double2*)(wp + 512 + k * 128 + lane * 2);
-        A[0][2 * k] = va.x;
-        A[0][2 * k + 1] = va.y;
-        B[2 * k] = vb.x;
-        B[2 * k + 1] = vb.y;
-    }
-    const double2 sc = *(const double2*)(wp + 1024 + 2 * s);          // log2 scales of this lane's chain
-    // the four flips of state bits 1, 2 (lane bits through the GF(2) map of the sweep: flip_b1, flip_b2)
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        A[1][j] = lane_flip_b1(A[0][j]);
-        A[2][j] = lane_flip_b2(A[0][j]);
-        A[3][j] = lane_flip_b2(A[1][j]);
-    }
-    double* full = q.rawervals ? q.rawervals + ((size_t)jb.ind * p.n_markers + m) * 1024 : nullptr;
-    double* lse  = q.turn_lse ? q.turn_lse + ((size_t)jb.ind * p.n_markers + m) * 128 : nullptr;
+    const Window& w = p.windows[jb.ind];
+    const int  s = lane & 7, sx = lane >> 3, s2 = s ^ sx;
     const bool s_ok = !(s & w.shiftignore) && s < w.shiftend;
+    const int  n_ok = __builtin_popcountll(__ballot(s_ok) & 0xFFull);
+    double*    L  = lds[wib];
+    // where this lane's loads go: it holds chain lane >> 3, position lane & 7, registers 2k, 2k + 1 of the sweep's layout
+    double*    Lw = L + (lane >> 3) * TURN_RS + (lane & 7) * 8;
+    const double* Ap = L + s * TURN_RS;
+    const double* Bp = L + (8 + s2) * TURN_RS;
+    // turn bits 0, 3, 6 come from sx bits 1, 2, 0
+    const int tshift = ((sx >> 1) & 1) | (((sx >> 2) & 1) << 3) | ((sx & 1) << 6);
+
+    const double floor_r   = (double)CNF2_MINFACTOR_F - factor;
+    const double floor_lse = n_ok > 0 ? floor_r + log((double)n_ok) : -INFINITY;
+
+    d2v va[4], vb[4];
+    d2v scA, scB;
+    auto request = [&](int ml) {
+        const double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * CNF2_TURN_ROW;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            va[k] = __builtin_nontemporal_load((const d2v*)(wp + k * 128 + lane * 2));
+            vb[k] = __builtin_nontemporal_load((const d2v*)(wp + 512 + k * 128 + lane * 2));
+        }
+        scA = *(const d2v*)(wp + 1024 + 4 * s);
+        scB = *(const d2v*)(wp + 1024 + 4 * s2 + 2);
+    };
 #pragma unroll 1
-    for (int sx = 0; sx < 8; sx++) {
-        // B and its scale from the chain this one turns into
-        double Bs[8];
+    for (int ml = ml0; ml < ml1; ml++) {
+        const int m = jb.first + ml;
+        request(ml);
+        wave_lds_fence();                       // the previous marker's reads are done
 #pragma unroll
-        for (int j = 0; j < 8; j++) Bs[j] = __shfl_xor(B[j], sx << 3);
-        const double lgBs = __shfl_xor(sc.y, sx << 3);
-        const double base = (sc.x + lgBs) * 0.69314718055994530942 - factor;
-        // 16 state flips in two groups of 8 turns; turn bits: 0 <- sx bit 1, 3 <- sx bit 2, 6 <- sx bit 0
-        const int tshift = ((sx >> 1) & 1) | (((sx >> 2) & 1) << 3) | ((sx & 1) << 6);
+        for (int k = 0; k < 4; k++) {
+            *(d2v*)(Lw + 2 * k)                = va[k];
+            *(d2v*)(Lw + 8 * TURN_RS + 2 * k) = vb[k];
+        }
+        const double K = scA.x * scB.x;         // scale of this lane's pair of modes: K * 2^E
+        const int    E = (int)scA.y + (int)scB.y;
+        wave_lds_fence();
+        double A[8][8];
 #pragma unroll
-        for (int grp = 0; grp < 2; grp++) {
-            double keep = 0.0;
+        for (int l = 0; l < 8; l++)
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int x = grp * 8 + t;                     // x bit 0 -> state bit 1, 1 -> bit 2, 2 -> bit 4, 3 -> bit 5
-                const int xl = x & 3, xj = (x >> 2) << 1;      // lane flips (b1, b2), register xor on j bits 1, 2
-                double v = 0.0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) v = fma(A[xl][j ^ xj], Bs[j], v);
-                v = chain_sum(v);
-                if (lo == t) keep = v;
+            for (int jj = 0; jj < 4; jj++) {
+                const d2v t = *(const d2v*)(Ap + l * 8 + 2 * jj);
+                A[l][2 * jj]     = t.x;
+                A[l][2 * jj + 1] = t.y;
             }
-            // this lane's turn of the group
-            const int x = grp * 8 + lo;
-            const int turn = tshift | ((x & 1) << 1) | (((x >> 1) & 1) << 2) | (((x >> 2) & 1) << 4) | (((x >> 3) & 1) << 5);
-            const double r = (keep > 0.0) ? base + log(keep) : (double)CNF2_MINFACTOR_F - factor;
-            if (full) full[turn * 8 + s] = r;
-            if (lse) {
-                // log-sum-exp over the admissible shift modes (cnF2freq.cpp:5802-5812), lanes of equal lo across chains
-                const double rv = s_ok ? r : -INFINITY;
-                double mx = fmax(rv, __shfl_xor(rv, 8));
-                mx = fmax(mx, __shfl_xor(mx, 16));
-                mx = fmax(mx, __shfl_xor(mx, 32));
-                mx = fmax(mx, (double)CNF2_MINFACTOR_F);
-                double ex = s_ok ? exp(r - mx) : 0.0;
-                ex += __shfl_xor(ex, 8);
-                ex += __shfl_xor(ex, 16);
-                ex += __shfl_xor(ex, 32);
-                if (s == 0) lse[turn] = mx + log(ex);
+        double acc[16];
+#pragma unroll
+        for (int x = 0; x < 16; x++) acc[x] = 0.0;
+        // B of one position (8 doubles) is requested a position ahead; the scheduling barriers keep the compiler from
+        // pulling all 32 reads to the front (128 registers it does not have)
+        d2v bn[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + 2 * jj);
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            d2v b[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) b[jj] = bn[jj];
+            if (l < 7) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + (l + 1) * 8 + 2 * jj);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    // x bit 0 -> state bit 1 (position ^ 2), 1 -> bit 2 (position ^ 7), 2 -> bit 4, 3 -> bit 5 (registers)
+                    const int Lx = ((x & 1) ? 2 : 0) ^ ((x & 2) ? 7 : 0), Jx = ((x >> 2) & 3) << 1;
+                    acc[x] = fma(A[l ^ Lx][(2 * jj) ^ Jx], b[jj].x, acc[x]);
+                    acc[x] = fma(A[l ^ Lx][(2 * jj + 1) ^ Jx], b[jj].y, acc[x]);
+                }
+            }
+            // the sums are only used under `if (full)` / `if (lse)`: without this the compiler sinks all 1 024 FMAs below
+            // the reads and holds every B value in registers
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                              "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+                         : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double* full = q.rawervals ? q.rawervals + ((size_t)jb.ind * p.n_markers + m) * 1024 : nullptr;
+        double* lse  = q.turn_lse ? q.turn_lse + ((size_t)jb.ind * p.n_markers + m) * 128 : nullptr;
+        if (full) {
+            const double base = (double)E * 0.69314718055994530942 - factor;
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                const int    turn = tshift | ((x & 1) << 1) | (((x >> 1) & 1) << 2) | (((x >> 2) & 1) << 4) | (((x >> 3) & 1) << 5);
+                const double kk   = acc[x] * K;
+                full[turn * 8 + s] = (kk > 0.0) ? base + log_pos(kk) : floor_r;
+            }
+        }
+        if (lse) {
+            // per flip x: sum over the admissible modes s of kk_s 2^E_s.  Usual case: the terms are scaled to the largest
+            // exponent E of the group's admissible modes (one max per marker).  Where a sum comes out below 2^-700 --
+            // every term an exact zero, or the mode with the largest E has no likelihood at this flip and the others sit
+            // hundreds of binary orders below it -- the flips are redone with a maximum per flip (turn_group_sums<true>).
+            double w2[2];
+            int    e2[2];
+            turn_group_sums<false>(acc, K, E, s_ok, s, w2, e2);
+            const bool thin = w2[0] < 0x1p-700 || w2[1] < 0x1p-700;
+            if (__any(thin)) {
+                double w2r[2];
+                int    e2r[2];
+                turn_group_sums<true>(acc, K, E, s_ok, s, w2r, e2r);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+                    if (w2[i] < 0x1p-700) {
+                        w2[i] = w2r[i];
+                        e2[i] = e2r[i];
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int    x    = ((s & 1) << 3) | (((s >> 1) & 1) << 2) | (((s >> 2) & 1) << 1) | i;
+                const int    turn = tshift | ((x & 1) << 1) | (((x >> 1) & 1) << 2) | (((x >> 2) & 1) << 4) | (((x >> 3) & 1) << 5);
+                // no admissible mode with a positive sum: every one of them sits at the floor (cnF2freq.cpp:5802-5812)
+                lse[turn] = (w2[i] > 0.0) ? ((double)e2[i] * 0.69314718055994530942 - factor) + log_pos(w2[i]) : floor_lse;
             }
         }
     }
 }
 void launch_turn_rows(const TurnParams& q, hipStream_t stream)
 {
-    dim3 grid(q.n_jobs, (q.max_len + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+    const int per_block = CNF2_WAVES_PER_BLOCK * CNF2_TURN_SPAN;
+    dim3 grid(q.n_jobs, (q.max_len + per_block - 1) / per_block);
     hipLaunchKernelGGL(turn_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 
