@@ -454,6 +454,7 @@ def main():
     if rank == 0:
         units_per_step = float(n) * M * world
         value = units_per_step * args.steps / dt
+        sweep_clock_mhz = ctx.sweep_clock()          # the last timed launch's own shader / wall clock stamps
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = (float(n) * M * B_UNIT) / (k_ms * 1e-3) / 1e9   # GB/s, this rank's launch
         # HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json, written by
@@ -506,7 +507,10 @@ def main():
         # the shader clock this device runs at under a vector load (boxes differ by several per cent and the sweep is
         # issue-bound, so its time tracks the clock); VALU instructions per unit from the SQ counters where they were
         # measured for these kernel sources (profiles/hbm_traffic.json)
-        clock_mhz = ctx.clock_probe()
+        probe_mhz = ctx.clock_probe()
+        # the kernel's own stamps when its shader-clock counter really counts shader cycles (a constant-rate counter would
+        # read as the wall clock's 100 MHz), else the FMA-loop probe
+        clock_mhz = sweep_clock_mhz if sweep_clock_mhz > 500.0 else probe_mhz
         valu_per_unit = None
         try:
             tj = json.load(open(args.traffic_file))
@@ -536,7 +540,9 @@ def main():
                          "frac_physical": (traffic / (k_ms * 1e-3) / HBM_PEAK) if traffic else None,
                          "kernel": " + ".join(kernels), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha,
-                         "effective_clock_mhz": clock_mhz, "frac_at_2400_mhz": achieved * 1e9 / HBM_PEAK * 2400.0 / clock_mhz,
+                         "effective_clock_mhz": clock_mhz, "sweep_kernel_clock_mhz": sweep_clock_mhz,
+                         "fma_probe_clock_mhz": probe_mhz,
+                         "frac_at_2400_mhz": achieved * 1e9 / HBM_PEAK * 2400.0 / clock_mhz,
                          "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
             "checks": checks,

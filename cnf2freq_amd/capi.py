@@ -31,7 +31,7 @@ SYMBOLS = [
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
-    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_clock_probe", "cnf2_stream",
+    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
 
@@ -119,6 +119,7 @@ def load():
         L.cnf2_workspace_bytes.argtypes = [vp]
         L.cnf2_workspace_bytes.restype = C.c_size_t
         L.cnf2_clock_probe.argtypes = [vp, vp]
+        L.cnf2_sweep_clock.argtypes = [vp, vp]
         L.cnf2_set_grid_reserve.argtypes = [vp, i32]
         L.cnf2_stream.argtypes = [vp]
         L.cnf2_stream.restype = vp
@@ -391,6 +392,12 @@ class Context:
         """Shader clock under a double-precision vector load, MHz."""
         v = C.c_double(0)
         self._chk(self.L.cnf2_clock_probe(self.h, C.byref(v)), "cnf2_clock_probe")
+        return v.value
+
+    def sweep_clock(self):
+        """Shader clock of the last sweep's untied fast-kernel launch (its own counters), MHz; 0 if none ran."""
+        v = C.c_double(0)
+        self._chk(self.L.cnf2_sweep_clock(self.h, C.byref(v)), "cnf2_sweep_clock")
         return v.value
 
     def update_stats(self):

@@ -62,6 +62,10 @@ struct cnf2_ctx {
     size_t  spill_bytes = 0;
     double *d_factors = nullptr, *d_loglik = nullptr, *d_dosage = nullptr;
     size_t  factors_cap = 0, loglik_cap = 0, dosage_cap = 0;
+    int32_t* d_lexp = nullptr;                 // binary exponents of the fast kernel's likelihoods: [n][C][8] then [n][C]
+    size_t   lexp_cap = 0;
+    unsigned long long* d_clock = nullptr;     // [4] clock stamps of the last plain fast-kernel launch
+    size_t   clock_cap = 0;
     double* d_scratch = nullptr;     // small parity buffers
     size_t  scratch_cap = 0;
 
@@ -203,6 +207,8 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_spill);
     (void)hipFree(ctx->d_factors);
     (void)hipFree(ctx->d_loglik);
+    (void)hipFree(ctx->d_lexp);
+    (void)hipFree(ctx->d_clock);
     (void)hipFree(ctx->d_dosage);
     (void)hipFree(ctx->d_scratch);
     (void)hipFree(ctx->d_slot_rec);
@@ -494,7 +500,15 @@ static int ready(cnf2_ctx* ctx)
     if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0)
         return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return prepare_windows(ctx);
+    int rc = prepare_windows(ctx);
+    if (rc) return rc;
+    const size_t ne = ctx->windows.size() * (size_t)ctx->n_chrom;
+    if ((rc = ensure(ctx, &ctx->d_lexp, &ctx->lexp_cap, ne * 9 + 1))) return rc;
+    if (!ctx->d_clock) {
+        if ((rc = ensure(ctx, &ctx->d_clock, &ctx->clock_cap, (size_t)4))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_clock, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    }
+    return CNF2_OK;
 }
 
 static void base_params(cnf2_ctx* ctx, KernelParams* p)
@@ -509,6 +523,8 @@ static void base_params(cnf2_ctx* ctx, KernelParams* p)
     p->chrom_logk = ctx->d_logk;
     p->n_markers = ctx->n_markers;
     p->n_chrom   = ctx->n_chrom;
+    p->fexp      = ctx->d_lexp;
+    p->lexp      = ctx->d_lexp + ctx->windows.size() * (size_t)ctx->n_chrom * 8;
 }
 
 static int max_chrom_len(const cnf2_ctx* ctx)
@@ -700,8 +716,10 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     }
     if (n_fast > 0) {
         int gf = (int)((n_fast + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
+        p.clock_out = ctx->d_clock;
         if ((flags & CNF2_XPOSE) && !(flags & CNF2_FULL_SPILL)) launch_fb_fast_xpose(p, gf < grid_fast ? gf : grid_fast, ctx->stream);
         else launch_fb_fast(p, gf < grid_fast ? gf : grid_fast, !(flags & CNF2_FULL_SPILL), ctx->stream);
+        p.clock_out = nullptr;
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_general > 0) {
@@ -750,6 +768,21 @@ int cnf2_last_kernel_ms(cnf2_ctx* ctx, float* kernel_ms, int n)
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     kernel_ms[0] = ms;
     for (int i = 1; i < n; i++) kernel_ms[i] = 0;
+    return CNF2_OK;
+}
+
+int cnf2_sweep_clock(cnf2_ctx* ctx, double* mhz_out)
+{
+    if (!ctx || !mhz_out) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *mhz_out = 0.0;
+    if (!ctx->d_clock) return CNF2_OK;
+    unsigned long long t[2] = {0, 0};
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(t, ctx->d_clock, sizeof(t), hipMemcpyDeviceToHost));
+    int khz = 0;
+    HIP_TRY(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (t[1] > 0 && khz > 0) *mhz_out = (double)t[0] / (double)t[1] * (double)khz * 1e-3;
     return CNF2_OK;
 }
 

@@ -71,7 +71,16 @@ struct KernelParams {
     // which kernel / producer specialisation swept a job (tests): [n_ind][n_chrom], 0-3 = fast kernel with that `hom`
     // class, 32 | homleaf = packed kernel, 64 = general kernel; NULL = not recorded
     int32_t*       path_log;
+    // fast kernel: the likelihoods leave the sweep as mantissa (in factors / loglik) and binary exponent (here); the
+    // logarithms are taken by likelihood_logs_kernel right after it, so that no transcendental sits in the sweep kernel.
+    // [n_ind][n_chrom][8] and [n_ind][n_chrom]; CNF2_LEXP_* mark chains / jobs without a likelihood
+    int32_t*       fexp;
+    int32_t*       lexp;
+    // [4] or NULL: shader-clock and wall-clock ticks of block 0's first wave (launch_fb_fast: the bench's effective clock)
+    unsigned long long* clock_out;
 };
+#define CNF2_LEXP_IGNORED (-2147483647 - 1)   /* shift mode not analysed: CNF2_IGNORED_D */
+#define CNF2_LEXP_DEAD    (-2147483647)       /* no likelihood left: CNF2_MINFACTOR_F */
 enum { PATH_TIED = 16, PATH_PACKED = 32, PATH_GENERAL = 64 };
 
 // Inputs of the batched HOT LOOP 2 kernel (acc_rows_kernel): the weights a STOREW sweep left for `n_jobs` jobs and

@@ -77,8 +77,22 @@ __device__ __forceinline__ double lane_flip_b1(double v) { return swizzle_xor<2>
 __device__ __forceinline__ double lane_flip_b2(double v) { return swizzle_xor<7>(v); }
 #endif
 __device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_all<0x128>(v); } // row_ror:8
-__device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16); }
-__device__ __forceinline__ double lane_xor32(double v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ double lane_xor16(double v) { return swizzle_xor<16>(v); }
+// lane id of a full wavefront, recomputed where it is asked for (volatile: not hoisted out of a job loop, where it would
+// occupy a register -- or a scratch slot -- for the whole kernel)
+__device__ __forceinline__ int fresh_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+__device__ __forceinline__ double lane_xor32(double v)
+{
+    const int a  = (fresh_lane() ^ 32) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // sum over the 8 lanes of a chain (lanes differing in bits 0-2); result in every lane.
 // Third step pairs lane i with lane 7-i of its group of 8 (row_half_mirror): after the two quad
@@ -860,15 +874,24 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
     __shared__ __attribute__((aligned(16))) double xlds[XPOSE ? CNF2_WAVES_PER_BLOCK : 1][XPOSE ? 64 * XPOSE_RS : 2];
     __shared__ double tsum[TIED ? CNF2_WAVES_PER_BLOCK : 1][TIED ? 24 : 1];     // TIED: class sums of the tile's markers over the combinations
 
-    const int lane  = threadIdx.x & 63;
     const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
     const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
     double*   tab   = lds[wib];
     double*   xb    = xlds[XPOSE ? wib : 0];
     double*   spill = p.spill + (size_t)wave * p.spill_stride;
+    // shader-clock and wall-clock ticks of the first wave (the bench's effective clock of this very kernel)
+    const bool stamp = p.clock_out != nullptr && wave == 0;
+    unsigned long long t_shader = 0, t_wall = 0;
+    if (stamp) {
+        t_shader = __builtin_readcyclecounter();
+        t_wall   = wall_clock64();
+    }
 
     for (int job = wave; job < p.n_jobs; job += nwave) {
+        // the lane number read afresh, as a value the compiler cannot see through: what is derived from it is formed per
+        // job, where it is used, instead of being held in registers (or spilled) for the whole kernel
+        const int lane = fresh_lane();
         const Job    jb = p.jobs[job];
         const Window w  = p.windows[jb.ind];
         FastCtx      c;
@@ -987,18 +1010,32 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         }
 
         // ---------------------------------------------------------------- likelihoods
-        // the butterflies dropped (1-r0)^4 (1-r1)^2 per gap: its logarithm over the chromosome comes back here
-        const double logk = p.chrom_logk[jb.chrom];
-        double fs = dead ? (double)CNF2_MINFACTOR_F : (log(mant) + (double)expo * 0.69314718055994530942);
-        if (!c.active) fs = CNF2_IGNORED_D;
-        double fmaxv = across_chains_max(fs);
-        fmaxv        = fmax(fmaxv, -1e15);
-        double term  = c.active ? exp(fs - fmaxv) : 0.0;
-        double real  = across_chains_sum(term);
-        double factor = fmaxv + log(real);
-        if (c.lo == 0) p.factors[((size_t)jb.ind * p.n_chrom + jb.chrom) * 8 + s] = (c.active && !dead) ? fs + logk : fs;
-        if (lane == 0) p.loglik[(size_t)jb.ind * p.n_chrom + jb.chrom] = (fmaxv > -1e14) ? factor + logk : factor;
-        const bool skip = isnan(factor) || factor < (double)CNF2_MINFACTOR_F;     // cnF2freq.cpp:5403
+        // P(data, mode s) = mant 2^expo per chain.  Everything the backward pass needs of them is exact binary scaling:
+        // with T = sum over the live chains of mant 2^(expo - emax), exp(-factor) = (1 / T) 2^-emax, and the reference's
+        // "40 below the total" rule (cnF2freq.cpp:5420-5421) compares a chain's term with T.  The logarithms the
+        // outputs hold (and the chromosome's dropped butterfly constants) are taken by likelihood_logs_kernel after the
+        // sweep: the sweep kernel has no transcendental and none of their constants in its registers.
+        const bool   alive  = c.active && !dead;
+        const double emaxd  = across_chains_max(alive ? (double)expo : -1e300);
+        const bool   any_alive = emaxd > -1e299;
+        const int    emax   = any_alive ? (int)emaxd : 0;
+        int          dsh    = expo - emax;
+        dsh                 = dsh < -2000 ? -2000 : dsh;
+        const double tmine  = alive ? ldexp(mant, dsh) : 0.0;
+        const double T      = across_chains_sum(tmine);
+        {
+            const size_t e = (size_t)jb.ind * p.n_chrom + jb.chrom;
+            const int    n_active = __builtin_popcountll(__ballot(c.active)) >> 3;
+            if (c.lo == 0) {
+                p.factors[e * 8 + s] = mant;
+                p.fexp[e * 8 + s]    = alive ? expo : (c.active ? CNF2_LEXP_DEAD : CNF2_LEXP_IGNORED);
+            }
+            if (lane == 0) {
+                // no live chain: every analysed mode sits at the floor, the total is the floor + log(their number)
+                p.loglik[e] = any_alive ? T : (double)n_active;
+                p.lexp[e]   = any_alive ? emax : CNF2_LEXP_DEAD;
+            }
+        }
         if (p.flags & KP_NO_DOSAGE) continue;
 
         // ---------------------------------------------------------------- backward + rows
@@ -1015,12 +1052,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         S.bdead = false;
         S.fmant = mant;          // becomes Fpre(m) after multiplying the reciprocals of k >= m
         S.fexpo = expo;
-        // exp(-factor) = xm * 2^xe
-        const double nf  = -factor * 1.4426950408889634074;
-        const double nfk = floor(nf);
-        const double xm  = exp2(nf - nfk);
-        const int    xe  = (int)nfk;
-        const bool   chain_on = c.active && !skip && !dead && !(factor - fs > 40.0);   // cnF2freq.cpp:5420-5421
+        // exp(-factor) = xm * 2^xe; a job without a live chain has no rows (cnF2freq.cpp:5403)
+        const double xm  = any_alive ? 1.0 / T : 0.0;
+        const int    xe  = -emax;
+        const bool   chain_on = alive && !(tmine * 2.3538526683701998e17 < T);        // factor - fs > 40: cnF2freq.cpp:5420-5421
         // software pipeline: the spill row (and its reciprocals) is requested one row ahead, straight into
         // the registers it is used from; nothing else in the marker loop is a vector memory operation
         auto load_row = [&](int idx) {
@@ -1270,6 +1305,38 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
           }
         }
     }
+    if (stamp && fresh_lane() == 0) {
+        p.clock_out[0] = __builtin_readcyclecounter() - t_shader;
+        p.clock_out[1] = wall_clock64() - t_wall;
+    }
+}
+
+// The logarithms of the likelihoods a fast-kernel launch left as mantissa and binary exponent: one thread per (job, shift
+// mode), thread 0 of a job also the job's total.  Adds the chromosome's dropped butterfly constants (chrom_logk).
+__global__ __launch_bounds__(256) void likelihood_logs_kernel(KernelParams p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_jobs * 8) return;
+    const Job    jb   = p.jobs[t >> 3];
+    const int    s    = t & 7;
+    const size_t e    = (size_t)jb.ind * p.n_chrom + jb.chrom;
+    const double logk = p.chrom_logk[jb.chrom];
+    const double ln2  = 0.69314718055994530942;
+    const int    fe   = p.fexp[e * 8 + s];
+    double       fs;
+    if (fe == CNF2_LEXP_IGNORED) fs = CNF2_IGNORED_D;
+    else if (fe == CNF2_LEXP_DEAD) fs = (double)CNF2_MINFACTOR_F;
+    else fs = log(p.factors[e * 8 + s]) + (double)fe * ln2 + logk;
+    p.factors[e * 8 + s] = fs;
+    if (s == 0) {
+        const int    le = p.lexp[e];
+        const double T  = p.loglik[e];
+        p.loglik[e] = (le == CNF2_LEXP_DEAD) ? (double)CNF2_MINFACTOR_F + log(T) : log(T) + (double)le * ln2 + logk;
+    }
+}
+static void launch_likelihood_logs(const KernelParams& p, hipStream_t stream)
+{
+    if (p.n_jobs > 0) hipLaunchKernelGGL(likelihood_logs_kernel, dim3((p.n_jobs * 8 + 255) / 256), dim3(256), 0, stream, p);
 }
 
 // =====================================================================================
@@ -3285,19 +3352,23 @@ void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
 void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 0, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 1, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 0, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream)
 {
     if (half_spill) hipLaunchKernelGGL(fb_fast_kernel<true>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL(fb_fast_kernel<false>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 
 void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, int n_markers, uint8_t* flags,
@@ -3309,6 +3380,7 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)
 {
@@ -3317,6 +3389,7 @@ void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)
 void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL((fb_fast_kernel<true, 2>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    launch_likelihood_logs(p, stream);
 }
 void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream)
 {
@@ -3331,7 +3404,7 @@ void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream)
 //     rawervals[turn][s] = log sum_k A_s(k ^ (turn & 54)) B_{s ^ shiftx}(k) + scales - factor:
 // per (job, marker) 64 pairs of shift modes (s, s ^ sx) x 16 flips of state bits 1, 2, 4, 5 = 1 024 dot products of
 // 64 terms -- 131 072 flops on 8.4 KB read: the kernel is bound by the f64 FMA rate, not by HBM.
-// One wavefront per (job, marker), lane = sx << 3 | s.  The sweep's rows go through LDS once ([chain][l][j], rows
+// One wavefront per (job, marker), lane = sx << 3 | s.  The sweep's rows go through LDS once ([chain][k][l][2], rows
 // padded to 66 doubles so that the 8 chains a read touches sit in different banks); a lane keeps its A_s whole in
 // registers (64 doubles), streams B_{s ^ sx} from LDS (one 16-byte read per 32 FMAs) and runs 16 accumulators, one
 // per flip: the flips are register renaming (A[l ^ L(x)][j ^ J(x)] with compile-time indices), there is no
@@ -3467,7 +3540,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
     const int  n_ok = __builtin_popcountll(__ballot(s_ok) & 0xFFull);
     double*    L  = lds[wib];
     // where this lane's loads go: it holds chain lane >> 3, position lane & 7, registers 2k, 2k + 1 of the sweep's layout
-    double*    Lw = L + (lane >> 3) * TURN_RS + (lane & 7) * 8;
+    // (a chain's row is [k][l][2]: the 8 lanes a ds_write_b128 serves together cover the 32 banks)
+    double*    Lw = L + (lane >> 3) * TURN_RS + (lane & 7) * 2;
     const double* Ap = L + s * TURN_RS;
     const double* Bp = L + (8 + s2) * TURN_RS;
     // turn bits 0, 3, 6 come from sx bits 1, 2, 0
@@ -3495,8 +3569,8 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
         wave_lds_fence();                       // the previous marker's reads are done
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            *(d2v*)(Lw + 2 * k)                = va[k];
-            *(d2v*)(Lw + 8 * TURN_RS + 2 * k) = vb[k];
+            *(d2v*)(Lw + 16 * k)                = va[k];
+            *(d2v*)(Lw + 8 * TURN_RS + 16 * k) = vb[k];
         }
         const double K = scA.x * scB.x;         // scale of this lane's pair of modes: K * 2^E
         const int    E = (int)scA.y + (int)scB.y;
@@ -3506,7 +3580,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
         for (int l = 0; l < 8; l++)
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                const d2v t = *(const d2v*)(Ap + l * 8 + 2 * jj);
+                const d2v t = *(const d2v*)(Ap + jj * 16 + l * 2);
                 A[l][2 * jj]     = t.x;
                 A[l][2 * jj + 1] = t.y;
             }
@@ -3517,7 +3591,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
         // pulling all 32 reads to the front (128 registers it does not have)
         d2v bn[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + 2 * jj);
+        for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16);
 #pragma unroll
         for (int l = 0; l < 8; l++) {
             d2v b[4];
@@ -3525,7 +3599,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
             for (int jj = 0; jj < 4; jj++) b[jj] = bn[jj];
             if (l < 7) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + (l + 1) * 8 + 2 * jj);
+                for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16 + (l + 1) * 2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

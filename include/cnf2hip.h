@@ -309,6 +309,10 @@ size_t cnf2_workspace_bytes(cnf2_ctx *ctx);
  * one wave-wide FMA issues per 4 cycles).  Boxes of the same model differ by several per cent; an issue-bound kernel
  * tracks this clock, so bench.py reports it next to the roofline fraction. */
 int    cnf2_clock_probe(cnf2_ctx *ctx, double *mhz_out);
+/* Shader clock of the last cnf2_sweep's untied fast-kernel launch itself, MHz: its first wave reads the shader-clock
+ * counter and the constant-rate wall clock when it starts and when it ends (s_memtime / s_memrealtime); 0 when no such
+ * launch has run.  Synchronises the context's stream. */
+int    cnf2_sweep_clock(cnf2_ctx *ctx, double *mhz_out);
 void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
 /* The sweep kernels are persistent (one resident wave per job in flight) and normally fill every
  * workgroup slot of the GPU.  Leaving `blocks` slots free lets another kernel -- the RCCL gather of

