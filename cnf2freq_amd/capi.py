@@ -31,7 +31,7 @@ SYMBOLS = [
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
-    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
+    "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
     "cnf2_set_grid_reserve",
 ]
 
@@ -101,6 +101,7 @@ def load():
         L.cnf2_descendants.argtypes = [vp, vp]
         L.cnf2_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.c_uint32]
         L.cnf2_sweep_accumulate.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
+        L.cnf2_reserve_accumulate.argtypes = [vp, i32, i32, C.c_uint32]
         L.cnf2_sweep_turn_scan.argtypes = [vp, i32, i32, vp, vp, C.c_uint32]
         L.cnf2_fixparents_scan.argtypes = [vp, vp, i32, vp]
         L.cnf2_variances.argtypes = [vp, vp, i32, i32, vp]

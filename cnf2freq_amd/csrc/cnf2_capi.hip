@@ -1021,6 +1021,8 @@ int cnf2_descendants(cnf2_ctx* ctx, int32_t* desc_out)
     return CNF2_OK;
 }
 
+enum : uint32_t { ACC_RESERVE_ONLY = 1u << 31 };     // internal flag of cnf2_sweep_accumulate (not in the header)
+
 // Batched HOT LOOP 2 with its reductions (cnF2freq.cpp:5416-5577, 5876-5902 with moveinfprobs / movehaplos
 // 3577-3616) for the analysed individuals [ind_begin, ind_end): the sweep kernels run in their accumulate
 // instantiation (they leave the posterior weights wg(s, g) of every marker in a batch buffer next to the usual
@@ -1036,7 +1038,8 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
     const bool out_dev = (flags & CNF2_OUT_DEVICE) != 0, acc_dev = (flags & CNF2_ACC_DEVICE) != 0;
     const bool acc_given = infprobs && haplobase && haplocount && homozyg;
     const bool acc_none = !infprobs && !haplobase && !haplocount && !homozyg;    // keep them in the context
-    if (!descendants || (!acc_given && !(acc_none && !acc_dev)) || ind_begin < 0 || ind_end > n_all || ind_begin > ind_end)
+    const bool reserve_only = (flags & ACC_RESERVE_ONLY) != 0;      // cnf2_reserve_accumulate: allocations only
+    if ((!descendants && !reserve_only) || (!acc_given && !(acc_none && !acc_dev)) || ind_begin < 0 || ind_end > n_all || ind_begin > ind_end)
         return fail(ctx, CNF2_ERR_ARG, "bad accumulate arguments");
     if (out_dev && (!factors_out || !loglik_out || !dosage_out)) return fail(ctx, CNF2_ERR_ARG, "output pointer is NULL");
     const HostPedigree& P = ctx->ped;
@@ -1055,7 +1058,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rec_empty, R));
         ctx->rec_cap = R;
     }
-    HIP_TRY(ctx, hipMemcpy(ctx->d_desc, descendants, sizeof(int32_t) * R, hipMemcpyHostToDevice));
+    if (descendants) HIP_TRY(ctx, hipMemcpy(ctx->d_desc, descendants, sizeof(int32_t) * R, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_rec_empty, P.empty.data(), R, hipMemcpyHostToDevice));
 
     // accumulators and sweep outputs
@@ -1138,6 +1141,10 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 fprintf(stderr, "  [sweep_accumulate] batch buffer of %.1f GB allocated in %.3f s (%zu jobs per batch of %zu)\n",
                         batch * per_job * 8 / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), batch,
                         jobs.size());
+        }
+        if (reserve_only) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return CNF2_OK;
         }
 
         KernelParams p;
@@ -1232,6 +1239,17 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
     }
     if (!out_dev || !acc_dev) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNF2_OK;
+}
+
+// The allocations of cnf2_sweep_accumulate for [ind_begin, ind_end) without the sweep: accumulators, outputs, spill and the
+// batch buffer of posterior weights (up to half of the free memory: a first hipMalloc of that size takes seconds on a
+// fresh device, 4.3 s for 125 GB measured).  A run calls this once after its uploads, so that its first iteration costs
+// what the others cost.
+int cnf2_reserve_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, uint32_t flags)
+{
+    const uint32_t keep = flags & (CNF2_NO_TIES | CNF2_DETERMINISTIC | CNF2_TIES_GENERAL);
+    return cnf2_sweep_accumulate(ctx, ind_begin, ind_end, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 keep | ACC_RESERVE_ONLY);
 }
 
 // Batched turn scan (HOT LOOP 3, cnF2freq.cpp:5686-5752) for the analysed individuals [ind_begin, ind_end): the sweep

@@ -38,6 +38,9 @@ void Engine::upload()
     children_.assign(P.inds.size(), 0);
     variances_.assign(P.inds.size() * (size_t)M, 0.0);
     lockstart_.assign(P.inds.size() * (size_t)(C > 0 ? C : 1), 0);
+    // the device buffers of the iterations now, not inside the first one (the batch buffer of the accumulate sweep is up to
+    // half of the free memory; its first hipMalloc takes seconds)
+    if (opt.update && N > 0) check(cnf2_reserve_accumulate(ctx, 0, N, 0), "cnf2_reserve_accumulate");
 }
 
 // rows travel in slabs of records: the staging copy stays bounded (config 4: 300 000 records x 200 080 markers would be

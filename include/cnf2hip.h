@@ -215,6 +215,10 @@ int cnf2_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *de
 int cnf2_sweep_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *descendants, double *factors_out,
                           double *loglik_out, double *dosage_out, double *infprobs, double *haplobase,
                           double *haplocount, double *homozyg, uint32_t flags);
+/* The allocations a later cnf2_sweep_accumulate(ind_begin, ind_end, ..., flags) makes -- accumulators, outputs, spill rows and
+ * the batch buffer of posterior weights (sized to half of the free device memory; a first hipMalloc of that size takes
+ * seconds) -- without the sweep, so that a run's first iteration (doit, cnF2freq.cpp:5294) costs what the others cost. */
+int cnf2_reserve_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, uint32_t flags);
 
 /* Batched turn scan (HOT LOOP 3; cnF2freq.cpp:5686-5752 with aroundturner 498-554): for every
  * analysed individual in [ind_begin, ind_end) and every marker,

@@ -64,6 +64,10 @@ for rep in range(2):
 print("turn scan          %.3f s for %d individuals  %.3g units/s (%.1f x sweep per unit)   lse[0,0,0]=%.6f"
       % (t_turn, nt, nt * M / t_turn, (t_turn / (nt * M)) / (t_sweep / units), float(lse[0, 0, 0].item())), flush=True)
 del lse
+# the allocations of the accumulate sweep before the first iteration (what the engine does after its uploads)
+t = time.time()
+ctx._chk(ctx.L.cnf2_reserve_accumulate(ctx.h, 0, n, 0), "cnf2_reserve_accumulate")
+print("reserve            %.3f s (batch buffer of the accumulate sweep: a first hipMalloc of half the free memory)" % (time.time() - t), flush=True)
 sf = float(sys.argv[5]) if len(sys.argv) > 5 else 0.013
 upd_flags = capi.ACC_DEVICE | (capi.UPDATE_PLAIN if len(sys.argv) > 6 and sys.argv[6] == "plain" else 0)
 for it in range(iters):
