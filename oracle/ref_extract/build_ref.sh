@@ -6,8 +6,25 @@
 # The whole reference is NOT buildable here (Boost, xstd/bit_set.hpp and toulbar2
 # are absent, cnF2freq.cpp:49-89,142-144), so the translation unit is assembled
 # by LINE RANGE from cnF2freq.cpp into a temp dir outside the repository,
-# compiled, and deleted.  No reference text enters /root/repo; only the shared
-# object lands in oracle/_ref/ (git-ignored, travels with gpurun).
+# compiled, and deleted: the functions of the path (emission, recursions, HOT LOOP
+# accumulators' helpers, postmarkerdata, the update functions) enter the build only
+# that way, and only the shared object lands in oracle/_ref/ (git-ignored, travels
+# with gpurun).
+#
+# What IS in the repository and follows the reference closely: ref_driver.inc, our
+# driver, replays the loop bodies of doit<> around those functions (the per-locus
+# fan-out and reductions of HOT LOOP 2, cpp:5513-5577 and 5876-5902; the
+# per-chromosome update pass and step-size control, cpp:6232-6392).  doit<> itself
+# cannot be taken by line range (it reads the toulbar2 / MPI / OpenMP scaffolding
+# around it), so these bodies are re-typed statement by statement next to the line
+# numbers they follow.  That file is therefore NOT free of reference-shaped text; it
+# is test infrastructure under oracle/, never compiled into the product, and the
+# reason the oracle's formal status stays "parity unpinned" (stand-in driver).
+#
+# Second stand-in (round 3): boost_gauss_shim.h supplies
+# boost::math::quadrature::gauss<double, 15>::integrate for cpp:4150 (Boost.Math is
+# not in the image): the published 15-point Gauss-Legendre rule, checked against
+# numpy's leggauss(15).
 #
 # Disclosure (DESIGN.md "Oracle"): two container names the extract mentions
 # (boost flat_map / the small_map alias of cpp:367) are aliased to std::map in
