@@ -20,6 +20,7 @@ ACC_LANES = 2048
 TIES_GENERAL = 4096
 UPDATE_PLAIN = 8192
 DETERMINISTIC = 16384
+TURN_VALU = 32768
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -349,14 +350,15 @@ class Context:
                                                C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
                                                flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
 
-    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True, ties_general=False):
+    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True, ties_general=False, valu=False):
         """Batched turn scan: rawervals [n][M][128][8] and / or their log-sum-exp over the admissible modes [n][M][128]."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         raw = np.zeros((n, self.n_markers, 128, 8)) if full else None
         ls = np.zeros((n, self.n_markers, 128)) if lse else None
         self._chk(self.L.cnf2_sweep_turn_scan(self.h, ind_begin, ind_end, _p(raw) if full else None, _p(ls) if lse else None,
-                                              (0 if ties else NO_TIES) | (TIES_GENERAL if ties_general else 0)),
+                                              (0 if ties else NO_TIES) | (TIES_GENERAL if ties_general else 0)
+                                              | (TURN_VALU if valu else 0)),
                   "cnf2_sweep_turn_scan")
         return raw, ls
 

@@ -814,7 +814,7 @@ size_t cnf2_workspace_bytes(cnf2_ctx* ctx)
 {
     if (!ctx) return 0;
     return ctx->spill_bytes + ctx->jobs_cap * sizeof(Job) +
-           (ctx->factors_cap + ctx->loglik_cap + ctx->dosage_cap + ctx->scratch_cap) * sizeof(double);
+           (ctx->factors_cap + ctx->loglik_cap + ctx->dosage_cap + ctx->scratch_cap + ctx->wbuf_cap) * sizeof(double);
 }
 
 // Runs fb_kernel<true> for one individual x chromosome and leaves the reference-layout store in the
@@ -1340,6 +1340,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     q.max_len   = mlen;
     q.rawervals = d_full;
     q.turn_lse  = d_lse;
+    q.valu_form = (flags & CNF2_TURN_VALU) ? 1 : 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int pass = 0; pass < 2; pass++) {
         const size_t lo = pass ? n_fast : 0, hi = pass ? jobs.size() : n_fast;

@@ -156,6 +156,7 @@ struct TurnParams {
     KernelParams kp;
     int          n_jobs, max_len;
     int          scaled_transitions;   // the batch came from the fast kernel (log-likelihoods include chrom_logk)
+    int          valu_form;            // the dot products on the vector ALU instead of the matrix cores (cross-check, A/B)
     double*      rawervals;   // [n_ind][n_markers][128][8] or NULL
     double*      turn_lse;    // [n_ind][n_markers][128] or NULL
 };

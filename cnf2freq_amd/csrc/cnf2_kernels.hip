@@ -3519,9 +3519,24 @@ __device__ __forceinline__ void turn_group_sums(const double (&acc)[16], double 
 #define CNF2_TURN_SPAN 8
 #endif
 constexpr int TURN_RS = 66;
-__global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
+// MFMA form: the 1 024 dot products of a unit are one 32 x 32 x 64 product C[(s, xa)][(s2, xb)] = sum_k A_s(k ^ F(xa))
+// B_s2(k ^ F(xb)) -- the flip x = xa | xb << 2 splits into the two that move the lane-held state bits (on A) and the two
+// that move the register-held ones (on B) -- run as 2 x 2 tiles x 16 k-steps of v_mfma_f64_16x16x4_f64.  The operands come
+// from LDS images in which every state coordinate is an address bit of a chain's 512-byte row (the four a flip can move --
+// fp, fq of the lane position, j1, j2 of the register index -- and the two none moves), so a flip is an XOR on the address;
+// the coordinate the lane's own flip bit moves sits at 16 bytes, rows are 544 bytes apart: the 32 lanes a ds_read_b64 serves
+// together then cover the 64 banks, and every read is the lane's base address (one of two, by that coordinate) plus an
+// immediate.  The sums leave through a [s][s2][x] image in
+// the same LDS and are read back by the lanes in the layout the rest of the kernel works in.
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int TURN_MRS = 68;          // doubles per chain row of the MFMA images (544 bytes)
+constexpr int TURN_CS  = 18;          // doubles per (s, s2) cell of the image the sums leave through
+constexpr int TURN_LDS_VALU = 16 * TURN_RS, TURN_LDS_MFMA = 64 * TURN_CS;
+template <bool MFMA>
+__global__ __launch_bounds__(CNF2_BLOCK, MFMA ? 4 : 2) void turn_rows_kernel(TurnParams q)
 {
-    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][16 * TURN_RS];
+    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][MFMA ? TURN_LDS_MFMA : TURN_LDS_VALU];
+    static_assert(16 * TURN_MRS <= TURN_LDS_MFMA, "the operand images and the image of the sums share the LDS");
     const int lane = threadIdx.x & 63;
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int job  = blockIdx.x;
@@ -3546,6 +3561,25 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
     const double* Bp = L + (8 + s2) * TURN_RS;
     // turn bits 0, 3, 6 come from sx bits 1, 2, 0
     const int tshift = ((sx >> 1) & 1) | (((sx >> 2) & 1) << 3) | ((sx & 1) << 6);
+    // MFMA form, byte offsets in the wave's LDS.  Loading role (chain lane >> 3, position l = lane & 7): the coordinates of
+    // l that the position flips move -- fp (l ^ 2 flips it), fq (l ^ 7 flips it) -- and the one they leave alone, fu.
+    int wA = 0, wB = 0, rAe = 0, rAo = 0, rBe = 0, rBo = 0, wC = 0, rC = 0;
+    if (MFMA) {
+        const int l = lane & 7, ch = lane >> 3;
+        const int fp = ((l >> 1) ^ l) & 1, fq = l & 1, fu = (l ^ (l >> 2)) & 1;
+        wA = ch * TURN_MRS * 8 + fp * 16 + fq * 32 + fu * 64;                      // + j1 * 128 + j2 * 256; j0 inside the 16 bytes
+        wB = (8 + ch) * TURN_MRS * 8 + fp * 32 + fu * 64 + fq * 128;               // + j1 * 16 + j2 * 256
+        // operand role: row / column lane & 15 = (mode lane & 7, low flip bit lane >> 3 & 1), k within the step = lane >> 4
+        const int so = lane & 7, xbit = (lane >> 3) & 1, g = lane >> 4;
+        const int baseA = so * TURN_MRS * 8 + (g >> 1) * 64 + (g & 1) * 8, baseB = baseA + 8 * TURN_MRS * 8;
+        rAe = baseA + xbit * 16;      // slot c even: (c ^ xbit) * 16 = c * 16 + xbit * 16
+        rAo = baseA - xbit * 16;      //        odd:                  = c * 16 - xbit * 16
+        rBe = baseB + xbit * 16;
+        rBo = baseB - xbit * 16;
+        // sums: this lane holds column (s2 = lane & 7, xb bit 0 = lane >> 3 & 1), rows (lane >> 4) + 4 reg
+        wC = ((g * 8 + so) * TURN_CS + xbit) * 8;
+        rC = (s * 8 + s2) * TURN_CS * 8;
+    }
 
     const double floor_r   = (double)CNF2_MINFACTOR_F - factor;
     const double floor_lse = n_ok > 0 ? floor_r + log((double)n_ok) : -INFINITY;
@@ -3566,58 +3600,109 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void turn_rows_kernel(TurnParams q)
     for (int ml = ml0; ml < ml1; ml++) {
         const int m = jb.first + ml;
         request(ml);
-        wave_lds_fence();                       // the previous marker's reads are done
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            *(d2v*)(Lw + 16 * k)                = va[k];
-            *(d2v*)(Lw + 8 * TURN_RS + 16 * k) = vb[k];
-        }
         const double K = scA.x * scB.x;         // scale of this lane's pair of modes: K * 2^E
         const int    E = (int)scA.y + (int)scB.y;
-        wave_lds_fence();
-        double A[8][8];
-#pragma unroll
-        for (int l = 0; l < 8; l++)
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const d2v t = *(const d2v*)(Ap + jj * 16 + l * 2);
-                A[l][2 * jj]     = t.x;
-                A[l][2 * jj + 1] = t.y;
-            }
         double acc[16];
+        if constexpr (MFMA) {
+            wave_lds_fence();                   // the previous marker's read-back is done
 #pragma unroll
-        for (int x = 0; x < 16; x++) acc[x] = 0.0;
-        // B of one position (8 doubles) is requested a position ahead; the scheduling barriers keep the compiler from
-        // pulling all 32 reads to the front (128 registers it does not have)
-        d2v bn[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16);
-#pragma unroll
-        for (int l = 0; l < 8; l++) {
-            d2v b[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) b[jj] = bn[jj];
-            if (l < 7) {
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16 + (l + 1) * 2);
+            for (int k = 0; k < 4; k++) {
+                *(d2v*)((char*)L + wA + ((k & 1) << 7) + ((k >> 1) << 8))  = va[k];      // j bits 1, 2 at 128, 256
+                *(d2v*)((char*)L + wB + ((k & 1) << 4) + ((k >> 1) << 8))  = vb[k];      // j bits 1, 2 at 16, 256
             }
-            __builtin_amdgcn_sched_barrier(0);
+            wave_lds_fence();
+            d4v c4[2][2];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
+            for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                for (int x = 0; x < 16; x++) {
-                    // x bit 0 -> state bit 1 (position ^ 2), 1 -> bit 2 (position ^ 7), 2 -> bit 4, 3 -> bit 5 (registers)
-                    const int Lx = ((x & 1) ? 2 : 0) ^ ((x & 2) ? 7 : 0), Jx = ((x >> 2) & 3) << 1;
-                    acc[x] = fma(A[l ^ Lx][(2 * jj) ^ Jx], b[jj].x, acc[x]);
-                    acc[x] = fma(A[l ^ Lx][(2 * jj + 1) ^ Jx], b[jj].y, acc[x]);
+                for (int nt = 0; nt < 2; nt++) c4[mt][nt] = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ks++) {
+                // k-step = the four movable state coordinates (fp, fq, j1, j2); the B image orders them (j1, j2, fp, fq)
+                const int fp = ks & 1, fq = (ks >> 1) & 1, j1 = (ks >> 2) & 1, j2 = ks >> 3;
+                double    a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    // tile t of the operand has its second flip on: fq for A, j2 for B; the first flip (fp / j1) is the lane's
+                    // bit, folded into the base address
+                    a[t] = *(const double*)((const char*)L + (fp ? rAo : rAe) + fp * 16 + (fq ^ t) * 32 + j1 * 128 + j2 * 256);
+                    b[t] = *(const double*)((const char*)L + (j1 ? rBo : rBe) + j1 * 16 + fp * 32 + fq * 128 + (j2 ^ t) * 256);
                 }
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        c4[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], c4[mt][nt], 0, 0, 0);
             }
-            // the sums are only used under `if (full)` / `if (lse)`: without this the compiler sinks all 1 024 FMAs below
-            // the reads and holds every B value in registers
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-                              "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
-                         : : "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            wave_lds_fence();                   // every lane's operand reads are done: the image of the sums takes the LDS
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++)
+                        *(double*)((char*)L + wC + ((reg & 1) * 32 * TURN_CS + ((2 * mt + (reg >> 1)) << 1) + 8 * nt) * 8) = c4[mt][nt][reg];
+            wave_lds_fence();
+#pragma unroll
+            for (int x2 = 0; x2 < 8; x2++) {
+                // the image keeps a cell's 16 sums in the order xb0 | xa << 1 | xb1 << 3 (the 16 lanes a ds_write_b64 serves
+                // together then fall into different banks); x = xa | xb << 2
+                const d2v t = *(const d2v*)((const char*)L + rC + x2 * 16);
+                const int xa = x2 & 3, xb1 = x2 >> 2;
+                acc[xa | (xb1 << 3)]     = t.x;
+                acc[xa | 4 | (xb1 << 3)] = t.y;
+            }
+        } else {
+            wave_lds_fence();                       // the previous marker's reads are done
+    #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                *(d2v*)(Lw + 16 * k)                = va[k];
+                *(d2v*)(Lw + 8 * TURN_RS + 16 * k) = vb[k];
+            }
+            wave_lds_fence();
+            double A[8][8];
+    #pragma unroll
+            for (int l = 0; l < 8; l++)
+    #pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const d2v t = *(const d2v*)(Ap + jj * 16 + l * 2);
+                    A[l][2 * jj]     = t.x;
+                    A[l][2 * jj + 1] = t.y;
+                }
+    #pragma unroll
+            for (int x = 0; x < 16; x++) acc[x] = 0.0;
+            // B of one position (8 doubles) is requested a position ahead; the scheduling barriers keep the compiler from
+            // pulling all 32 reads to the front (128 registers it does not have)
+            d2v bn[4];
+    #pragma unroll
+            for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16);
+    #pragma unroll
+            for (int l = 0; l < 8; l++) {
+                d2v b[4];
+    #pragma unroll
+                for (int jj = 0; jj < 4; jj++) b[jj] = bn[jj];
+                if (l < 7) {
+    #pragma unroll
+                    for (int jj = 0; jj < 4; jj++) bn[jj] = *(const d2v*)(Bp + jj * 16 + (l + 1) * 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+    #pragma unroll
+                    for (int x = 0; x < 16; x++) {
+                        // x bit 0 -> state bit 1 (position ^ 2), 1 -> bit 2 (position ^ 7), 2 -> bit 4, 3 -> bit 5 (registers)
+                        const int Lx = ((x & 1) ? 2 : 0) ^ ((x & 2) ? 7 : 0), Jx = ((x >> 2) & 3) << 1;
+                        acc[x] = fma(A[l ^ Lx][(2 * jj) ^ Jx], b[jj].x, acc[x]);
+                        acc[x] = fma(A[l ^ Lx][(2 * jj + 1) ^ Jx], b[jj].y, acc[x]);
+                    }
+                }
+                // the sums are only used under `if (full)` / `if (lse)`: without this the compiler sinks all 1 024 FMAs below
+                // the reads and holds every B value in registers
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                                  "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+                             : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         double* full = q.rawervals ? q.rawervals + ((size_t)jb.ind * p.n_markers + m) * 1024 : nullptr;
         double* lse  = q.turn_lse ? q.turn_lse + ((size_t)jb.ind * p.n_markers + m) * 128 : nullptr;
@@ -3664,7 +3749,8 @@ void launch_turn_rows(const TurnParams& q, hipStream_t stream)
 {
     const int per_block = CNF2_WAVES_PER_BLOCK * CNF2_TURN_SPAN;
     dim3 grid(q.n_jobs, (q.max_len + per_block - 1) / per_block);
-    hipLaunchKernelGGL(turn_rows_kernel, grid, dim3(CNF2_BLOCK), 0, stream, q);
+    if (q.valu_form) hipLaunchKernelGGL(turn_rows_kernel<false>, grid, dim3(CNF2_BLOCK), 0, stream, q);
+    else hipLaunchKernelGGL(turn_rows_kernel<true>, grid, dim3(CNF2_BLOCK), 0, stream, q);
 }
 
 int fb_fast_blocks_per_cu()

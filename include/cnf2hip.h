@@ -82,6 +82,9 @@ enum {
                                     range) and one more kernel adds the rows of every record in ascending order of the
                                     individual, instead of f64 atomics in order of arrival: accumulators -- and with them
                                     whole iterations -- reproduce to the bit from run to run */
+    CNF2_TURN_VALU    = 1u << 15, /* cnf2_sweep_turn_scan: the 1 024 dot products per (individual, marker) on the vector ALU (one lane
+                                    per pair of shift modes, flips as register renaming) instead of the matrix cores
+                                    (v_mfma_f64_16x16x4: a 32 x 32 x 64 product per unit); same sums in another order: cross-check, A/B */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same

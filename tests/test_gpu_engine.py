@@ -442,3 +442,24 @@ def test_demo_files_of_the_reference(libs, tmp_path):
         f.write("argmax class agrees on %d of 36 rows\n" % sum(
             int(np.argmax(blocks[n][t]) == np.argmax([float(x) for x in stale[stale.index(n) + 1 + t].split("\t")[:3]]))
             for n in ("C:1", "D:1") for t in range(18)))
+
+
+def test_reserve_accumulate_and_sweep_clock(libs):
+    """cnf2_reserve_accumulate makes the allocations of a later cnf2_sweep_accumulate (the same call is then a no-op for the
+    batch buffer: the workspace does not grow), and cnf2_sweep_clock reports the shader clock of the last plain sweep from
+    the kernel's own stamps (between 0.5 and 3 GHz on an MI355X)."""
+    capi, host = libs
+    ped = synth.make_outbred3(6, 4, 40, 2, seed=5, missing=0.2)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    assert ctx.sweep_clock() == 0.0
+    ctx._chk(ctx.L.cnf2_reserve_accumulate(ctx.h, 0, len(ped.dous), 0), "cnf2_reserve_accumulate")
+    w0 = ctx.L.cnf2_workspace_bytes(ctx.h)
+    desc = ctx.descendants()
+    r1 = ctx.sweep_accumulate(desc)
+    assert ctx.L.cnf2_workspace_bytes(ctx.h) == w0
+    r2 = ctx.sweep()
+    mhz = ctx.sweep_clock()
+    assert 500.0 < mhz < 3000.0, mhz
+    assert np.allclose(r1["loglik"], r2["loglik"], rtol=1e-12, atol=0)
+    ctx.close()

@@ -824,7 +824,12 @@ def test_batched_turn_scan_matches_reference(capi, case):
     ped, z = load_golden(case)
     ctx = capi.Context(0)
     ctx.upload(ped)
-    raw, lse = ctx.sweep_turn_scan()
+    raw, lse = ctx.sweep_turn_scan()                       # the dot products on the matrix cores (default)
+    raw_v, lse_v = ctx.sweep_turn_scan(valu=True)          # ... on the vector ALU: the same sums in another order
+    both = np.isfinite(raw) & np.isfinite(raw_v) & (np.abs(raw) < 1e14)
+    assert np.array_equal(np.abs(raw) < 1e14, np.abs(raw_v) < 1e14)
+    np.testing.assert_allclose(raw[both], raw_v[both], rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(lse, lse_v, rtol=1e-11, atol=1e-10)
     for j in range(len(ped.dous)):
         if not z["ok"][j]:
             continue

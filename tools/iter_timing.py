@@ -1,7 +1,8 @@
 """Measurement aid: one haplotyping iteration of BASELINE config 5's shape (3-generation outbred, 20 % missing) on one
 GPU, through the C ABI with everything device-resident: plain sweep, sweep + HOT LOOP 2 accumulators
 (cnf2_sweep_accumulate), the update passes of every chromosome.
-usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations] [scalefactor] [flow|plain]"""
+usage: python tools/iter_timing.py [families] [snps per chromosome] [chromosomes] [iterations] [scalefactor] [flow|plain] [det]
+(det = CNF2_DETERMINISTIC accumulators)"""
 import ctypes as C
 import os
 import sys
@@ -70,10 +71,11 @@ ctx._chk(ctx.L.cnf2_reserve_accumulate(ctx.h, 0, n, 0), "cnf2_reserve_accumulate
 print("reserve            %.3f s (batch buffer of the accumulate sweep: a first hipMalloc of half the free memory)" % (time.time() - t), flush=True)
 sf = float(sys.argv[5]) if len(sys.argv) > 5 else 0.013
 upd_flags = capi.ACC_DEVICE | (capi.UPDATE_PLAIN if len(sys.argv) > 6 and sys.argv[6] == "plain" else 0)
+acc_flags = capi.DETERMINISTIC if len(sys.argv) > 7 and sys.argv[7] == "det" else 0
 for it in range(iters):
     t = time.time()
     ctx.sweep_accumulate_device(desc, 0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(), inf.data_ptr(),
-                                hb.data_ptr(), hc.data_ptr(), hz.data_ptr())
+                                hb.data_ptr(), hc.data_ptr(), hz.data_ptr(), acc_flags)
     ctx.sync()
     t_acc = time.time() - t
     t = time.time()
