@@ -542,7 +542,6 @@ def main():
                          "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha,
                          "effective_clock_mhz": clock_mhz, "sweep_kernel_clock_mhz": sweep_clock_mhz,
                          "fma_probe_clock_mhz": probe_mhz,
-                         "frac_at_2400_mhz": achieved * 1e9 / HBM_PEAK * 2400.0 / clock_mhz,
                          "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
             "checks": checks,

@@ -1143,6 +1143,10 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                         jobs.size());
         }
         if (reserve_only) {
+            // ... and the buffers of the update passes (cnf2_update_pass): results of a chromosome's flows, the scouts' list
+            if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 26 * sizeof(unsigned long long)));
+            if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)mlen * 4))) return rc;
+            if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, ((size_t)1 << 27) * 3))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return CNF2_OK;
         }
