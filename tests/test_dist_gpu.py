@@ -117,3 +117,16 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     assert not set(got) & set(got1)
     got.update(got1)
     assert got == want and len(want) == 15 * 2
+
+
+def test_rccl_exchange_on_one_rank():
+    """The nccl (= RCCL) backend with a world of one on GPU 0: the all-reduce of an iteration's exchange on tensors that alias
+    the engine's device slabs, and the tiled gather, through the library that carries them on a multi-GPU node (two ranks
+    cannot share a GPU under RCCL, so this is what a one-GPU box can run of it)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rccl_one_rank_worker.py"), "29581"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OK " in r.stdout
