@@ -596,8 +596,11 @@ CNF2_UHD double flow_time_bound(const SlopeTerms& s, double xa, double xb, doubl
 // to show the gradient monotone, the closing in on the root -- happens at fixed step numbers, the same for every lane,
 // and a same-sign step that the constant bound C15 / s1 does not settle ends the scout (the finish pass has the finer
 // bound and the quadrature).
+// max_steps: give up after that many steps of this call (returns 3: the flow is neither ended nor at a quadrature; its
+// completed steps are in f->it and f->path like for 2) -- the first of two scout passes runs a few steps of every flow,
+// the second the rest of the few that are still going, with wavefronts full of them.
 template <class G>
-CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations)
+CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations, int max_steps = 1 << 30)
 {
     const double eps = f->epsilon, top = 1.0 - f->epsilon;
     const double limit = scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9);
@@ -629,6 +632,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
             f->live = false;
             return 0;
         }
+        if (step >= max_steps) return 3;
         // is the gradient monotone on the bracket (and on the way from the start)?  Tried while the bracket shrinks.
         if (step == 0 || step == 1 || step == 2 || step == 4 || step == 7 || step == 11 || step == 16) {
             if (!mono && f->lo >= eps && f->hi <= top) {

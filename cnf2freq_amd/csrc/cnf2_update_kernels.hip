@@ -218,9 +218,12 @@ struct FlowSupply {
     bool               more;          // the list has slots the wave has not read
 };
 // tops the queue up to at least `wanted` entries (or until the list is exhausted)
+// An entry's item_steps: ~0 = nothing in this slot; bit 63 set = the flow is still scouting (the second scout pass takes it,
+// `scouting` = true); else it waits for its quadratures (the finish pass).
+#define FLOW_SCOUTING (1ull << 63)
 template <class Entry>
 __device__ __forceinline__ void flow_supply(FlowSupply<Entry>* q, Entry* queue, unsigned long long* next, const Entry* todo,
-                                            unsigned long long n_items, int wanted)
+                                            unsigned long long n_items, int wanted, bool scouting = false)
 {
     const int lane = threadIdx.x & 63;
     while (q->more && q->count < wanted) {
@@ -239,7 +242,7 @@ __device__ __forceinline__ void flow_supply(FlowSupply<Entry>* q, Entry* queue, 
         Entry e;
         e.item_steps = ~0ull;
         if (slot < q->end) e = todo[slot];
-        const bool               holds = e.item_steps != ~0ull;
+        const bool               holds = e.item_steps != ~0ull && ((e.item_steps & FLOW_SCOUTING) != 0) == scouting;
         const unsigned long long mask = __ballot(holds);
         if (holds) queue[q->count + __popcll(mask & ((1ull << lane) - 1ull))] = e;
         q->count += __popcll(mask);
@@ -284,6 +287,9 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
 }
 
+#ifndef FLOW_SCOUT_STEPS
+#define FLOW_SCOUT_STEPS 3      /* steps of the first scout pass (the first closing-in on the root would come at step 3) */
+#endif
 __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
                                                               double* flow_out, FlowTodo* todo)
 {
@@ -309,12 +315,13 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
                 n_pinned = 1;
             } else {
                 const SlopeTerms st = certainty_slope(c);
-                if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, FLOW_SCOUT_STEPS);
+                if (r == 0) {
                     flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
                     n_done = 1;
                 } else {
                     aside = true;
-                    e.item_steps = (item << 6) | (unsigned long long)f.it;
+                    e.item_steps = (item << 6) | (unsigned long long)f.it | (r == 3 ? FLOW_SCOUTING : 0ull);
                     e.path = f.path;
                 }
             }
@@ -326,6 +333,49 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+// Second scout pass: the flows the first left scouting, 64 of them per wavefront and round (persistent, the finish pass's
+// supply); a flow ends here or its slot is rewritten for the finish pass.
+__global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, unsigned long long* next, FlowTodo* todo,
+                                                              unsigned long long item0, unsigned long long n_items, double* flow_out)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ FlowTodo  queue[FLOW_QUEUE];
+    FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
+    int      hits = 0, evals_all = 0;
+    unsigned n_done = 0;
+    for (;;) {
+        flow_supply(&q, queue, next, (const FlowTodo*)todo, n_items, 64, true);
+        if (q.count == 0) break;
+        FlowTodo e;
+        const bool got = flow_pop(&q, queue, true, &e);
+        if (got) {
+            const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
+            CertaintyFlow c;
+            certainty_item(u, item, sc, &c);
+            FlowState f;
+            auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
+            flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
+            flow_replay(&f, e.path, (int)(e.item_steps & 63));
+            const SlopeTerms st = certainty_slope(c);
+            int evals = 0;
+            FlowTodo out;
+            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                out.item_steps = ~0ull;
+                out.path = 0;
+                n_done++;
+            } else {
+                out.item_steps = (item << 6) | (unsigned long long)f.it;
+                out.path = f.path;
+            }
+            todo[item - item0] = out;
+            evals_all += evals;
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats, 0u, (unsigned)evals_all, n_done, 0u);
 }
 
 __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
@@ -458,12 +508,13 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
             n_pinned = 1;
         } else {
             const SlopeTerms st = haplo_slope(h);
-            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+            const int        rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, FLOW_SCOUT_STEPS);
+            if (rs == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
             } else {
                 aside = true;
-                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it;
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (rs == 3 ? FLOW_SCOUTING : 0ull);
                 e.path = f.path;
                 e.similarity = similarity;
             }
@@ -475,6 +526,49 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+__global__ __launch_bounds__(64) void haploweight_scout2_kernel(UpdateParams u, unsigned long long* next, HaploTodo* todo,
+                                                                unsigned long long item0, unsigned long long n_items)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    __shared__ HaploTodo  queue[FLOW_QUEUE];
+    FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
+    int      hits = 0, evals_all = 0;
+    unsigned n_done = 0;
+    for (;;) {
+        flow_supply(&q, queue, next, (const HaploTodo*)todo, n_items, 64, true);
+        if (q.count == 0) break;
+        HaploTodo e;
+        if (flow_pop(&q, queue, true, &e)) {
+            const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
+            size_t row_i, k;
+            int    r;
+            haplo_item(u, item, &row_i, &k, &r);
+            const double hw = u.hw[row_i];
+            HaploFlow    h;
+            haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+            FlowState f;
+            auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+            flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+            flow_replay(&f, e.path, (int)(e.item_steps & 63));
+            const SlopeTerms st = haplo_slope(h);
+            int evals = 0;
+            HaploTodo out = e;
+            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+                out.item_steps = ~0ull;
+                n_done++;
+            } else {
+                out.item_steps = (item << 6) | (unsigned long long)f.it;
+                out.path = f.path;
+            }
+            todo[item - item0] = out;
+            evals_all += evals;
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 4 : nullptr, 0u, (unsigned)evals_all, n_done, 0u);
 }
 
 __global__ __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
@@ -549,6 +643,8 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         hipLaunchKernelGGL(certainty_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
         const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(certainty_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
+                           (FlowTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n, u.flow_out);
         hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                            (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
     }
@@ -560,6 +656,8 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, (HaploTodo*)u.todo);
         const size_t w = (n + 63) / 64;
+        hipLaunchKernelGGL(haploweight_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
+                           (HaploTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n);
         hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                            (const HaploTodo*)u.todo, (unsigned long long)n);
     }
