@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
 //           midpoints are answered from what is known about it.  In the steady state of a run three flows in four
 //           end here, after ~20 evaluations instead of ~65.  A flow that reaches a quadrature is set aside: its item,
 //           the number of steps it has completed and their decisions (16 or 24 bytes).
+//           The certainties' scout runs in two passes: the first stops every flow after FLOW_SCOUT_STEPS steps (early in a
+//           run 98 % of them are at a quadrature by then), the second takes the few still scouting, 64 per wavefront.
 //   finish  the flows set aside, as a persistent kernel: a wavefront runs ONE literal step (flow_advance: midpoint, the
 //           bound, the quadrature) of 64 independent flows per round and hands a lane the next flow from a global counter
 //           when its own has ended (refills are batched: a lane waits until FLOW_REFILL lanes are free, or nothing else
@@ -508,13 +510,14 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
             n_pinned = 1;
         } else {
             const SlopeTerms st = haplo_slope(h);
-            const int        rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, FLOW_SCOUT_STEPS);
-            if (rs == 0) {
+            // (one pass: most weight flows scout for dozens of steps, so a second pass would take nearly all of them up again --
+            // measured 10 % slower than this)
+            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
             } else {
                 aside = true;
-                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (rs == 3 ? FLOW_SCOUTING : 0ull);
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it;
                 e.path = f.path;
                 e.similarity = similarity;
             }
@@ -526,49 +529,6 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
-}
-
-__global__ __launch_bounds__(64) void haploweight_scout2_kernel(UpdateParams u, unsigned long long* next, HaploTodo* todo,
-                                                                unsigned long long item0, unsigned long long n_items)
-{
-    const StepControl        sc = {u.scalefactor, u.entropyfactor};
-    __shared__ HaploTodo  queue[FLOW_QUEUE];
-    FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
-    int      hits = 0, evals_all = 0;
-    unsigned n_done = 0;
-    for (;;) {
-        flow_supply(&q, queue, next, (const HaploTodo*)todo, n_items, 64, true);
-        if (q.count == 0) break;
-        HaploTodo e;
-        if (flow_pop(&q, queue, true, &e)) {
-            const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
-            size_t row_i, k;
-            int    r;
-            haplo_item(u, item, &row_i, &k, &r);
-            const double hw = u.hw[row_i];
-            HaploFlow    h;
-            haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
-            FlowState f;
-            auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
-            flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
-            flow_replay(&f, e.path, (int)(e.item_steps & 63));
-            const SlopeTerms st = haplo_slope(h);
-            int evals = 0;
-            HaploTodo out = e;
-            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
-                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
-                out.item_steps = ~0ull;
-                n_done++;
-            } else {
-                out.item_steps = (item << 6) | (unsigned long long)f.it;
-                out.path = f.path;
-            }
-            todo[item - item0] = out;
-            evals_all += evals;
-        }
-    }
-    if (hits) atomicAdd(u.hits, hits);
-    flow_stats(u.stats ? u.stats + 4 : nullptr, 0u, (unsigned)evals_all, n_done, 0u);
 }
 
 __global__ __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
@@ -656,8 +616,6 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, (HaploTodo*)u.todo);
         const size_t w = (n + 63) / 64;
-        hipLaunchKernelGGL(haploweight_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
-                           (HaploTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n);
         hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                            (const HaploTodo*)u.todo, (unsigned long long)n);
     }
