@@ -1529,6 +1529,8 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
         u.stats = getenv("CNF2_UPDATE_STATS") ? ctx->d_flow_next + 2 : nullptr;     // diagnostics cost a few atomics per wavefront
         u.todo = ctx->d_todo;
         u.todo_cap = chunk;
+        const char* sp = getenv("CNF2_SCOUT_PASSES");               // A/B switch (tools/ab_scout.py): 1 = the certainties' scout in one pass
+        u.scout_passes = (sp && sp[0] == '1') ? 1 : 2;
     }
     launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());

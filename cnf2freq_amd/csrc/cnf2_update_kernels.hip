@@ -292,6 +292,7 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
 #ifndef FLOW_SCOUT_STEPS
 #define FLOW_SCOUT_STEPS 3      /* steps of the first scout pass (the first closing-in on the root would come at step 3) */
 #endif
+template <bool TWO_PASSES>
 __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
                                                               double* flow_out, FlowTodo* todo)
 {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
                 n_pinned = 1;
             } else {
                 const SlopeTerms st = certainty_slope(c);
-                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, FLOW_SCOUT_STEPS);
+                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30);
                 if (r == 0) {
                     flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
                     n_done = 1;
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
             n_pinned = 1;
         } else {
             const SlopeTerms st = haplo_slope(h);
-            // (one pass: most weight flows scout for dozens of steps, so a second pass would take nearly all of them up again --
-            // measured 10 % slower than this)
+            // (one pass: most weight flows scout for dozens of steps, so a second pass takes nearly all of them up again -- measured
+            // 1.2 % slower over 40 iterations, tools/ab_scout.py)
             if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
@@ -600,11 +601,16 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     for (size_t i0 = 0; i0 < n1 * 4; i0 += cap) {
         const size_t n = n1 * 4 - i0 < cap ? n1 * 4 - i0 : cap;
         (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
-        hipLaunchKernelGGL(certainty_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
-                           (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
         const size_t w = (n + 63) / 64;
-        hipLaunchKernelGGL(certainty_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
-                           (FlowTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n, u.flow_out);
+        if (u.scout_passes == 1) {
+            hipLaunchKernelGGL(certainty_scout_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                               (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
+        } else {
+            hipLaunchKernelGGL(certainty_scout_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+                               (unsigned long long)n, u.flow_out, (FlowTodo*)u.todo);
+            hipLaunchKernelGGL(certainty_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
+                               (FlowTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n, u.flow_out);
+        }
         hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                            (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
     }
