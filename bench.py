@@ -238,6 +238,11 @@ def main_iterations(args):
     fams = 2500 if args.inds == 10000 else max(1, args.inds // 4)
     ped = synth.make_outbred3(fams, 4, args.snps_per_chrom, chroms, seed=2, missing=0.2)      # the same pedigree on every rank
     n, M, R = len(ped.dous), ped.n_markers, ped.n_rec
+    # the engine prints the reference's progress lines ("Scale factor now ...") on stdout: they go to stderr here, so that
+    # stdout carries the one JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     t0 = time.perf_counter()
     run = cdist.start_iterations(ped, device=local)
     t_setup = time.perf_counter() - t0
@@ -262,6 +267,11 @@ def main_iterations(args):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    sys.stdout.flush()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)          # the C library's own buffer of the engine's lines, before stdout comes back
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         st = run.state()
         out = {
