@@ -215,7 +215,7 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     rs = np.random.RandomState(2)
     ped.hw[1:] = np.where(rs.rand(*ped.hw[1:].shape) < 0.2, 0.5, 0.05 + 0.9 * rs.rand(*ped.hw[1:].shape))
     ctxs = {}
-    for name in ("flow", "plain"):
+    for name in ("flow", "flow1", "plain"):
         ctx = capi.Context(0)
         ctx.upload(ped)
         ctx.snapshot_priors((1 - ped.empty).astype(np.uint8))
@@ -229,17 +229,24 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     total_hits = 0
     for rnd in range(4):
         out = {}
-        for name, flags in (("flow", 0), ("plain", capi.UPDATE_PLAIN)):
+        # flow: the product's kernels (the certainties' scout in two passes); flow1: that scout in one pass (CNF2_SCOUT_PASSES=1)
+        for name, flags, passes in (("flow", 0, None), ("flow1", 0, "1"), ("plain", capi.UPDATE_PLAIN, None)):
             ctx = ctxs[name]
             acc = ctx.sweep_accumulate(desc, deterministic=True)
-            hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
+            if passes:
+                os.environ["CNF2_SCOUT_PASSES"] = passes
+            try:
+                hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
+            finally:
+                os.environ.pop("CNF2_SCOUT_PASSES", None)
             out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
-        assert out["flow"][0] == out["plain"][0], rnd
         total_hits += sum(out["flow"][0])
-        for x, y in zip(out["flow"][1], out["plain"][1]):
-            assert np.array_equal(x, y), rnd
-        for k in ("infprobs", "haplobase", "haplocount"):
-            assert np.array_equal(out["flow"][2][k], out["plain"][2][k], equal_nan=True), (rnd, k)
+        for name in ("flow", "flow1"):
+            assert out[name][0] == out["plain"][0], (rnd, name)
+            for x, y in zip(out[name][1], out["plain"][1]):
+                assert np.array_equal(x, y), (rnd, name)
+            for k in ("infprobs", "haplobase", "haplocount"):
+                assert np.array_equal(out[name][2][k], out["plain"][2][k], equal_nan=True), (rnd, name, k)
     assert total_hits > 0
     for ctx in ctxs.values():
         ctx.close()
