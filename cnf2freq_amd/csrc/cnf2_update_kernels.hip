@@ -84,39 +84,64 @@ __global__ __launch_bounds__(64) void phase_ratio_kernel(UpdateParams u)
     const double* hw = u.hw + (size_t)u.row_of[r] * u.n_markers;
     double* fw = u.fw + ((size_t)r * u.n_markers + c0) * 2;
     double* ratio = u.ratio + (size_t)r * u.n_markers + c0;
-    // phase_ratio() of cnf2_update.h with a constant relhaplo
+    // phase_ratio() of cnf2_update.h with a constant relhaplo.  The recurrences are serial per (record, chromosome) and a
+    // thread's loads are a cache line apart from its neighbours': the weights (and, on the way back, the stored forward
+    // pairs) are requested 8 markers at a time so that their latencies overlap; the arithmetic is the serial one.
     double s0 = 0.5, s1 = 0.5;
     const double n = u.relhaplo, nb = 1 - n;
-    for (int m = c0; m < c1; m++) {
-        const double w = hw[m];
-        s0 *= fabs(1 - w);
-        s1 *= fabs(0 - w);
-        fw[(m - c0) * 2] = s0;
-        fw[(m - c0) * 2 + 1] = s1;
-        if (s0 + s1 < 1e-10) {
-            s0 *= 1e20;
-            s1 *= 1e20;
+    for (int m0 = c0; m0 < c1; m0 += 8) {
+        double w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w8[i] = hw[m0 + i < c1 ? m0 + i : c1 - 1];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = m0 + i;
+            if (m < c1) {
+                const double w = w8[i];
+                s0 *= fabs(1 - w);
+                s1 *= fabs(0 - w);
+                fw[(m - c0) * 2] = s0;
+                fw[(m - c0) * 2 + 1] = s1;
+                if (s0 + s1 < 1e-10) {
+                    s0 *= 1e20;
+                    s1 *= 1e20;
+                }
+                const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+                s0 = t0;
+                s1 = t1;
+            }
         }
-        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
-        s0 = t0;
-        s1 = t1;
     }
     s0 = s1 = 0.5;
     const int last = c1 - c0 - 1;
     ratio[last] = fw[last * 2 + 1] / (fw[last * 2] + fw[last * 2 + 1]);
-    for (int m = c1 - 2; m >= c0; m--) {
-        const double w = hw[m + 1];
-        s0 *= fabs(1 - w);
-        s1 *= fabs(0 - w);
-        const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
-        s0 = t0;
-        s1 = t1;
-        if (s0 + s1 < 1e-10) {
-            s0 *= 1e20;
-            s1 *= 1e20;
+    for (int mh = c1 - 2; mh >= c0; mh -= 8) {
+        double w8[8], f8[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = mh - i < c0 ? c0 : mh - i;
+            w8[i] = hw[m + 1];
+            f8[i][0] = fw[(m - c0) * 2];
+            f8[i][1] = fw[(m - c0) * 2 + 1];
         }
-        const double r0 = s0 * fw[(m - c0) * 2], r1 = s1 * fw[(m - c0) * 2 + 1];
-        ratio[m - c0] = r1 / (r0 + r1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = mh - i;
+            if (m >= c0) {
+                const double w = w8[i];
+                s0 *= fabs(1 - w);
+                s1 *= fabs(0 - w);
+                const double t0 = s0 * n + s1 * nb, t1 = s1 * n + s0 * nb;
+                s0 = t0;
+                s1 = t1;
+                if (s0 + s1 < 1e-10) {
+                    s0 *= 1e20;
+                    s1 *= 1e20;
+                }
+                const double r0 = s0 * f8[i][0], r1 = s1 * f8[i][1];
+                ratio[m - c0] = r1 / (r0 + r1);
+            }
+        }
     }
 }
 
