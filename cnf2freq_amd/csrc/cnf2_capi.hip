@@ -1531,6 +1531,8 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
         u.todo_cap = chunk;
         const char* sp = getenv("CNF2_SCOUT_PASSES");               // A/B switch (tools/ab_scout.py): 1 = the certainties' scout in one pass
         u.scout_passes = (sp && sp[0] == '1') ? 1 : 2;
+        const char* cb = getenv("CNF2_CERTAINTY_BOTH");             // 1 = both values' flows are run, as the reference does (bit-exact form)
+        u.mirror = (cb && cb[0] == '1') ? 0 : 1;
     }
     launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());

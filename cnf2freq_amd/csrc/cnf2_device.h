@@ -136,6 +136,7 @@ struct UpdateParams {
     unsigned long long* stats;       // [24] diagnostics of the flow kernels (cnf2_update_stats), may be null
     void*          todo;          // flows the scouts set aside for the finish kernels (24 bytes each)
     size_t         todo_cap;      // flows per chunk of a scout = entries of todo
+    int            mirror;        // certainties: run one flow per side where both values have evidence, the other is its mirror image
     int            scout_passes;  // certainties: 2 = a short first scout pass and a second for the flows still going; 1 = one pass (A/B)
     double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };

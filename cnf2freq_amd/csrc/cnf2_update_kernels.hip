@@ -293,7 +293,9 @@ __device__ __forceinline__ bool flow_pop(FlowSupply<Entry>* q, const Entry* queu
 
 // item = ((r * len + mi) * 2 + side) * 2 + v: the flow of value v + 1 on one side of (record, marker);
 // flow_out[item] = its new probability (0 where the value has no evidence)
-__device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c)
+// both (optional): the side's other value has evidence too
+__device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c,
+                                               bool* both = nullptr)
 {
     const int          len = u.last - u.first + 1;
     const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
@@ -301,6 +303,7 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     const int          r = (int)(e / len), m = u.first + (int)(e % len);
     const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
     const double       pair[2] = {inf[0], inf[1]};
+    if (both) *both = pair[0] > 0 && pair[1] > 0;
     const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
     const bool         has_prior = u.has_prior[r] != 0;
     const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
@@ -312,6 +315,33 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     s.prior_allele = side ? (pap >> 4) : (pap & 15);
     s.prior_sure = side ? psu.y : psu.x;
     return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
+}
+
+// Mirror (u.mirror): the two values of a side start at y and 1 - y, their evidence shares are g and h - g, their priors p and
+// 1 - p: the gradient of one is the negative of the other's at the mirrored position, G_2(1 - x) = -G_1(x) (the data term
+// swaps a and b, logit changes sign), so the second flow is the first one mirrored and ends at 1 - its end, with the same
+// capped moves.  Where both values have evidence only value 1's flow is run; value 2 gets 1 - result and the hits count
+// twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
+// environment (and CNF2_UPDATE_PLAIN) keep that literal form, which the bit-exactness tests compare.
+// which item a position (item >> 1) runs under the mirror: value 1 when it has evidence, else value 2
+__device__ __forceinline__ unsigned long long certainty_mirror_item(const UpdateParams& u, unsigned long long pos)
+{
+    const int          len = u.last - u.first + 1;
+    const int          side = (int)(pos & 1);
+    const unsigned long long e = pos >> 1;
+    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
+    return pos * 2 + ((inf[0] > 0) ? 0 : 1);
+}
+// the result of a flow (and of its mirror image)
+__device__ __forceinline__ void certainty_store(const UpdateParams& u, double* flow_out, unsigned long long item, bool both, double out,
+                                                int* hits, int flow_hits_)
+{
+    flow_out[item] = out;
+    if (u.mirror) {
+        flow_out[item ^ 1] = both ? 1.0 - out : 0.0;
+        if (both) *hits += flow_hits_;
+    }
 }
 
 #ifndef FLOW_SCOUT_STEPS
@@ -328,10 +358,13 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
     bool     aside = false;
     FlowTodo e;
     if (t < n_items) {
-        const unsigned long long item = item0 + t;
+        // item0, n_items count items, or positions (items >> 1) under the mirror
+        const unsigned long long item = u.mirror ? certainty_mirror_item(u, item0 + t) : item0 + t;
         CertaintyFlow c;
-        if (!certainty_item(u, item, sc, &c)) {
+        bool          both = false;
+        if (!certainty_item(u, item, sc, &c, &both)) {
             flow_out[item] = 0.0;
+            if (u.mirror) flow_out[item ^ 1] = 0.0;
         } else {
             FlowState f;
             auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
@@ -339,13 +372,19 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
             n_flows = 1;
             if (f.pinned) {                 // no gradient evaluations left
                 while (flow_advance(&f, grad, sc.scalefactor)) {}
-                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                int          h = 0;
+                const double out = flow_end(f, sc.scalefactor, &h, false);
+                hits += h;
+                certainty_store(u, flow_out, item, both, out, &hits, h);
                 n_pinned = 1;
             } else {
                 const SlopeTerms st = certainty_slope(c);
                 const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30);
                 if (r == 0) {
-                    flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                    int          h = 0;
+                    const double out = flow_end(f, sc.scalefactor, &h, false);
+                    hits += h;
+                    certainty_store(u, flow_out, item, both, out, &hits, h);
                     n_done = 1;
                 } else {
                     aside = true;
@@ -381,7 +420,8 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
         if (got) {
             const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
             CertaintyFlow c;
-            certainty_item(u, item, sc, &c);
+            bool both = false;
+            certainty_item(u, item, sc, &c, &both);
             FlowState f;
             auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
             flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
@@ -390,7 +430,10 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
             int evals = 0;
             FlowTodo out;
             if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
-                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                int          h = 0;
+                const double res = flow_end(f, sc.scalefactor, &h, false);
+                hits += h;
+                certainty_store(u, flow_out, item, both, res, &hits, h);
                 out.item_steps = ~0ull;
                 out.path = 0;
                 n_done++;
@@ -398,7 +441,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
                 out.item_steps = (item << 6) | (unsigned long long)f.it;
                 out.path = f.path;
             }
-            todo[item - item0] = out;
+            todo[(u.mirror ? item >> 1 : item) - item0] = out;
             evals_all += evals;
         }
     }
@@ -412,7 +455,7 @@ __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, un
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
     __shared__ FlowTodo  queue[FLOW_QUEUE];
     FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
-    bool               have = false;
+    bool               have = false, both = false;
     unsigned long long item = 0;
     CertaintyFlow      c;
     FlowState          f;
@@ -428,7 +471,7 @@ __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, un
             FlowTodo e;
             if (flow_pop(&q, queue, !have, &e)) {
                 item = e.item_steps >> 6;
-                certainty_item(u, item, sc, &c);
+                certainty_item(u, item, sc, &c, &both);
                 flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
                 flow_replay(&f, e.path, (int)(e.item_steps & 63));
                 st = certainty_slope(c);
@@ -441,7 +484,10 @@ __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, un
         if (have) {
             n_steps++;
             if (!flow_advance(&f, grad, sc.scalefactor, bound)) {
-                flow_out[item] = flow_end(f, sc.scalefactor, &hits, false);
+                int          h = 0;
+                const double res = flow_end(f, sc.scalefactor, &h, false);
+                hits += h;
+                certainty_store(u, flow_out, item, both, res, &hits, h);
                 have = false;
                 n_quads += f.quads;
                 n_why1 += f.why == 1;
@@ -623,8 +669,9 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     // todo_cap flows so that the list of flows set aside stays bounded.
     (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
     const size_t cap = u.todo_cap;
-    for (size_t i0 = 0; i0 < n1 * 4; i0 += cap) {
-        const size_t n = n1 * 4 - i0 < cap ? n1 * 4 - i0 : cap;
+    const size_t nc = u.mirror ? n1 * 2 : n1 * 4;            // positions under the mirror, else items
+    for (size_t i0 = 0; i0 < nc; i0 += cap) {
+        const size_t n = nc - i0 < cap ? nc - i0 : cap;
         (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
         const size_t w = (n + 63) / 64;
         if (u.scout_passes == 1) {

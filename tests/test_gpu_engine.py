@@ -215,7 +215,7 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     rs = np.random.RandomState(2)
     ped.hw[1:] = np.where(rs.rand(*ped.hw[1:].shape) < 0.2, 0.5, 0.05 + 0.9 * rs.rand(*ped.hw[1:].shape))
     ctxs = {}
-    for name in ("flow", "flow1", "plain"):
+    for name in ("mirror", "flow", "flow1", "plain"):
         ctx = capi.Context(0)
         ctx.upload(ped)
         ctx.snapshot_priors((1 - ped.empty).astype(np.uint8))
@@ -229,16 +229,19 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     total_hits = 0
     for rnd in range(4):
         out = {}
-        # flow: the product's kernels (the certainties' scout in two passes); flow1: that scout in one pass (CNF2_SCOUT_PASSES=1)
-        for name, flags, passes in (("flow", 0, None), ("flow1", 0, "1"), ("plain", capi.UPDATE_PLAIN, None)):
+        # mirror: the product's kernels (one flow per side where both values have evidence, the other its mirror image);
+        # flow: both values' flows as the reference runs them (CNF2_CERTAINTY_BOTH=1), the certainties' scout in two passes;
+        # flow1: that scout in one pass (CNF2_SCOUT_PASSES=1)
+        for name, flags, env in (("mirror", 0, {}), ("flow", 0, {"CNF2_CERTAINTY_BOTH": "1"}),
+                                 ("flow1", 0, {"CNF2_CERTAINTY_BOTH": "1", "CNF2_SCOUT_PASSES": "1"}), ("plain", capi.UPDATE_PLAIN, {})):
             ctx = ctxs[name]
             acc = ctx.sweep_accumulate(desc, deterministic=True)
-            if passes:
-                os.environ["CNF2_SCOUT_PASSES"] = passes
+            os.environ.update(env)
             try:
                 hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
             finally:
-                os.environ.pop("CNF2_SCOUT_PASSES", None)
+                for k in env:
+                    os.environ.pop(k, None)
             out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
         total_hits += sum(out["flow"][0])
         for name in ("flow", "flow1"):
@@ -247,6 +250,17 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
                 assert np.array_equal(x, y), (rnd, name)
             for k in ("infprobs", "haplobase", "haplocount"):
                 assert np.array_equal(out[name][2][k], out["plain"][2][k], equal_nan=True), (rnd, name, k)
+        # the mirrored form: from the same state the same capped moves and values within rounding of the literal ones.  (Its
+        # context is put back on the literal rows after every round: a flow's result is a bisection midpoint, so an input
+        # that differs in its last bit can end a bisection a step earlier or later and move the result by the width of the
+        # tolerance band -- states that differ by rounding drift apart over the rounds, as two runs of the reference do.)
+        assert out["mirror"][0] == out["plain"][0], rnd
+        for x, y in zip(out["mirror"][1], out["plain"][1]):
+            if x.dtype.kind == "f":
+                np.testing.assert_allclose(x, y, rtol=1e-12, atol=1e-13)
+            else:
+                assert np.array_equal(x, y), rnd
+        ctxs["mirror"].update_rows(1, *out["plain"][1])
     assert total_hits > 0
     for ctx in ctxs.values():
         ctx.close()

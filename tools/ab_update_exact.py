@@ -9,6 +9,8 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+
+os.environ.setdefault("CNF2_CERTAINTY_BOTH", "1")      # the exact comparison is with both values' flows run (the mirror shortcut off)
 import torch  # noqa: F401
 
 from cnf2freq_amd import host, synth
