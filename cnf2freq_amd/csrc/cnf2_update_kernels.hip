@@ -293,9 +293,12 @@ __device__ __forceinline__ bool flow_pop(FlowSupply<Entry>* q, const Entry* queu
 
 // item = ((r * len + mi) * 2 + side) * 2 + v: the flow of value v + 1 on one side of (record, marker);
 // flow_out[item] = its new probability (0 where the value has no evidence)
-// both (optional): the side's other value has evidence too
+// partner (optional): what the side's other value is to this one -- PARTNER_NONE: it has no evidence; PARTNER_MIRROR: its
+// flow is this one's mirror image; PARTNER_APART: it has evidence but an allele value other than 1, 2 (the sex-marker
+// sentinel) is called or prior on this side, for which the two starts and priors are not complementary: its own flow
+enum { PARTNER_NONE = 0, PARTNER_MIRROR = 1, PARTNER_APART = 2 };
 __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c,
-                                               bool* both = nullptr)
+                                               int* partner = nullptr)
 {
     const int          len = u.last - u.first + 1;
     const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
@@ -303,7 +306,6 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     const int          r = (int)(e / len), m = u.first + (int)(e % len);
     const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
     const double       pair[2] = {inf[0], inf[1]};
-    if (both) *both = pair[0] > 0 && pair[1] > 0;
     const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
     const bool         has_prior = u.has_prior[r] != 0;
     const uint8_t      ap = u.allele8[i], pap = has_prior ? u.prior_allele8[i] : 0;
@@ -314,14 +316,16 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     s.sure = side ? su.y : su.x;
     s.prior_allele = side ? (pap >> 4) : (pap & 15);
     s.prior_sure = side ? psu.y : psu.x;
+    if (partner)
+        *partner = !(pair[0] > 0 && pair[1] > 0) ? PARTNER_NONE : ((s.allele > 2 || s.prior_allele > 2) ? PARTNER_APART : PARTNER_MIRROR);
     return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
 }
 
 // Mirror (u.mirror): the two values of a side start at y and 1 - y, their evidence shares are g and h - g, their priors p and
 // 1 - p: the gradient of one is the negative of the other's at the mirrored position, G_2(1 - x) = -G_1(x) (the data term
 // swaps a and b, logit changes sign), so the second flow is the first one mirrored and ends at 1 - its end, with the same
-// capped moves.  Where both values have evidence only value 1's flow is run; value 2 gets 1 - result and the hits count
-// twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
+// capped moves.  Where both values have evidence (and the side's called and prior alleles are 0, 1 or 2) only value 1's flow
+// is run; value 2 gets 1 - result and the hits count twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
 // environment (and CNF2_UPDATE_PLAIN) keep that literal form, which the bit-exactness tests compare.
 // which item a position (item >> 1) runs under the mirror: value 1 when it has evidence, else value 2
 __device__ __forceinline__ unsigned long long certainty_mirror_item(const UpdateParams& u, unsigned long long pos)
@@ -334,13 +338,15 @@ __device__ __forceinline__ unsigned long long certainty_mirror_item(const Update
     return pos * 2 + ((inf[0] > 0) ? 0 : 1);
 }
 // the result of a flow (and of its mirror image)
-__device__ __forceinline__ void certainty_store(const UpdateParams& u, double* flow_out, unsigned long long item, bool both, double out,
+__device__ __forceinline__ void certainty_store(const UpdateParams& u, double* flow_out, unsigned long long item, int partner, double out,
                                                 int* hits, int flow_hits_)
 {
     flow_out[item] = out;
-    if (u.mirror) {
-        flow_out[item ^ 1] = both ? 1.0 - out : 0.0;
-        if (both) *hits += flow_hits_;
+    if (u.mirror && partner == PARTNER_MIRROR) {
+        flow_out[item ^ 1] = 1.0 - out;
+        *hits += flow_hits_;
+    } else if (u.mirror && partner == PARTNER_NONE) {
+        flow_out[item ^ 1] = 0.0;
     }
 }
 
@@ -361,11 +367,20 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
         // item0, n_items count items, or positions (items >> 1) under the mirror
         const unsigned long long item = u.mirror ? certainty_mirror_item(u, item0 + t) : item0 + t;
         CertaintyFlow c;
-        bool          both = false;
+        int           both = PARTNER_NONE;
         if (!certainty_item(u, item, sc, &c, &both)) {
             flow_out[item] = 0.0;
             if (u.mirror) flow_out[item ^ 1] = 0.0;
         } else {
+            if (u.mirror && both == PARTNER_APART) {            // rare: the other value's own flow, literally and to its end
+                CertaintyFlow c2;
+                certainty_item(u, item ^ 1, sc, &c2);
+                FlowState f2;
+                auto grad2 = [&](double x) CNF2_LI { return certainty_rgradient(c2, x); };
+                flow_begin(&f2, grad2, c2.curprob, c2.epsilon, sc.scalefactor, false);
+                while (flow_advance(&f2, grad2, sc.scalefactor)) {}
+                flow_out[item ^ 1] = flow_end(f2, sc.scalefactor, &hits, false);
+            }
             FlowState f;
             auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
             flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
         if (got) {
             const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
             CertaintyFlow c;
-            bool both = false;
+            int both = PARTNER_NONE;
             certainty_item(u, item, sc, &c, &both);
             FlowState f;
             auto grad = [&](double x) CNF2_LI { return certainty_rgradient(c, x); };
@@ -455,7 +470,8 @@ __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, un
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
     __shared__ FlowTodo  queue[FLOW_QUEUE];
     FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
-    bool               have = false, both = false;
+    bool               have = false;
+    int                both = PARTNER_NONE;
     unsigned long long item = 0;
     CertaintyFlow      c;
     FlowState          f;
