@@ -707,7 +707,8 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     for (size_t i0 = 0; i0 < n3; i0 += cap) {
         const size_t n = n3 - i0 < cap ? n3 - i0 : cap;
         (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
-        hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
+        // one wavefront per block: a block's slot is free as soon as its own 64 flows are done (-1 % against blocks of 256)
+        hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, (HaploTodo*)u.todo);
         const size_t w = (n + 63) / 64;
         hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
