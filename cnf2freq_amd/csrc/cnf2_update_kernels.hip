@@ -324,10 +324,12 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
 // Mirror (u.mirror): the two values of a side start at y and 1 - y, their evidence shares are g and h - g, their priors p and
 // 1 - p: the gradient of one is the negative of the other's at the mirrored position, G_2(1 - x) = -G_1(x) (the data term
 // swaps a and b, logit changes sign), so the second flow is the first one mirrored and ends at 1 - its end, with the same
-// capped moves.  Where both values have evidence (and the side's called and prior alleles are 0, 1 or 2) only value 1's flow
-// is run; value 2 gets 1 - result and the hits count twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
+// capped moves.  Where both values have evidence (and the side's called and prior alleles are 0, 1 or 2) only the called
+// value's flow is run; the other gets 1 - result and the hits count twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
 // environment (and CNF2_UPDATE_PLAIN) keep that literal form, which the bit-exactness tests compare.
-// which item a position (item >> 1) runs under the mirror: value 1 when it has evidence, else value 2
+// which item a position (item >> 1) runs under the mirror: the value the side is called as (the one that starts at or above
+// 1/2 and, as a rule, wins the pick of cnF2freq.cpp:4292-4300: its result is then bit for bit the literal one, and only the
+// value that loses is a mirror image), value 1 for an unknown allele; a value without evidence yields to the other
 __device__ __forceinline__ unsigned long long certainty_mirror_item(const UpdateParams& u, unsigned long long pos)
 {
     const int          len = u.last - u.first + 1;
@@ -335,7 +337,16 @@ __device__ __forceinline__ unsigned long long certainty_mirror_item(const Update
     const unsigned long long e = pos >> 1;
     const int          r = (int)(e / len), m = u.first + (int)(e % len);
     const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
-    return pos * 2 + ((inf[0] > 0) ? 0 : 1);
+    const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
+    const uint8_t      ap = u.allele8[i];
+    const double2      su = u.sure[i];
+    const int          allele = side ? (ap >> 4) : (ap & 15);
+    const double       sure = side ? su.y : su.x;
+    // the starting probability of value 1: |[allele == 1] - sure|, 1/2 for an unknown allele
+    const double       y0 = allele == 0 ? 0.5 : fabs((allele == 1 ? 1.0 : 0.0) - sure);
+    int                v = y0 >= 0.5 ? 0 : 1;
+    if (!(inf[v] > 0)) v ^= 1;
+    return pos * 2 + v;
 }
 // the result of a flow (and of its mirror image)
 __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* flow_out, unsigned long long item, int partner, double out,
