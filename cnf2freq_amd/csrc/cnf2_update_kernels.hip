@@ -296,7 +296,11 @@ __device__ __forceinline__ bool flow_pop(FlowSupply<Entry>* q, const Entry* queu
 // partner (optional): what the side's other value is to this one -- PARTNER_NONE: it has no evidence; PARTNER_MIRROR: its
 // flow is this one's mirror image; PARTNER_APART: it has evidence but an allele value other than 1, 2 (the sex-marker
 // sentinel) is called or prior on this side, for which the two starts and priors are not complementary: its own flow
-enum { PARTNER_NONE = 0, PARTNER_MIRROR = 1, PARTNER_APART = 2 };
+// PARTNER_TIE: both values start at exactly 1/2 (unknown allele, or a certainty of 1/2): the two flows are mirror images here
+// too, but where there is no net evidence both stay at 1/2 and the pick between them is made by the last bits of two
+// independently rounded results -- such sides keep both flows (a pass of their own, u.mirror == 2) so that the labels of
+// uninformative alleles come out as in the form that runs every flow.
+enum { PARTNER_NONE = 0, PARTNER_MIRROR = 1, PARTNER_APART = 2, PARTNER_TIE = 3 };
 __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned long long item, const StepControl& sc, CertaintyFlow* c,
                                                int* partner = nullptr)
 {
@@ -317,15 +321,16 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     s.prior_allele = side ? (pap >> 4) : (pap & 15);
     s.prior_sure = side ? psu.y : psu.x;
     if (partner)
-        *partner = !(pair[0] > 0 && pair[1] > 0) ? PARTNER_NONE : ((s.allele > 2 || s.prior_allele > 2) ? PARTNER_APART : PARTNER_MIRROR);
+        *partner = !(pair[0] > 0 && pair[1] > 0) ? PARTNER_NONE
+                 : ((s.allele > 2 || s.prior_allele > 2) ? PARTNER_APART : ((s.allele == 0 || s.sure == 0.5) ? PARTNER_TIE : PARTNER_MIRROR));
     return certainty_flow_setup(pair, v, s, u.children[r], sc, c);
 }
 
 // Mirror (u.mirror): the two values of a side start at y and 1 - y, their evidence shares are g and h - g, their priors p and
 // 1 - p: the gradient of one is the negative of the other's at the mirrored position, G_2(1 - x) = -G_1(x) (the data term
 // swaps a and b, logit changes sign), so the second flow is the first one mirrored and ends at 1 - its end, with the same
-// capped moves.  Where both values have evidence (and the side's called and prior alleles are 0, 1 or 2) only the called
-// value's flow is run; the other gets 1 - result and the hits count twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
+// capped moves.  Where both values have evidence (the side's called and prior alleles being 0, 1 or 2 and its start not
+// exactly 1/2) only the called value's flow is run; the other gets 1 - result and the hits count twice.  The reference runs both (cnF2freq.cpp:4222-4290) and lands within rounding of this; CNF2_CERTAINTY_BOTH=1 in the
 // environment (and CNF2_UPDATE_PLAIN) keep that literal form, which the bit-exactness tests compare.
 // which item a position (item >> 1) runs under the mirror: the value the side is called as (the one that starts at or above
 // 1/2 and, as a rule, wins the pick of cnF2freq.cpp:4292-4300: its result is then bit for bit the literal one, and only the
@@ -353,10 +358,10 @@ __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* f
                                                 int* hits, int flow_hits_)
 {
     flow_out[item] = out;
-    if (u.mirror && partner == PARTNER_MIRROR) {
+    if (u.mirror == 1 && partner == PARTNER_MIRROR) {
         flow_out[item ^ 1] = 1.0 - out;
         *hits += flow_hits_;
-    } else if (u.mirror && partner == PARTNER_NONE) {
+    } else if (u.mirror == 1 && partner == PARTNER_NONE) {
         flow_out[item ^ 1] = 0.0;
     }
 }
@@ -375,15 +380,19 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
     bool     aside = false;
     FlowTodo e;
     if (t < n_items) {
-        // item0, n_items count items, or positions (items >> 1) under the mirror
-        const unsigned long long item = u.mirror ? certainty_mirror_item(u, item0 + t) : item0 + t;
+        // item0, n_items count items, or positions (items >> 1) in the mirror pass (u.mirror == 1); the pass of the ties
+        // (u.mirror == 2) goes over the items again and takes the sides the mirror pass left out, each value on its own
+        const unsigned long long item = u.mirror == 1 ? certainty_mirror_item(u, item0 + t) : item0 + t;
         CertaintyFlow c;
         int           both = PARTNER_NONE;
-        if (!certainty_item(u, item, sc, &c, &both)) {
+        const bool    present = certainty_item(u, item, sc, &c, &both);
+        if ((u.mirror == 1 && both == PARTNER_TIE) || (u.mirror == 2 && both != PARTNER_TIE)) {
+            // not this pass's
+        } else if (!present) {
             flow_out[item] = 0.0;
-            if (u.mirror) flow_out[item ^ 1] = 0.0;
+            if (u.mirror == 1) flow_out[item ^ 1] = 0.0;
         } else {
-            if (u.mirror && both == PARTNER_APART) {            // rare: the other value's own flow, literally and to its end
+            if (u.mirror == 1 && both == PARTNER_APART) {            // rare: the other value's own flow, literally and to its end
                 CertaintyFlow c2;
                 certainty_item(u, item ^ 1, sc, &c2);
                 FlowState f2;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
                 out.item_steps = (item << 6) | (unsigned long long)f.it;
                 out.path = f.path;
             }
-            todo[(u.mirror ? item >> 1 : item) - item0] = out;
+            todo[(u.mirror == 1 ? item >> 1 : item) - item0] = out;
             evals_all += evals;
         }
     }
@@ -696,7 +705,12 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     // todo_cap flows so that the list of flows set aside stays bounded.
     (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
     const size_t cap = u.todo_cap;
-    const size_t nc = u.mirror ? n1 * 2 : n1 * 4;            // positions under the mirror, else items
+    // the certainties: every flow (u.mirror == 0), or the mirror pass over the sides (1) and then the pass of the ties (2)
+    for (int pass = u.mirror ? 1 : 0; pass <= (u.mirror ? 2 : 0); pass++) {
+    UpdateParams up = u;
+    up.mirror = pass;
+    const UpdateParams& u = up;
+    const size_t nc = pass == 1 ? n1 * 2 : n1 * 4;           // positions in the mirror pass, else items
     for (size_t i0 = 0; i0 < nc; i0 += cap) {
         const size_t n = nc - i0 < cap ? nc - i0 : cap;
         (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
@@ -712,6 +726,7 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         }
         hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                            (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+    }
     }
     hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
     hipLaunchKernelGGL(phase_ratio_kernel, dim3((n2 + 63) / 64), dim3(64), 0, stream, u);
