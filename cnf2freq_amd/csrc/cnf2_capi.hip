@@ -1144,7 +1144,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         }
         if (reserve_only) {
             // ... and the buffers of the update passes (cnf2_update_pass): results of a chromosome's flows, the scouts' list
-            if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 26 * sizeof(unsigned long long)));
+            if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
             if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)mlen * 4))) return rc;
             if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, ((size_t)1 << 27) * 3))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1519,7 +1519,7 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     u.entropyfactor = entropyfactor;
     u.hits = ctx->d_hits;
     if (!(flags & CNF2_UPDATE_PLAIN)) {
-        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 26 * sizeof(unsigned long long)));
+        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
         if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)(u.last - u.first + 1) * 4))) return rc;
         // the scouts work through their flows in chunks; a chunk's worth of set-aside entries (24 bytes each)
         const size_t chunk = (size_t)1 << 27;

@@ -353,6 +353,18 @@ __device__ __forceinline__ unsigned long long certainty_mirror_item(const Update
     if (!(inf[v] > 0)) v ^= 1;
     return pos * 2 + v;
 }
+// the pass of the ties looks at every item: most are sorted out from the called allele and its certainty alone
+__device__ __forceinline__ bool certainty_may_tie(const UpdateParams& u, unsigned long long item)
+{
+    const int          len = u.last - u.first + 1;
+    const int          side = (int)((item >> 1) & 1);
+    const unsigned long long e = item >> 2;
+    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
+    const uint8_t      ap = u.allele8[i];
+    const double2      su = u.sure[i];
+    return (side ? (ap >> 4) : (ap & 15)) == 0 || (side ? su.y : su.x) == 0.5;
+}
 // the result of a flow (and of its mirror image)
 __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* flow_out, unsigned long long item, int partner, double out,
                                                 int* hits, int flow_hits_)
@@ -385,8 +397,9 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
         const unsigned long long item = u.mirror == 1 ? certainty_mirror_item(u, item0 + t) : item0 + t;
         CertaintyFlow c;
         int           both = PARTNER_NONE;
-        const bool    present = certainty_item(u, item, sc, &c, &both);
-        if ((u.mirror == 1 && both == PARTNER_TIE) || (u.mirror == 2 && both != PARTNER_TIE)) {
+        const bool    look = u.mirror != 2 || certainty_may_tie(u, item);
+        const bool    present = look && certainty_item(u, item, sc, &c, &both);
+        if (!look || (u.mirror == 1 && both == PARTNER_TIE) || (u.mirror == 2 && both != PARTNER_TIE)) {
             // not this pass's
         } else if (!present) {
             flow_out[item] = 0.0;
@@ -433,6 +446,8 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
         if (!aside) e.item_steps = ~0ull;                     // nothing set aside in this slot
         todo[t] = e;
     }
+    // the pass of the ties mostly sets nothing aside: its second scout pass and its finish pass return at once unless told
+    if (u.mirror == 2 && aside) u.flow_next[(e.item_steps & FLOW_SCOUTING) ? 27 : 26] = 1ull;
     flow_hits(u.hits, hits);
     flow_stats(u.stats, n_flows, (unsigned)evals, n_done, n_pinned);
 }
@@ -447,6 +462,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
     FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
     int      hits = 0, evals_all = 0;
     unsigned n_done = 0;
+    if (u.mirror == 2 && u.flow_next[27] == 0ull) return;
     for (;;) {
         flow_supply(&q, queue, next, (const FlowTodo*)todo, n_items, 64, true);
         if (q.count == 0) break;
@@ -475,6 +491,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
             } else {
                 out.item_steps = (item << 6) | (unsigned long long)f.it;
                 out.path = f.path;
+                if (u.mirror == 2) u.flow_next[26] = 1ull;
             }
             todo[(u.mirror == 1 ? item >> 1 : item) - item0] = out;
             evals_all += evals;
@@ -490,6 +507,7 @@ __global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, un
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
     __shared__ FlowTodo  queue[FLOW_QUEUE];
     FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
+    if (u.mirror == 2 && u.flow_next[26] == 0ull) return;
     bool               have = false;
     int                both = PARTNER_NONE;
     unsigned long long item = 0;
@@ -714,6 +732,7 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     for (size_t i0 = 0; i0 < nc; i0 += cap) {
         const size_t n = nc - i0 < cap ? nc - i0 : cap;
         (void)hipMemsetAsync(u.flow_next, 0, 2 * sizeof(unsigned long long), stream);
+        (void)hipMemsetAsync(u.flow_next + 26, 0, 2 * sizeof(unsigned long long), stream);     // the pass of the ties: anything set aside?
         const size_t w = (n + 63) / 64;
         if (u.scout_passes == 1) {
             hipLaunchKernelGGL(certainty_scout_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (unsigned long long)i0,
