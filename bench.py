@@ -10,6 +10,13 @@ shift modes, likelihoods and the per-locus dosage rows) over the rank's individu
 resident in HBM.  Individuals shard across ranks with no data-path collective (weak scaling:
 every rank owns --inds individuals); after the sweep the posteriors are gathered on rank 0
 with one RCCL gather inside the timed region.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process starts the N
+ranks itself -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
+arguments>` as a CHILD process, before anything here has imported torch or loaded the HIP
+library (a process that has touched the GPU must not start or become another program's
+launcher) -- relays rank 0's JSON line on stdout and exits with the child's code.  The
+partition the ranks take is the reference's own (cnF2freq.cpp:5297-5299).
 """
 import os
 
@@ -22,6 +29,61 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def requested_gpus(argv):
+    """--gpus N of the command line, read without argparse's exit paths (the full parser runs in the ranks)."""
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def launch_ranks(argv):
+    """Start `--gpus N` ranks as a child process when no launcher did (see the module docstring).  Returns None when
+    this process is itself a rank (or N = 1), else the exit code to leave with.  Nothing that initialises HIP may
+    have been imported when this runs: CNF2_BENCH_PARENT_TRACE=<file> records sys.modules at the moment of the
+    spawn for the test that checks it."""
+    n = requested_gpus(argv)
+    if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    trace = os.environ.get("CNF2_BENCH_PARENT_TRACE")
+    if trace:
+        with open(trace, "w") as f:
+            json.dump({"modules": sorted(sys.modules), "cmd": cmd}, f)
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in child.stdout:                 # rank 0's JSON line goes to stdout, anything else a rank printed to stderr
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print("bench.py: the ranks printed %d result lines, expected 1" % lines, file=sys.stderr)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = launch_ranks(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
 
 import numpy as np
 import torch
@@ -224,6 +286,10 @@ def main_iterations(args):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend="gloo")
+        world = dist.get_world_size()        # n_gpus of the line = the world the process group really has
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the process group has %d rank(s): reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -313,6 +379,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend="gloo")
+        world = dist.get_world_size()        # n_gpus of the line = the world the process group really has
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the process group has %d rank(s): reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
     torch.cuda.set_device(local)
@@ -460,12 +530,19 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # every rank's own launch time and kernel clock (roofline per rank: the ranks run the same launch on their own GPU)
+    sweep_clock_mhz = ctx.sweep_clock()          # the last timed launch's own shader / wall clock stamps
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    mine = torch.tensor([k_ms, sweep_clock_mhz], dtype=torch.float64, device=tmax.device)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(x) for x in t.cpu()] for t in per_rank]
 
     if rank == 0:
         units_per_step = float(n) * M * world
         value = units_per_step * args.steps / dt
-        sweep_clock_mhz = ctx.sweep_clock()          # the last timed launch's own shader / wall clock stamps
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = (float(n) * M * B_UNIT) / (k_ms * 1e-3) / 1e9   # GB/s, this rank's launch
         # HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json, written by
         # tools/profile_round.sh): reported only if it was measured for THIS workload and THESE kernel sources
@@ -552,7 +629,11 @@ def main():
                          "algorithmic_bytes_per_unit": B_UNIT, "kernel_src_sha": src_sha,
                          "effective_clock_mhz": clock_mhz, "sweep_kernel_clock_mhz": sweep_clock_mhz,
                          "fma_probe_clock_mhz": probe_mhz,
-                         "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac},
+                         "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac,
+                         # achieved / frac above are rank 0's launch; every rank's own launch beside it
+                         "per_rank": [{"rank": r, "kernel_ms": km, "achieved": float(n) * M * B_UNIT / (km * 1e-3) / 1e9,
+                                       "frac": float(n) * M * B_UNIT / (km * 1e-3) / HBM_PEAK,
+                                       "sweep_kernel_clock_mhz": ck} for r, (km, ck) in enumerate(per_rank)]},
             "loglik_checksum": float(np.sum(ll[np.isfinite(ll)])),
             "checks": checks,
             "gather_ms_per_step": float(np.mean(gather_ms)) if gather_ms else 0.0,
@@ -560,10 +641,10 @@ def main():
         }
         if merge_info:
             out["merge_modes"] = merge_info
-        if args.cpu_seconds > 0 and world == 1 and sample is not None:      # CPU baseline leg: rank 0 at N = 1 only
+        if args.cpu_seconds > 0 and sample is not None:      # CPU baseline leg: rank 0, after the timed region, at every N
             try:
                 out["cpu_baseline"] = cpu_baseline(sample, pos, starts, args)
-                out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]      # whole job over the CPU path
             except Exception as e:  # the baseline must never take the GPU line down
                 out["cpu_baseline"] = {"value": None, "unit": "individual*marker/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
