@@ -33,7 +33,7 @@ SYMBOLS = [
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
-    "cnf2_set_grid_reserve",
+    "cnf2_set_grid_reserve", "cnf2_set_batch_jobs",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
         L.cnf2_clock_probe.argtypes = [vp, vp]
         L.cnf2_sweep_clock.argtypes = [vp, vp]
         L.cnf2_set_grid_reserve.argtypes = [vp, i32]
+        L.cnf2_set_batch_jobs.argtypes = [vp, i32]
         L.cnf2_stream.argtypes = [vp]
         L.cnf2_stream.restype = vp
         _lib = L
@@ -243,6 +244,10 @@ class Context:
 
     def set_grid_reserve(self, blocks):
         self._chk(self.L.cnf2_set_grid_reserve(self.h, blocks), "cnf2_set_grid_reserve")
+
+    def set_batch_jobs(self, jobs):
+        """Cap on the jobs per batch of sweep_accumulate / sweep_turn_scan (0 = what memory allows)."""
+        self._chk(self.L.cnf2_set_batch_jobs(self.h, jobs), "cnf2_set_batch_jobs")
 
     def workspace_bytes(self):
         return int(self.L.cnf2_workspace_bytes(self.h))

@@ -52,6 +52,7 @@ struct cnf2_ctx {
     uint8_t*            d_rowflags = nullptr;
     int                 fast_blocks_per_cu = 1;
     int                 reserve_blocks = 0;     // workgroup slots left free for concurrent kernels (RCCL)
+    int                 batch_jobs = 0;         // cap on the jobs per batch of the batched consumers (0 = what memory allows)
 
     // workspace
     Job*    d_jobs = nullptr;
@@ -251,6 +252,13 @@ int cnf2_set_grid_reserve(cnf2_ctx* ctx, int blocks)
 {
     if (!ctx || blocks < 0) return CNF2_ERR_ARG;
     ctx->reserve_blocks = blocks;
+    return CNF2_OK;
+}
+
+int cnf2_set_batch_jobs(cnf2_ctx* ctx, int jobs)
+{
+    if (!ctx || jobs < 0) return CNF2_ERR_ARG;
+    ctx->batch_jobs = jobs;
     return CNF2_OK;
 }
 
@@ -1116,7 +1124,8 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->spill_bytes + ctx->wbuf_cap * sizeof(double);
         // spill: one slot per resident wave, at most a quarter of what is free
-        int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu;
+        int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu - ctx->reserve_blocks;
+        if (grid_cap < 1) grid_cap = 1;
         const size_t per_blk = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
         if ((size_t)grid_cap * per_blk > free_b / 4) grid_cap = (int)(free_b / 4 / per_blk);
         if (grid_cap < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the spill of one block");
@@ -1132,6 +1141,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the weights of one job (%zu MB)", per_job >> 17);
         if (batch > jobs.size()) batch = jobs.size();
         if (batch > 1000000) batch = 1000000;
+        if (ctx->batch_jobs > 0 && batch > (size_t)ctx->batch_jobs) batch = (size_t)ctx->batch_jobs;
         {
             // CNF2_TIMING: the first call of a run allocates the batch buffer (up to half the free memory) -- seconds
             const bool timing = getenv("CNF2_TIMING") != nullptr && ctx->wbuf_cap < batch * per_job;
@@ -1312,7 +1322,8 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     free_b += ctx->spill_bytes + ctx->wbuf_cap * sizeof(double);
-    int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu;
+    int          grid_cap = ctx->n_cu * ctx->fast_blocks_per_cu - ctx->reserve_blocks;
+    if (grid_cap < 1) grid_cap = 1;
     const size_t per_blk = (size_t)CNF2_WAVES_PER_BLOCK * stride * sizeof(double);
     if ((size_t)grid_cap * per_blk > free_b / 4) grid_cap = (int)(free_b / 4 / per_blk);
     if (grid_cap < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the spill of one block");
@@ -1327,6 +1338,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the alpha/beta rows of one job");
     if (batch > jobs.size()) batch = jobs.size();
     if (batch > 1000000) batch = 1000000;
+    if (ctx->batch_jobs > 0 && batch > (size_t)ctx->batch_jobs) batch = (size_t)ctx->batch_jobs;
     if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
     KernelParams p;
     base_params(ctx, &p);

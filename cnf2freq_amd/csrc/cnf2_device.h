@@ -110,7 +110,8 @@ void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream);
 // (cnF2freq.cpp:6232-6392): processinfprobs for the markers of that chromosome, updatehaploweights for every marker
 // of the chromosomes swept so far in this iteration.
 struct UpdateParams {
-    int            n_rec, n_markers, n_chrom, chrom, first, last;   // first / last marker of `chrom`
+    int            n_rec, n_markers, n_chrom, chrom, first, last;   // first / last marker of `chrom`; n_rec = records this pass updates
+    const int32_t* rec_list;      // device [n_rec] the records this pass updates (ascending), or null = records 0 .. n_rec - 1
     int            chromstarts_host_upto;                           // chromstarts[chrom + 1]
     const int32_t* chromstarts;   // device [n_chrom + 1]
     const int32_t* row_of;        // [n_rec]

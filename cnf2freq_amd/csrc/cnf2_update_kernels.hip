@@ -17,6 +17,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The records a pass updates: all of them, or the listed ones (a rank of a multi-process run updates the records it owns;
+// u.n_rec counts the listed records then).  Everything indexed by record -- accumulators, rows, scratch -- keeps the
+// record's own index; only the flows' item numbers (and flow_out, which they index) count listed records.
+__device__ __forceinline__ int update_rec(const UpdateParams& u, size_t listed) { return u.rec_list ? u.rec_list[listed] : (int)listed; }
+
 // ---------------------------------------------------------------------------------------------------
 // Per-iteration parameter updates on the device (cnf2_update.h; processinfprobs / updatehaploweights,
 // cnF2freq.cpp:4179-4323, 4533-4734), after the sweep of chromosome `chrom` has been accounted for.
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(256) void certainty_update_kernel(UpdateParams u)
     const int len = u.last - u.first + 1;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)u.n_rec * len) return;
-    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    const int r = update_rec(u, (size_t)(t / len)), m = u.first + (int)(t % len);
     double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
     const size_t i = (size_t)u.row_of[r] * u.n_markers + m;
     const bool   has_prior = u.has_prior[r] != 0, empty = u.rec_empty[r] != 0;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(64) void phase_ratio_kernel(UpdateParams u)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= u.n_rec * (u.chrom + 1)) return;
-    const int r = t / (u.chrom + 1), c = t % (u.chrom + 1);
+    const int r = update_rec(u, (size_t)(t / (u.chrom + 1))), c = t % (u.chrom + 1);
     const int c0 = u.chromstarts[c], c1 = u.chromstarts[c + 1];
     const double* hc = u.acc_hc + (size_t)r * u.n_markers;
     bool any = false;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void haploweight_update_kernel(UpdateParams u)
     const int    upto = u.chromstarts[u.chrom + 1];
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)u.n_rec * upto) return;
-    const int r = (int)(t / upto), m = (int)(t % upto);
+    const int r = update_rec(u, (size_t)(t / upto)), m = (int)(t % upto);
     int c = 0;
     while (m >= u.chromstarts[c + 1]) c++;
     if (!u.anyinfo[(size_t)r * u.n_chrom + c]) return;
@@ -307,7 +312,7 @@ __device__ __forceinline__ bool certainty_item(const UpdateParams& u, unsigned l
     const int          len = u.last - u.first + 1;
     const int          v = (int)(item & 1), side = (int)((item >> 1) & 1);
     const unsigned long long e = item >> 2;
-    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const int          r = update_rec(u, (size_t)(e / len)), m = u.first + (int)(e % len);
     const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
     const double       pair[2] = {inf[0], inf[1]};
     const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
@@ -340,7 +345,7 @@ __device__ __forceinline__ unsigned long long certainty_mirror_item(const Update
     const int          len = u.last - u.first + 1;
     const int          side = (int)(pos & 1);
     const unsigned long long e = pos >> 1;
-    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const int          r = update_rec(u, (size_t)(e / len)), m = u.first + (int)(e % len);
     const double*      inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4 + side * 2;
     const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
     const uint8_t      ap = u.allele8[i];
@@ -359,7 +364,7 @@ __device__ __forceinline__ bool certainty_may_tie(const UpdateParams& u, unsigne
     const int          len = u.last - u.first + 1;
     const int          side = (int)((item >> 1) & 1);
     const unsigned long long e = item >> 2;
-    const int          r = (int)(e / len), m = u.first + (int)(e % len);
+    const int          r = update_rec(u, (size_t)(e / len)), m = u.first + (int)(e % len);
     const size_t       i = (size_t)u.row_of[r] * u.n_markers + m;
     const uint8_t      ap = u.allele8[i];
     const double2      su = u.sure[i];
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) void certainty_pick_kernel(UpdateParams u, con
     const int    len = u.last - u.first + 1;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)u.n_rec * len) return;
-    const int r = (int)(t / len), m = u.first + (int)(t % len);
+    const int r = update_rec(u, (size_t)(t / len)), m = u.first + (int)(t % len);
     double*   inf = u.acc_inf + ((size_t)r * u.n_markers + m) * 4;
     const double4 a = *(const double4*)inf, o = *(const double4*)(flow_out + t * 4);
     if (a.x == 0.0 && a.y == 0.0 && a.z == 0.0 && a.w == 0.0) return;          // nothing was added, nothing to clear
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(256) void certainty_pick_kernel(UpdateParams u, con
 __device__ __forceinline__ bool haplo_item(const UpdateParams& u, unsigned long long item, size_t* row_i, size_t* k, int* r_out)
 {
     const int upto = u.chromstarts_host_upto;
-    const int r = (int)(item / upto), m = (int)(item % upto);
+    const int r = update_rec(u, (size_t)(item / upto)), m = (int)(item % upto);
     int       c = 0;
     while (m >= u.chromstarts[c + 1]) c++;
     *row_i = (size_t)u.row_of[r] * u.n_markers + m;

@@ -325,6 +325,11 @@ void  *cnf2_stream(cnf2_ctx *ctx); /* hipStream_t of the context */
  * workgroup slot of the GPU.  Leaving `blocks` slots free lets another kernel -- the RCCL gather of
  * the previous sweep's posteriors -- run beside the sweep instead of behind it. */
 int    cnf2_set_grid_reserve(cnf2_ctx *ctx, int blocks);
+/* The batched consumers (cnf2_sweep_accumulate, cnf2_sweep_turn_scan) run their jobs (individual x chromosome) in batches
+ * sized to the memory that is free; `jobs` > 0 caps a batch at that many jobs (0 = no cap).  Results do not depend on the
+ * batch size; the knob exists so that the multi-batch path can be exercised at test sizes and memory use bounded by a caller
+ * that shares the GPU. */
+int    cnf2_set_batch_jobs(cnf2_ctx *ctx, int jobs);
 
 #ifdef __cplusplus
 }

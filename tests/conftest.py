@@ -108,6 +108,31 @@ def oracle_ped(ped):
     return OraclePed(a, s, h, ped.par, ped.empty, ped.pos)
 
 
+def oracle_accumulate_threaded(o, ped, desc, first, last, threads=None):
+    """o.accumulate(ped.dous, ...) with the individuals spread over threads: what an individual adds to the per-record
+    accumulators does not depend on the others (cnF2freq.cpp:5876-5902 runs per individual), so the slabs of disjoint groups
+    add up to the whole list's; homozyg is per individual.  The oracle's C code is reentrant and ctypes drops the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(ped.dous)
+    threads = threads or max(1, min(16, len(os.sched_getaffinity(0)), n))
+    chunks = [np.arange(k, n, threads) for k in range(threads)]
+    chunks = [c for c in chunks if len(c)]
+    gens = ped.gen[ped.dous]
+
+    def work(idx):
+        return idx, o.accumulate(ped.dous[idx], gens[idx], desc, first=first, last=last)
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        parts = list(ex.map(work, chunks))
+    out = {k: np.zeros_like(parts[0][1][k]) for k in ("infprobs", "haplobase", "haplocount")}
+    nm = last - first + 1
+    out["homozyg"] = np.zeros((n, nm, 2))
+    for idx, r in parts:
+        for k in ("infprobs", "haplobase", "haplocount"):
+            out[k] += r[k]
+        out["homozyg"][idx] = r["homozyg"]
+    return out
+
+
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
     return load_golden(request.param)

@@ -1,0 +1,177 @@
+"""GPU suite (-m gpu): the two code paths that test-size inputs never reached on their own.
+
+(a) The persistent job loop.  The sweep kernels keep one wave per job in flight up to what is resident (256 CUs x 2
+    blocks x 4 waves) and a wave that finishes a job takes the next one: LDS tables, spill slot, the mantissa / exponent
+    likelihood state, the lane id -- everything a wave carries from job k to job k + 1 -- is only exercised when there are
+    more jobs than resident waves.  cnf2_set_grid_reserve leaves all but ONE block free here, so 4 waves sweep every job
+    of the fixture (50 or more each); the results must equal the unconstrained launch to the bit and the oracle at the
+    usual tolerances -- plain sweep (cnF2freq.cpp:5294-5403), accumulate mode (5406-5583) and turn-scan mode (5668-5752).
+(b) The multi-batch path of the batched consumers: cnf2_set_batch_jobs caps a batch at 3 jobs, so cnf2_sweep_accumulate
+    and cnf2_sweep_turn_scan walk many batches on a two-chromosome pedigree; against the oracle and the one-batch run."""
+import numpy as np
+import pytest
+
+from cnf2freq_amd import synth
+from conftest import oracle_accumulate_threaded, oracle_ped
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+ONE_BLOCK = 1 << 20          # more slots than the GPU has: the grid is clamped to one block of 4 waves
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from cnf2freq_amd import capi as c
+    assert c.load().cnf2_device_count() >= 1, "no HIP device: the product path has no fallback"
+    return c
+
+
+def test_one_block_sweeps_config1_fifty_jobs_per_wave(capi):
+    """BASELINE configs[0] (F2 200 x 501): 200 jobs on 4 waves."""
+    ped = synth.make_f2(200, 500, 1, seed=12345, chrom_cm=100.0)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    free = ctx.sweep()
+    ctx.set_grid_reserve(ONE_BLOCK)
+    one = ctx.sweep()
+    ctx.set_grid_reserve(0)
+    for k in ("factors", "loglik", "dosage"):
+        assert np.array_equal(one[k], free[k]), "one block differs from the full grid in " + k
+    want = oracle_ped(ped).sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    np.testing.assert_allclose(one["factors"][:, 0], want["factors"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(one["loglik"][:, 0], want["factor"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(one["dosage"], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
+
+
+def test_one_block_sweeps_the_tied_advanced_intercross(capi):
+    """Advanced intercross with tied and untied windows over two chromosomes: both the plain and the tied instantiation
+    run their jobs on one block each (the tied kernel's job loop also restores beta and the scales per tie combination)."""
+    ped = synth.make_ail(6, 30, 4, 30, 2, seed=11, chrom_cm=60.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    n = len(ped.dous)
+    tied = sum(1 for j in range(n) if (ctx.window_info(j)["tie"] >= 0).any())
+    assert tied * 2 >= 40 and (n - tied) * 2 >= 100, (tied, n)
+    free = ctx.sweep()
+    ctx.set_grid_reserve(ONE_BLOCK)
+    one = ctx.sweep()
+    ctx.set_grid_reserve(0)
+    for k in ("factors", "loglik", "dosage"):
+        assert np.array_equal(one[k], free[k]), "one block differs from the full grid in " + k
+    o = oracle_ped(ped)
+    for c in range(2):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(one["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(one["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
+
+
+def _check_accumulators(got, ped, o, desc, rtol=1e-8):
+    for c in range(len(ped.chromstarts) - 1):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = oracle_accumulate_threaded(o, ped, desc, first, last)
+        for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+            np.testing.assert_allclose(got[k][:, first:last + 1], want[k], rtol=rtol, atol=1e-12, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["outbred", "ail"])
+def test_one_block_accumulate_mode(capi, kind):
+    """The accumulate instantiation (sweep + posterior weights + HOT LOOP 2 kernels) with every job on one block."""
+    if kind == "outbred":
+        ped = synth.make_outbred3(25, 4, 6, 2, seed=21, missing=0.2, random_hw=True, random_sure=True)
+    else:
+        ped = synth.make_ail(6, 25, 4, 6, 2, seed=13, chrom_cm=40.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    assert len(ped.dous) * 2 >= 200          # 50 jobs per wave of the one block
+    desc = ctx.descendants()
+    free = ctx.sweep_accumulate(desc, deterministic=True)
+    ctx.set_grid_reserve(ONE_BLOCK)
+    one = ctx.sweep_accumulate(desc, deterministic=True)
+    one_atomic = ctx.sweep_accumulate(desc)
+    ctx.set_grid_reserve(0)
+    # CNF2_DETERMINISTIC: every individual's contributions in a row of its own, added in ascending order -- the grid
+    # must not show in a single bit
+    for k in ("factors", "loglik", "dosage", "infprobs", "haplobase", "haplocount", "homozyg"):
+        assert np.array_equal(one[k], free[k], equal_nan=True), "one block differs from the full grid in " + k
+    o = oracle_ped(ped)
+    _check_accumulators(one, ped, o, desc)
+    _check_accumulators(one_atomic, ped, o, desc)
+    ctx.close()
+
+
+def test_one_block_turn_scan_mode(capi):
+    """The turn-scan instantiation (alpha after emission, beta and scales of every marker into the batch buffer) with
+    every job on one block: equal to the full grid to the bit, and to the oracle's aroundturner queries."""
+    ped = synth.make_outbred3(25, 4, 9, 2, seed=22, missing=0.2, random_hw=True, random_sure=True)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    raw_free, lse_free = ctx.sweep_turn_scan()
+    ctx.set_grid_reserve(ONE_BLOCK)
+    raw, lse = ctx.sweep_turn_scan()
+    ctx.set_grid_reserve(0)
+    assert np.array_equal(raw, raw_free, equal_nan=True) and np.array_equal(lse, lse_free, equal_nan=True)
+    o = oracle_ped(ped)
+    checked = 0
+    for j in range(0, len(ped.dous), 5):
+        ind = int(ped.dous[j])
+        gen = int(ped.gen[ind])
+        for c in range(2):
+            first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+            if not o.sweep_ind(ind, gen, first=first, last=last, mode=2)["ok"]:
+                continue
+            for m in (first, (first + last) // 2, last):
+                want = o.turn_scan(ind, m, gen, first=first, last=last)
+                live = ~np.isnan(want)
+                np.testing.assert_allclose(raw[j, m][live], want[live], rtol=1e-9, atol=1e-8)
+                checked += 1
+    assert checked > 20
+    ctx.close()
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_accumulate_in_batches_of_three_jobs(capi, deterministic):
+    """cnf2_sweep_accumulate with the batch capped at 3 jobs (cnf2_set_batch_jobs) on a two-chromosome outbred pedigree
+    with 20 % missing genotypes: 24 jobs = 8 batches per kernel, against the oracle and against the one-batch run."""
+    ped = synth.make_outbred3(4, 3, 17, 2, seed=31, missing=0.2, random_hw=True, random_sure=True)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = ctx.descendants()
+    whole = ctx.sweep_accumulate(desc, deterministic=deterministic)
+    ctx.set_batch_jobs(3)
+    got = ctx.sweep_accumulate(desc, deterministic=deterministic)
+    ctx.set_batch_jobs(0)
+    for k in ("factors", "loglik", "dosage", "homozyg"):
+        assert np.array_equal(got[k], whole[k], equal_nan=True), k
+    for k in ("infprobs", "haplobase", "haplocount"):
+        if deterministic:
+            assert np.array_equal(got[k], whole[k], equal_nan=True), k
+        else:
+            np.testing.assert_allclose(got[k], whole[k], rtol=1e-12, atol=1e-15, equal_nan=True, err_msg=k)
+    _check_accumulators(got, ped, oracle_ped(ped), desc)
+    ctx.close()
+
+
+def test_tied_accumulate_and_turn_scan_in_batches(capi):
+    """The same cap on an advanced intercross (tied windows take their own kernels and their own batches) and on the
+    batched turn scan."""
+    ped = synth.make_ail(4, 6, 3, 9, 2, seed=5, chrom_cm=20.0, missing=0.05)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = ctx.descendants()
+    whole = ctx.sweep_accumulate(desc, deterministic=True)
+    raw_whole, lse_whole = ctx.sweep_turn_scan()
+    ctx.set_batch_jobs(3)
+    got = ctx.sweep_accumulate(desc, deterministic=True)
+    raw, lse = ctx.sweep_turn_scan()
+    ctx.set_batch_jobs(0)
+    for k in ("factors", "loglik", "dosage", "infprobs", "haplobase", "haplocount", "homozyg"):
+        assert np.array_equal(got[k], whole[k], equal_nan=True), k
+    assert np.array_equal(raw, raw_whole, equal_nan=True) and np.array_equal(lse, lse_whole, equal_nan=True)
+    _check_accumulators(got, ped, oracle_ped(ped), desc)
+    ctx.close()
