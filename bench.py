@@ -274,10 +274,47 @@ def cpu_baseline(sample_packed, pos, starts, args):
                       % (k, mc, dt, what)}
 
 
+def cpu_baseline_iterations(args):
+    """CPU path of a haplotyping iteration timed beside the GPU on a bounded sample of the same workload: a few families of
+    the same generator (same seed, shape and missing rate), chromosome 1 only.  kind "reference" = the reference's own code
+    (oracle/_ref: its sweep, HOT LOOP 2 with reductions and the update functions cnF2freq.cpp:4004-4734, driven by
+    ref_iteration -- a serial replay of doit's loops, so 1 core); the oracle is the thing timed here, never the thing shipped."""
+    from cnf2freq_amd import synth
+    from oracle.ref_extract import pyref
+    if not pyref.available(ieee=False):
+        return {"value": None, "unit": "individual*marker/s per iteration", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref is not built on this host"}
+
+    def run(fams, snps):
+        ped = synth.make_outbred3(fams, 4, snps, 1, seed=2, missing=0.2)
+        R = pyref.RefPed(ped, ieee=False, fixtrees_all=False)
+        R.set_priors()
+        R.set_dous()
+        R.L.ref_postmarkerdata(ped.n_rec + 1)
+        hits = np.zeros(1, np.int32)
+        t0 = time.perf_counter()
+        R.L.ref_iteration(hits.ctypes.data, None, ped.n_rec)
+        return time.perf_counter() - t0, len(ped.dous) * ped.n_markers
+
+    # the reference spends ~14 ms per individual x marker of an iteration (its updates bisect with a 15-point quadrature of a
+    # long polynomial per step): one family on a stretch of chromosome 1, sized from a 40-marker probe to the time budget
+    snps = min(40, args.snps_per_chrom)
+    dt, units = run(1, snps)
+    want = int(min(args.snps_per_chrom, max(snps, snps * args.cpu_seconds / max(dt, 1e-3))))
+    if want > snps * 1.5:
+        snps = want
+        dt, units = run(1, snps)
+    return {"value": units / dt, "unit": "individual*marker/s per iteration", "cores": 1, "kind": "reference",
+            "sample": "1 family (4 analysed individuals, 10 records) x %d markers of the same generator, one iteration after "
+                      "postmarkerdata, %.1f s" % (units // 4, dt)}
+
+
 def main_iterations(args):
     """BASELINE config 5's unit of work: haplotyping iterations of one pedigree, the analysed individuals split over the ranks
-    (work-balanced blocks), the per-record accumulators summed by one all-reduce per iteration (RCCL), every rank running the
-    same update passes.  Strong scaling (the pedigree is fixed).  One JSON line from rank 0 with the time of every iteration."""
+    in work-balanced blocks cut between families, every rank updating the records it owns; what ranks exchange per iteration
+    is the records their windows share (one reduce-scatter of their accumulators, one all-gather of their new rows -- nothing
+    when no family straddles a boundary) and the hit counters (cnf2freq_amd.dist.Transport over RCCL).  Strong scaling (the
+    pedigree is fixed).  One JSON line from rank 0 with the time of every iteration."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -312,7 +349,9 @@ def main_iterations(args):
     t0 = time.perf_counter()
     run = cdist.start_iterations(ped, device=local)
     t_setup = time.perf_counter() - t0
-    before = synth.dosage_accuracy(ped, run.state()) if rank == 0 else None
+    st0 = run.state()                 # (a collective once iterations have run: every rank calls it)
+    before = synth.dosage_accuracy(ped, st0) if rank == 0 else None
+    del st0
     for _ in range(args.warmup):
         run.iteration()
     if world > 1:
@@ -338,8 +377,9 @@ def main_iterations(args):
     ctypes.CDLL(None).fflush(None)          # the C library's own buffer of the engine's lines, before stdout comes back
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
+    st = run.state()                  # gathers every rank's private records: a collective, outside the timed region
     if rank == 0:
-        st = run.state()
+        plan = run.plan
         out = {
             "metric": "haplotyping iterations/s (BASELINE config 5: sweep + accumulators + update passes per iteration)",
             "value": args.iterations / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.iterations, "warmup": args.warmup,
@@ -349,13 +389,30 @@ def main_iterations(args):
                                    "20%% of genotypes missing, %d chromosomes x %d SNPs (+1 dummy each)"
                                    % (fams, R, n, chroms, args.snps_per_chrom),
                        "analysed_individuals": n, "markers": M,
-                       "parallelism": "analysed individuals in %d work-balanced block(s), one all-reduce (sum) of the accumulator "
-                                      "slabs per iteration, update passes replicated" % world},
+                       "parallelism": "analysed individuals in %d work-balanced block(s) cut between families; per iteration one "
+                                      "reduce-scatter of the shared records' accumulators, update passes of the records a rank "
+                                      "owns, one sum of the hit counters per pass, one all-gather of the shared records' rows" % world},
+            # what the collectives carry per iteration: the buffers' bytes and the payload in them (shared records x (48 + 25) B
+            # x markers + 4 B per chromosome pass); the full slabs an all-reduce of everything would move, for scale
+            "exchange_bytes_per_iteration": plan["bytes_accumulators"] + plan["bytes_rows"] + plan["bytes_hits"],
+            "exchange": {"shared_records": plan["n_shared"], "records": R, "payload_bytes_per_iteration": plan["bytes_payload"],
+                         "reduce_scatter_buffer_bytes": plan["bytes_accumulators"], "all_gather_buffer_bytes": plan["bytes_rows"],
+                         "hit_counter_bytes": plan["bytes_hits"], "full_slab_bytes": R * M * 48,
+                         "bytes_moved_by_rank0_in_all": run.transport.bytes_moved,
+                         "records_owned_by_rank0": int(len(plan["owned"]))},
             "units_per_s": float(n) * M * args.iterations / dt,
             "iteration_s": per_it, "block": list(run.block), "setup_s": t_setup,
             "scalefactor": st["scalefactor"], "last_hits": st["hits"],
             "withheld_genotypes_before": before, "withheld_genotypes_after": synth.dosage_accuracy(ped, st),
         }
+        if args.cpu_seconds > 0:          # CPU baseline leg: rank 0, after the timed region, at every N
+            try:
+                out["cpu_baseline"] = cpu_baseline_iterations(args)
+                if out["cpu_baseline"]["value"]:
+                    out["gpu_over_cpu"] = out["units_per_s"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline must never take the GPU line down
+                out["cpu_baseline"] = {"value": None, "unit": "individual*marker/s per iteration", "cores": 0, "kind": "reference",
+                                       "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     run.close()
     if world > 1:

@@ -19,6 +19,8 @@ ACC_TABLE = 1024
 ACC_LANES = 2048
 TIES_GENERAL = 4096
 UPDATE_PLAIN = 8192
+UPDATE_BOTH_FLOWS = 1 << 16       # both allele values' certainty flows (the bit-exact form of the fast update kernels)
+UPDATE_ONE_SCOUT = 1 << 17        # the certainties' scout in one pass (A/B)
 DETERMINISTIC = 16384
 TURN_VALU = 32768
 MINFACTOR = float(np.float32(-1e15))
@@ -33,7 +35,9 @@ SYMBOLS = [
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
-    "cnf2_set_grid_reserve", "cnf2_set_batch_jobs",
+    "cnf2_set_grid_reserve", "cnf2_set_batch_jobs", "cnf2_window_table", "cnf2_update_pass_records", "cnf2_exchange_buffer", "cnf2_exchange_download", "cnf2_exchange_upload",
+    "cnf2_packed_accumulator_doubles", "cnf2_packed_row_bytes", "cnf2_pack_accumulators", "cnf2_unpack_accumulators",
+    "cnf2_pack_rows", "cnf2_unpack_rows",
 ]
 
 
@@ -124,6 +128,17 @@ def load():
         L.cnf2_sweep_clock.argtypes = [vp, vp]
         L.cnf2_set_grid_reserve.argtypes = [vp, i32]
         L.cnf2_set_batch_jobs.argtypes = [vp, i32]
+        L.cnf2_window_table.argtypes = [vp, vp]
+        L.cnf2_update_pass_records.argtypes = [vp, i32, vp, i32, vp, vp, C.c_double, C.c_double, vp, C.c_uint32]
+        L.cnf2_exchange_buffer.argtypes = [vp, C.c_size_t, vp]
+        L.cnf2_exchange_download.argtypes = [vp, vp, C.c_size_t]
+        L.cnf2_exchange_upload.argtypes = [vp, vp, C.c_size_t]
+        L.cnf2_packed_accumulator_doubles.argtypes = [vp]
+        L.cnf2_packed_accumulator_doubles.restype = C.c_size_t
+        L.cnf2_packed_row_bytes.argtypes = [vp]
+        L.cnf2_packed_row_bytes.restype = C.c_size_t
+        for f in (L.cnf2_pack_accumulators, L.cnf2_unpack_accumulators, L.cnf2_pack_rows, L.cnf2_unpack_rows):
+            f.argtypes = [vp, vp, i32, vp]
         L.cnf2_stream.argtypes = [vp]
         L.cnf2_stream.restype = vp
         _lib = L
@@ -208,6 +223,25 @@ class Context:
         self.upload_map(ped.pos, ped.chromstarts)
         self.upload_rows(ped.allele, ped.sure, ped.hw)
         self.upload_pedigree(ped.par, ped.empty, ped.gen, ped.row_of, ped.dous if dous is None else dous)
+
+    def upload_for_updates(self, ped, has_prior=None):
+        """upload() in the form the update passes need: one genotype row per record (row 0 stays the blank row; updates
+        write rows in place), and the rows remembered as priors (records that are not `empty` count as genotyped)."""
+        a, s, h = ped.dense()
+        R = ped.n_rec
+        self.upload_map(ped.pos, ped.chromstarts)
+        self.upload_rows(np.concatenate([a[:1] * 0, a]).astype(np.uint8), np.concatenate([s[:1] * 0, s]),
+                         np.concatenate([h[:1] * 0 + 0.5, h]))
+        self.upload_pedigree(ped.par, ped.empty, ped.gen, np.arange(1, R + 1, dtype=np.int32), ped.dous)
+        self.snapshot_priors((1 - np.asarray(ped.empty)).astype(np.uint8) if has_prior is None else has_prior)
+
+    def sweep_accumulate_keep(self, desc, ind_begin=0, ind_end=None, deterministic=False):
+        """One haplotyping sweep whose accumulators stay in the context (for update_pass(..., acc=None),
+        update_pass_records, pack_accumulators, download_accumulators)."""
+        ind_end = self.n_ind if ind_end is None else ind_end
+        desc = np.ascontiguousarray(desc, np.int32)
+        self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), None, None, None, None, None, None, None,
+                                               DETERMINISTIC if deterministic else 0), "cnf2_sweep_accumulate")
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
@@ -395,6 +429,43 @@ class Context:
         self._chk(self.L.cnf2_update_pass(self.h, chrom, _p(ch), _p(de), a[0], a[1], a[2], scalefactor, entropyfactor,
                                           _p(hits), flags), "cnf2_update_pass")
         return int(hits[0])
+
+    def update_pass_records(self, chrom, recs, children, descendants, scalefactor, entropyfactor=1.0, flags=0):
+        """update_pass restricted to the listed records (ascending), on the accumulators the context holds."""
+        rc_ = np.ascontiguousarray(recs, np.int32)
+        ch = np.ascontiguousarray(children, np.int32)
+        de = np.ascontiguousarray(descendants, np.int32)
+        hits = np.zeros(1, np.int32)
+        self._chk(self.L.cnf2_update_pass_records(self.h, chrom, _p(rc_), len(rc_), _p(ch), _p(de), scalefactor, entropyfactor,
+                                                  _p(hits), flags), "cnf2_update_pass_records")
+        return int(hits[0])
+
+    def window_table(self):
+        """window_info() of every analysed individual in one call: int32 [n_ind][17]."""
+        out = np.zeros((self.n_ind, 17), np.int32)
+        self._chk(self.L.cnf2_window_table(self.h, _p(out)), "cnf2_window_table")
+        return out
+
+    def exchange_buffer(self, nbytes):
+        p = C.c_void_p(0)
+        self._chk(self.L.cnf2_exchange_buffer(self.h, nbytes, C.byref(p)), "cnf2_exchange_buffer")
+        return p.value
+
+    def pack_accumulators(self, recs, d_packed):
+        r = np.ascontiguousarray(recs, np.int32)
+        self._chk(self.L.cnf2_pack_accumulators(self.h, _p(r), len(r), C.c_void_p(d_packed)), "cnf2_pack_accumulators")
+
+    def unpack_accumulators(self, recs, d_packed):
+        r = np.ascontiguousarray(recs, np.int32)
+        self._chk(self.L.cnf2_unpack_accumulators(self.h, _p(r), len(r), C.c_void_p(d_packed)), "cnf2_unpack_accumulators")
+
+    def pack_rows(self, recs, d_packed):
+        r = np.ascontiguousarray(recs, np.int32)
+        self._chk(self.L.cnf2_pack_rows(self.h, _p(r), len(r), C.c_void_p(d_packed)), "cnf2_pack_rows")
+
+    def unpack_rows(self, recs, d_packed):
+        r = np.ascontiguousarray(recs, np.int32)
+        self._chk(self.L.cnf2_unpack_rows(self.h, _p(r), len(r), C.c_void_p(d_packed)), "cnf2_unpack_rows")
 
     def clock_probe(self):
         """Shader clock under a double-precision vector load, MHz."""

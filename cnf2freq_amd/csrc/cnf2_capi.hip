@@ -107,6 +107,12 @@ struct cnf2_ctx {
     int32_t* d_pathlog = nullptr;
     size_t   pathlog_cap = 0;
     int      pathlog_n = 0;
+    int32_t* d_updrecs = nullptr;         // the records an update pass is restricted to
+    size_t   updrecs_cap = 0;
+    int32_t* d_xidx = nullptr;            // index lists of the exchange packers
+    size_t   xidx_cap = 0;
+    uint8_t* d_xbuf = nullptr;            // staging buffer of the exchanges (cnf2_exchange_buffer)
+    size_t   xbuf_cap = 0;
     Window*  d_scanwin = nullptr;
     size_t   scanwin_cap = 0;
     uint8_t* d_okout = nullptr;
@@ -235,6 +241,9 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_todo);
     (void)hipFree(ctx->d_part);
     (void)hipFree(ctx->d_gather);
+    (void)hipFree(ctx->d_updrecs);
+    (void)hipFree(ctx->d_xidx);
+    (void)hipFree(ctx->d_xbuf);
     (void)hipFree(ctx->d_scanwin);
     (void)hipFree(ctx->d_pathlog);
     (void)hipFree(ctx->d_okout);
@@ -498,6 +507,17 @@ int cnf2_window_info(cnf2_ctx* ctx, int ind, int32_t* out17)
     for (int i = 0; i < 7; i++) {
         out17[3 + i]  = slot_rec[i];
         out17[10 + i] = w.tie[i];
+    }
+    return CNF2_OK;
+}
+
+int cnf2_window_table(cnf2_ctx* ctx, int32_t* out17_all)
+{
+    if (!ctx || !out17_all) return CNF2_ERR_ARG;
+    const int n = (int)ctx->windows.size();
+    for (int j = 0; j < n; j++) {
+        const int rc = cnf2_window_info(ctx, j, out17_all + (size_t)j * 17);
+        if (rc) return rc;
     }
     return CNF2_OK;
 }
@@ -1029,6 +1049,16 @@ int cnf2_descendants(cnf2_ctx* ctx, int32_t* desc_out)
     return CNF2_OK;
 }
 
+// Entries of the list the update scouts set flows aside on: a chunk of the pass's flows, at most 2^27 (3.2 GB)
+static size_t todo_chunk(size_t n_rec, size_t chrom_len, size_t markers_upto)
+{
+    const size_t n1 = n_rec * chrom_len * 4, n3 = n_rec * markers_upto;
+    size_t       want = n1 > n3 ? n1 : n3;
+    if (want < 4096) want = 4096;
+    const size_t cap = (size_t)1 << 27;
+    return want < cap ? want : cap;
+}
+
 enum : uint32_t { ACC_RESERVE_ONLY = 1u << 31 };     // internal flag of cnf2_sweep_accumulate (not in the header)
 
 // Batched HOT LOOP 2 with its reductions (cnF2freq.cpp:5416-5577, 5876-5902 with moveinfprobs / movehaplos
@@ -1156,7 +1186,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
             // ... and the buffers of the update passes (cnf2_update_pass): results of a chromosome's flows, the scouts' list
             if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
             if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)mlen * 4))) return rc;
-            if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, ((size_t)1 << 27) * 3))) return rc;
+            if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, todo_chunk(R, (size_t)mlen, M) * 3))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return CNF2_OK;
         }
@@ -1425,11 +1455,17 @@ int cnf2_snapshot_priors(cnf2_ctx* ctx, const uint8_t* has_prior)
     return CNF2_OK;
 }
 
-int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const int32_t* descendants, double* infprobs,
-                     double* haplobase, double* haplocount, double scalefactor, double entropyfactor, int* hits_out,
-                     uint32_t flags)
+static int update_pass_impl(cnf2_ctx* ctx, int chrom, const int32_t* recs, int n_recs, const int32_t* children,
+                            const int32_t* descendants, double* infprobs, double* haplobase, double* haplocount, double scalefactor,
+                            double entropyfactor, int* hits_out, uint32_t flags)
 {
     if (!ctx || !children || !descendants || !hits_out) return fail(ctx, CNF2_ERR_ARG, "bad update arguments");
+    if (recs) {
+        if (n_recs < 0) return fail(ctx, CNF2_ERR_ARG, "bad record list");
+        for (int i = 0; i < n_recs; i++)
+            if (recs[i] < 0 || recs[i] >= ctx->ped.n_rec || (i > 0 && recs[i] <= recs[i - 1]))
+                return fail(ctx, CNF2_ERR_ARG, "the record list must be ascending and within the pedigree (position %d)", i);
+    }
     if (!ctx->d_allele8 || ctx->ped.n_rec == 0 || !ctx->d_rho) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
     if (!ctx->priors_set) return fail(ctx, CNF2_ERR_STATE, "cnf2_snapshot_priors must be called after the rows were uploaded");
     if (chrom < 0 || chrom >= ctx->n_chrom) return fail(ctx, CNF2_ERR_ARG, "chromosome out of range");
@@ -1503,6 +1539,13 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     UpdateParams u;
     memset(&u, 0, sizeof(u));
     u.n_rec = P.n_rec;
+    if (recs) {
+        if ((rc = ensure(ctx, &ctx->d_updrecs, &ctx->updrecs_cap, (size_t)(n_recs > 0 ? n_recs : 1)))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_updrecs, recs, sizeof(int32_t) * n_recs, hipMemcpyHostToDevice, ctx->stream));
+        u.n_rec = n_recs;
+        u.rec_list = ctx->d_updrecs;
+    }
+    const size_t RU = (size_t)u.n_rec;         // records this pass updates
     u.n_markers = ctx->n_markers;
     u.n_chrom = ctx->n_chrom;
     u.chrom = chrom;
@@ -1532,21 +1575,21 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
     u.hits = ctx->d_hits;
     if (!(flags & CNF2_UPDATE_PLAIN)) {
         if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
-        if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)(u.last - u.first + 1) * 4))) return rc;
-        // the scouts work through their flows in chunks; a chunk's worth of set-aside entries (24 bytes each)
-        const size_t chunk = (size_t)1 << 27;
+        if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, (RU ? RU : 1) * (size_t)(u.last - u.first + 1) * 4))) return rc;
+        // the scouts work through their flows in chunks; a chunk's worth of set-aside entries (24 bytes each), no more
+        // than the pass has flows (certainties: 4 per record and marker of the chromosome; weights: 1 per record and marker
+        // of the chromosomes so far)
+        const size_t chunk = todo_chunk(RU, (size_t)(u.last - u.first + 1), (size_t)u.chromstarts_host_upto);
         if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, chunk * 3))) return rc;
         u.flow_next = ctx->d_flow_next;
         u.flow_out = ctx->d_flow_out;
-        u.stats = getenv("CNF2_UPDATE_STATS") ? ctx->d_flow_next + 2 : nullptr;     // diagnostics cost a few atomics per wavefront
+        u.stats = getenv("CNF2_UPDATE_STATS") ? ctx->d_flow_next + 2 : nullptr;     // diagnostics only (no effect on results): a few atomics per wavefront
         u.todo = ctx->d_todo;
-        u.todo_cap = chunk;
-        const char* sp = getenv("CNF2_SCOUT_PASSES");               // A/B switch (tools/ab_scout.py): 1 = the certainties' scout in one pass
-        u.scout_passes = (sp && sp[0] == '1') ? 1 : 2;
-        const char* cb = getenv("CNF2_CERTAINTY_BOTH");             // 1 = both values' flows are run, as the reference does (bit-exact form)
-        u.mirror = (cb && cb[0] == '1') ? 0 : 1;
+        u.todo_cap = ctx->todo_cap / 3;
+        u.scout_passes = (flags & CNF2_UPDATE_ONE_SCOUT) ? 1 : 2;
+        u.mirror = (flags & CNF2_UPDATE_BOTH_FLOWS) ? 0 : 1;
     }
-    launch_update_pass(u, ctx->stream);
+    if (u.n_rec > 0) launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->windows_dirty = true;          // rows changed: the "homozygous everywhere" flags must be derived again
     HIP_TRY(ctx, hipMemcpyAsync(hits_out, ctx->d_hits, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1556,6 +1599,158 @@ int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const in
         HIP_TRY(ctx, hipMemcpyAsync(haplocount, a_hc, R * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_update_pass(cnf2_ctx* ctx, int chrom, const int32_t* children, const int32_t* descendants, double* infprobs,
+                     double* haplobase, double* haplocount, double scalefactor, double entropyfactor, int* hits_out,
+                     uint32_t flags)
+{
+    return update_pass_impl(ctx, chrom, nullptr, 0, children, descendants, infprobs, haplobase, haplocount, scalefactor, entropyfactor,
+                            hits_out, flags);
+}
+
+int cnf2_update_pass_records(cnf2_ctx* ctx, int chrom, const int32_t* recs, int n_recs, const int32_t* children,
+                             const int32_t* descendants, double scalefactor, double entropyfactor, int* hits_out, uint32_t flags)
+{
+    if (!recs && n_recs != 0) return fail(ctx, CNF2_ERR_ARG, "bad record list");
+    static const int32_t none = 0;
+    return update_pass_impl(ctx, chrom, recs ? recs : &none, n_recs, children, descendants, nullptr, nullptr, nullptr, scalefactor,
+                            entropyfactor, hits_out, flags & ~(uint32_t)CNF2_ACC_DEVICE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exchange support of multi-process runs: listed records' accumulators / rows to and from a packed device buffer
+// ------------------------------------------------------------------------------------------------
+int cnf2_exchange_buffer(cnf2_ctx* ctx, size_t bytes, void** d_buf)
+{
+    if (!ctx || !d_buf) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = ensure(ctx, &ctx->d_xbuf, &ctx->xbuf_cap, bytes ? bytes : 1);
+    if (rc) return rc;
+    *d_buf = ctx->d_xbuf;
+    return CNF2_OK;
+}
+
+int cnf2_exchange_download(cnf2_ctx* ctx, void* host_dst, size_t bytes)
+{
+    if (!ctx || !host_dst) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "more than the exchange buffer holds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_dst, ctx->d_xbuf, bytes, hipMemcpyDeviceToHost));
+    return CNF2_OK;
+}
+
+int cnf2_exchange_upload(cnf2_ctx* ctx, const void* host_src, size_t bytes)
+{
+    if (!ctx || !host_src) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "more than the exchange buffer holds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_xbuf, host_src, bytes, hipMemcpyHostToDevice));
+    return CNF2_OK;
+}
+
+size_t cnf2_packed_accumulator_doubles(const cnf2_ctx* ctx) { return ctx ? (size_t)ctx->n_markers * 6 : 0; }
+size_t cnf2_packed_row_bytes(const cnf2_ctx* ctx) { return ctx ? (((size_t)ctx->n_markers * 25 + 7) & ~(size_t)7) : 0; }
+
+// uploads recs (and, with rows, the rows they sit on) as index lists: d_xidx = [recs | rows]
+static int exchange_lists(cnf2_ctx* ctx, const int32_t* recs, int n, bool rows)
+{
+    if (!ctx || (!recs && n > 0) || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad record list");
+    if (ctx->ped.n_rec == 0 || !ctx->d_allele8) return fail(ctx, CNF2_ERR_STATE, "rows and pedigree must be uploaded first");
+    std::vector<int32_t> idx((size_t)n * 2);
+    for (int i = 0; i < n; i++) {
+        if (recs[i] < 0 || recs[i] >= ctx->ped.n_rec) return fail(ctx, CNF2_ERR_ARG, "record out of range at %d", i);
+        idx[i] = recs[i];
+        idx[(size_t)n + i] = ctx->ped.row_of[recs[i]];
+        if (rows && idx[(size_t)n + i] == 0) return fail(ctx, CNF2_ERR_ARG, "record %d sits on the shared blank row", recs[i]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, &ctx->d_xidx, &ctx->xidx_cap, (size_t)(n > 0 ? n : 1) * 2);
+    if (rc) return rc;
+    if (n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xidx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // idx goes out of scope
+    }
+    return CNF2_OK;
+}
+
+static int have_accumulators(cnf2_ctx* ctx)
+{
+    const size_t R = (size_t)ctx->ped.n_rec, M = (size_t)ctx->n_markers;
+    if (!ctx->d_acc_inf || !ctx->d_acc_hb || !ctx->d_acc_hc || ctx->acc_inf_cap < R * M * 4 || ctx->acc_hb_cap < R * M ||
+        ctx->acc_hc_cap < R * M)
+        return fail(ctx, CNF2_ERR_STATE, "the context holds no accumulators (cnf2_sweep_accumulate with NULL accumulator pointers first)");
+    return CNF2_OK;
+}
+
+int cnf2_pack_accumulators(cnf2_ctx* ctx, const int32_t* recs, int n, double* d_packed)
+{
+    int rc = exchange_lists(ctx, recs, n, false);
+    if (rc) return rc;
+    if (n == 0) return CNF2_OK;
+    if (!d_packed) return fail(ctx, CNF2_ERR_ARG, "packed buffer is NULL");
+    if ((rc = have_accumulators(ctx))) return rc;
+    const size_t M = (size_t)ctx->n_markers, S = M * 6;
+    launch_copy_rows_f64(ctx->d_acc_inf, M * 4, ctx->d_xidx, d_packed, S, nullptr, n, M * 4, ctx->stream);
+    launch_copy_rows_f64(ctx->d_acc_hb, M, ctx->d_xidx, d_packed + M * 4, S, nullptr, n, M, ctx->stream);
+    launch_copy_rows_f64(ctx->d_acc_hc, M, ctx->d_xidx, d_packed + M * 5, S, nullptr, n, M, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_unpack_accumulators(cnf2_ctx* ctx, const int32_t* recs, int n, const double* d_packed)
+{
+    int rc = exchange_lists(ctx, recs, n, false);
+    if (rc) return rc;
+    if (n == 0) return CNF2_OK;
+    if (!d_packed) return fail(ctx, CNF2_ERR_ARG, "packed buffer is NULL");
+    if ((rc = have_accumulators(ctx))) return rc;
+    const size_t M = (size_t)ctx->n_markers, S = M * 6;
+    launch_copy_rows_f64(d_packed, S, nullptr, ctx->d_acc_inf, M * 4, ctx->d_xidx, n, M * 4, ctx->stream);
+    launch_copy_rows_f64(d_packed + M * 4, S, nullptr, ctx->d_acc_hb, M, ctx->d_xidx, n, M, ctx->stream);
+    launch_copy_rows_f64(d_packed + M * 5, S, nullptr, ctx->d_acc_hc, M, ctx->d_xidx, n, M, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_pack_rows(cnf2_ctx* ctx, const int32_t* recs, int n, void* d_packed)
+{
+    int rc = exchange_lists(ctx, recs, n, true);
+    if (rc) return rc;
+    if (n == 0) return CNF2_OK;
+    if (!d_packed) return fail(ctx, CNF2_ERR_ARG, "packed buffer is NULL");
+    const size_t   M = (size_t)ctx->n_markers, B = cnf2_packed_row_bytes(ctx);
+    const int32_t* rows = ctx->d_xidx + n;
+    uint8_t*       q = (uint8_t*)d_packed;
+    launch_copy_rows_f64((const double*)ctx->d_sure, M * 2, rows, (double*)q, B / 8, nullptr, n, M * 2, ctx->stream);
+    launch_copy_rows_f64(ctx->d_hw, M, rows, (double*)(q + M * 16), B / 8, nullptr, n, M, ctx->stream);
+    launch_copy_rows_u8(ctx->d_allele8, M, rows, q + M * 24, B, nullptr, n, M, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNF2_OK;
+}
+
+int cnf2_unpack_rows(cnf2_ctx* ctx, const int32_t* recs, int n, const void* d_packed)
+{
+    int rc = exchange_lists(ctx, recs, n, true);
+    if (rc) return rc;
+    if (n == 0) return CNF2_OK;
+    if (!d_packed) return fail(ctx, CNF2_ERR_ARG, "packed buffer is NULL");
+    const size_t   M = (size_t)ctx->n_markers, B = cnf2_packed_row_bytes(ctx);
+    const int32_t* rows = ctx->d_xidx + n;
+    const uint8_t* q = (const uint8_t*)d_packed;
+    launch_copy_rows_f64((const double*)q, B / 8, nullptr, (double*)ctx->d_sure, M * 2, rows, n, M * 2, ctx->stream);
+    launch_copy_rows_f64((const double*)(q + M * 16), B / 8, nullptr, ctx->d_hw, M, rows, n, M, ctx->stream);
+    launch_copy_rows_u8(q + M * 24, B, nullptr, ctx->d_allele8, M, rows, n, M, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->windows_dirty = true;          // rows changed: the "homozygous everywhere" flags must be derived again
     return CNF2_OK;
 }
 

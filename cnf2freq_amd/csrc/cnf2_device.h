@@ -143,6 +143,10 @@ struct UpdateParams {
 };
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);
 void launch_clock_probe(int n_cu, int iters, double* sink, hipStream_t stream);
+void launch_copy_rows_f64(const double* src, size_t src_stride, const int32_t* src_idx, double* dst, size_t dst_stride,
+                          const int32_t* dst_idx, int n, size_t elems, hipStream_t stream);
+void launch_copy_rows_u8(const uint8_t* src, size_t src_stride, const int32_t* src_idx, uint8_t* dst, size_t dst_stride,
+                         const int32_t* dst_idx, int n, size_t elems, hipStream_t stream);
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream);

@@ -767,6 +767,41 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 }
 
 
+// Listed rows of a table to or from a packed buffer (the exchanges of a multi-process run: accumulators of the records ranks
+// share, rows of the records a rank has updated).  Row i of the copy is src[(src_idx ? src_idx[i] : i) * src_stride ..] ->
+// dst[(dst_idx ? dst_idx[i] : i) * dst_stride ..], `elems` elements; blockIdx.x walks a row, blockIdx.y the rows.
+template <class T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, size_t src_stride, const int32_t* __restrict__ src_idx,
+                                                        T* __restrict__ dst, size_t dst_stride, const int32_t* __restrict__ dst_idx, int n,
+                                                        size_t elems)
+{
+    for (int i = blockIdx.y; i < n; i += gridDim.y) {
+        const T* s = src + (size_t)(src_idx ? src_idx[i] : i) * src_stride;
+        T*       d = dst + (size_t)(dst_idx ? dst_idx[i] : i) * dst_stride;
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += (size_t)gridDim.x * blockDim.x) d[e] = s[e];
+    }
+}
+template <class T>
+static void copy_rows_t(const void* src, size_t src_stride, const int32_t* src_idx, void* dst, size_t dst_stride, const int32_t* dst_idx,
+                        int n, size_t elems, hipStream_t stream)
+{
+    if (n <= 0 || elems == 0) return;
+    size_t gx = (elems + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_rows_kernel<T>, dim3((unsigned)gx, (unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, stream, (const T*)src,
+                       src_stride, src_idx, (T*)dst, dst_stride, dst_idx, n, elems);
+}
+void launch_copy_rows_f64(const double* src, size_t src_stride, const int32_t* src_idx, double* dst, size_t dst_stride,
+                          const int32_t* dst_idx, int n, size_t elems, hipStream_t stream)
+{
+    copy_rows_t<double>(src, src_stride, src_idx, dst, dst_stride, dst_idx, n, elems, stream);
+}
+void launch_copy_rows_u8(const uint8_t* src, size_t src_stride, const int32_t* src_idx, uint8_t* dst, size_t dst_stride,
+                         const int32_t* dst_idx, int n, size_t elems, hipStream_t stream)
+{
+    copy_rows_t<uint8_t>(src, src_stride, src_idx, dst, dst_stride, dst_idx, n, elems, stream);
+}
+
 // Clock probe: every SIMD of the chip gets 4 wavefronts that each issue `iters` x 8 independent double-precision FMAs and
 // nothing else: a SIMD issues one wave-wide f64 FMA per 4 cycles, so the kernel lasts 4 x 8 x iters x 4 cycles and its
 // duration gives the shader clock the device actually runs at under a vector-ALU load (boxes differ by several per cent,

@@ -96,37 +96,93 @@ void Engine::set_block(int begin, int end)
 
 std::vector<double> Engine::work_costs()
 {
-    std::vector<double> cost(N, 0.0);
+    std::vector<double>  cost(N, 0.0);
+    std::vector<int32_t> w((size_t)N * 17);
+    if (N > 0) check(cnf2_window_table(ctx, w.data()), "cnf2_window_table");
     for (int j = 0; j < N; j++) {
-        int32_t w[17];
-        check(cnf2_window_info(ctx, j, w), "cnf2_window_info");
         int groups = 0;
-        for (int k = 0; k < 7; k++) groups = std::max(groups, w[10 + k] + 1);
+        for (int k = 0; k < 7; k++) groups = std::max(groups, w[(size_t)j * 17 + 10 + k] + 1);
         cost[j] = (double)M * (1.0 + (double)(1 << groups));
     }
     return cost;
 }
 
-void Engine::balanced_block(int rank, int world, int* begin, int* end)
+Partition Engine::plan(int rank, int world)
 {
     if (world < 1 || rank < 0 || rank >= world) throw EngineError(CNF2_ERR_ARG, "rank out of range");
-    const std::vector<double> cost = work_costs();
-    double total = 0;
-    for (double c : cost) total += c;
-    // boundary b_k = first individual whose prefix cost reaches k / world of the total
-    auto boundary = [&](int k) {
-        if (k <= 0) return 0;
-        if (k >= world) return N;
-        const double target = total * k / world;
-        double       run = 0;
-        for (int j = 0; j < N; j++) {
-            if (run + 0.5 * cost[j] >= target) return j;
-            run += cost[j];
+    std::vector<int32_t> w((size_t)N * 17);
+    if (N > 0) check(cnf2_window_table(ctx, w.data()), "cnf2_window_table");
+    return plan_partition((int)P.inds.size(), N, M, w.data(), rank, world);
+}
+
+void Engine::balanced_block(int rank, int world, int* begin, int* end)
+{
+    const Partition Q = plan(rank, world);
+    *begin = Q.bounds[rank];
+    *end = Q.bounds[rank + 1];
+}
+
+void Engine::set_partition(int rank, int world, ExchangeFn fn, void* user)
+{
+    if (world > 1 && !fn) throw EngineError(CNF2_ERR_ARG, "a partition over several ranks needs a transport");
+    part_ = plan(rank, world);
+    exchange_ = fn;
+    exchange_user_ = user;
+    set_block(part_.bounds[rank], part_.bounds[rank + 1]);
+}
+
+void Engine::exchange_bytes(size_t out[4]) const
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (part_.world <= 1) return;
+    const size_t S = cnf2_packed_accumulator_doubles(ctx) * sizeof(double), B = cnf2_packed_row_bytes(ctx);
+    out[0] = (size_t)part_.world * part_.seg_shared * S;
+    out[1] = (size_t)part_.world * part_.seg_shared * B;
+    out[2] = (size_t)C * sizeof(int32_t);
+    out[3] = part_.n_shared * (S + B) + out[2];
+}
+
+void Engine::exchange(int op, void* buf, size_t count, size_t seg, const char* what)
+{
+    const int rc = exchange_(exchange_user_, op, buf, count, seg);
+    if (rc != 0) throw EngineError(CNF2_ERR_STATE, std::string("the transport failed in ") + what + " (" + std::to_string(rc) + ")");
+}
+
+// every rank's newer rows of its private records to every rank: one all-gather of packed rows, in slices so that the
+// staging buffer stays bounded (a full config-5 state is 6 GB)
+void Engine::gather_private_rows()
+{
+    if (part_.world <= 1 || !rows_partial_) return;
+    const size_t B = cnf2_packed_row_bytes(ctx);
+    const size_t slice = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)part_.world * B));
+    for (size_t i0 = 0; i0 < part_.seg_private; i0 += slice) {
+        const size_t k = std::min(slice, part_.seg_private - i0);
+        void* buf = nullptr;
+        check(cnf2_exchange_buffer(ctx, (size_t)part_.world * k * B, &buf), "cnf2_exchange_buffer");
+        auto part_of = [&](int q, const int32_t** recs) {
+            const std::vector<int32_t>& v = part_.private_of[q];
+            if (i0 >= v.size()) return 0;
+            *recs = v.data() + i0;
+            return (int)std::min(k, v.size() - i0);
+        };
+        const int32_t* mine = nullptr;
+        const int      nm = part_of(part_.rank, &mine);
+        check(cnf2_pack_rows(ctx, mine, nm, (uint8_t*)buf + (size_t)part_.rank * k * B), "cnf2_pack_rows");
+        exchange(X_GATHER_SEGMENTS, buf, (size_t)part_.world * k * B, k * B, "the gather of the rows");
+        for (int q = 0; q < part_.world; q++) {
+            if (q == part_.rank) continue;
+            const int32_t* theirs = nullptr;
+            const int      nt = part_of(q, &theirs);
+            check(cnf2_unpack_rows(ctx, theirs, nt, (const uint8_t*)buf + (size_t)q * k * B), "cnf2_unpack_rows");
         }
-        return N;
-    };
-    *begin = boundary(rank);
-    *end = boundary(rank + 1);
+    }
+    rows_partial_ = false;
+}
+
+void Engine::sync_rows()
+{
+    gather_private_rows();
+    if (rows_stale_) pull_rows();
 }
 
 void Engine::accumulators(double* haplobase, double* haplocount)
@@ -506,13 +562,21 @@ void Engine::iteration(FILE* out)
                   "cnf2_sweep");
     }
     lap("sweep + accumulators");
-    if (opt.update && N > 0 && exchange_) {
-        // ranks share ancestors: their slabs are partial sums until the one all-reduce of the iteration
-        double *d_inf, *d_hb, *d_hc;
-        check(cnf2_sync(ctx), "cnf2_sync");
-        check(cnf2_accumulator_ptrs(ctx, &d_inf, &d_hb, &d_hc), "cnf2_accumulator_ptrs");
-        const int rc = exchange_(exchange_user_, d_inf, d_hb, d_hc, (size_t)R, (size_t)M);
-        if (rc != 0) throw EngineError(CNF2_ERR_STATE, "the exchange callback failed (" + std::to_string(rc) + ")");
+    const bool multi = part_.world > 1 && exchange_ != nullptr;
+    const size_t S = cnf2_packed_accumulator_doubles(ctx), B = cnf2_packed_row_bytes(ctx);
+    if (opt.update && N > 0 && multi && part_.seg_shared > 0) {
+        // the records several ranks' windows touch hold partial sums: packed by owner, one reduce-scatter, the owner keeps
+        // the total (cnF2freq.cpp:6245-6254 reduces per individual; private records need nothing)
+        void* buf = nullptr;
+        check(cnf2_exchange_buffer(ctx, (size_t)part_.world * part_.seg_shared * std::max(S * sizeof(double), B), &buf), "cnf2_exchange_buffer");
+        double* q = (double*)buf;
+        for (int k = 0; k < part_.world; k++)
+            check(cnf2_pack_accumulators(ctx, part_.shared_of[k].data(), (int)part_.shared_of[k].size(), q + (size_t)k * part_.seg_shared * S),
+                  "cnf2_pack_accumulators");
+        exchange(X_SUM_SEGMENTS, buf, (size_t)part_.world * part_.seg_shared * S, part_.seg_shared * S, "the sum of the shared accumulators");
+        check(cnf2_unpack_accumulators(ctx, part_.shared_of[part_.rank].data(), (int)part_.shared_of[part_.rank].size(),
+                                       q + (size_t)part_.rank * part_.seg_shared * S),
+              "cnf2_unpack_accumulators");
         lap("exchange of the accumulators");
     }
     pass_hits_.assign(C, 0);
@@ -544,9 +608,21 @@ void Engine::iteration(FILE* out)
         if (opt.print_rows)
             for (int r = 0; r < R; r++) fprintf(out, "FIRST PASS: %d\n", P.inds[r].n);
         int hits = 0;
-        check(cnf2_update_pass(ctx, c, children_.data(), desc.data(), nullptr, nullptr, nullptr, scalefactor_, entropyfactor_,
-                               &hits, getenv("CNF2_UPDATE_PLAIN") ? CNF2_UPDATE_PLAIN : 0),      // A/B switch (tuning aid)
-              "cnf2_update_pass");
+        // CNF2_DETERMINISTIC runs stay pinned to the bit-exact update form (both certainty flows of a side) unless the caller
+        // chose a form itself
+        const uint32_t uflags = update_flags_set_ ? update_flags_ : (deterministic_ ? (uint32_t)CNF2_UPDATE_BOTH_FLOWS : 0u);
+        if (multi) {
+            // this rank's records only; the step-size control needs the hits of all of them (cnF2freq.cpp:6373-6392)
+            check(cnf2_update_pass_records(ctx, c, part_.owned.data(), (int)part_.owned.size(), children_.data(), desc.data(),
+                                           scalefactor_, entropyfactor_, &hits, uflags),
+                  "cnf2_update_pass_records");
+            int32_t h = hits;
+            exchange(X_SUM_HITS, &h, 1, 1, "the sum of the hit counters");
+            hits = h;
+        } else
+            check(cnf2_update_pass(ctx, c, children_.data(), desc.data(), nullptr, nullptr, nullptr, scalefactor_, entropyfactor_,
+                                   &hits, uflags),
+                  "cnf2_update_pass");
         if (opt.print_rows)
             for (int r = 0; r < R; r++) fprintf(out, "SKEWNESS PASS: %d\n", P.inds[r].n);
         const int  mx = std::max(oldhits_, oldhits2_), mn = std::min(oldhits_, oldhits2_);
@@ -561,6 +637,25 @@ void Engine::iteration(FILE* out)
         pass_hits_[c] = hits;
         fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
         lap("update pass");
+    }
+    if (opt.update && N > 0 && multi) {
+        // the new rows of the shared records from their owners to everybody (their next sweep reads them); the private
+        // records' rows stay where they are until somebody asks for the whole state (sync_rows)
+        if (part_.seg_shared > 0) {
+            void* buf = nullptr;
+            check(cnf2_exchange_buffer(ctx, (size_t)part_.world * part_.seg_shared * std::max(S * sizeof(double), B), &buf), "cnf2_exchange_buffer");
+            uint8_t* q = (uint8_t*)buf;
+            check(cnf2_pack_rows(ctx, part_.shared_of[part_.rank].data(), (int)part_.shared_of[part_.rank].size(),
+                                 q + (size_t)part_.rank * part_.seg_shared * B),
+                  "cnf2_pack_rows");
+            exchange(X_GATHER_SEGMENTS, buf, (size_t)part_.world * part_.seg_shared * B, part_.seg_shared * B, "the gather of the shared rows");
+            for (int k = 0; k < part_.world; k++)
+                if (k != part_.rank)
+                    check(cnf2_unpack_rows(ctx, part_.shared_of[k].data(), (int)part_.shared_of[k].size(), q + (size_t)k * part_.seg_shared * B),
+                          "cnf2_unpack_rows");
+            lap("exchange of the shared rows");
+        }
+        rows_partial_ = true;
     }
     if (opt.update && N > 0) rows_stale_ = true;
 }

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "cnf2_partition.h"
 #include "cnf2_readers.h"
 #include "cnf2hip.h"
 
@@ -40,11 +41,17 @@ struct EngineError : std::runtime_error {
     EngineError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
 };
 
-// The one exchange of a multi-process haplotyping iteration (the reference's reduce calls,
-// cnF2freq.cpp:6245-6254): sums the per-record accumulator slabs of all ranks in place.  The pointers are DEVICE
-// addresses (infprobs [n_rec][n_markers][2][2], haplobase / haplocount [n_rec][n_markers]); return 0 on success.
-typedef int (*ExchangeFn)(void* user, double* d_infprobs, double* d_haplobase, double* d_haplocount, size_t n_rec,
-                          size_t n_markers);
+// Transport of a multi-process haplotyping run (the reference's reduce calls, cnF2freq.cpp:6245-6254).
+// The engine packs what ranks must exchange -- the accumulators and rows of the records their windows SHARE, never the
+// [n_rec][M] slabs -- into one device buffer of `world` equal segments and asks the transport for one collective on it:
+//   X_SUM_SEGMENTS     buf = device, `count` doubles in segments of `seg`: on return segment `rank` holds the sum over all
+//                      ranks of that segment (a reduce-scatter; the other segments are left undefined)
+//   X_SUM_HITS         buf = HOST int32[count]: in-place sum over all ranks (the hit counters of an update pass)
+//   X_GATHER_SEGMENTS  buf = device, `count` bytes in segments of `seg`: every rank has filled its own segment; on return
+//                      all segments are filled on every rank (an all-gather)
+// Returns 0 on success.
+enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2 };
+typedef int (*ExchangeFn)(void* user, int op, void* buf, size_t count, size_t seg);
 
 class Engine {
 public:
@@ -61,24 +68,35 @@ public:
     // cnF2freq.cpp:8157-8192
     void dump(FILE* out, int limit);
 
-    // multi-process runs: this rank sweeps the analysed individuals [begin, end) of dous (ancestors' rows are replicated on
-    // every rank), `fn` sums the accumulators of all ranks after the sweep, every rank then runs the same update pass on the
-    // same numbers (cnF2freq.cpp:5297-5299, 6245-6254, 6344-6392).  Rows are printed for the rank's own block.
+    // a sub-range of the analysed individuals [begin, end) of dous for this process's sweeps and rows (single-process use;
+    // multi-process runs call set_partition, which sets the rank's block)
     void   set_block(int begin, int end);
     // what the sweep kernels spend on every analysed individual, up to a constant: markers x (1 forward + one backward pass
     // per tie combination).  The shift modes of cnF2freq.cpp:5359, 5378 do not enter: a wavefront carries all 8 modes of
     // its individual whether they are masked or not (SURVEY 8(e)'s sum of M x S_act is the cost model of the CPU path).
     std::vector<double> work_costs();
-    // contiguous blocks of dous with near-equal cost: block `rank` of `world` (cnF2freq.cpp:5297-5299 deals individuals
-    // round-robin; contiguous blocks keep a rank's output rows together)
+    // block `rank` of `world` as plan() cuts them (cnF2freq.cpp:5297-5299 deals individuals round-robin; contiguous blocks
+    // keep a rank's output rows together)
     void   balanced_block(int rank, int world, int* begin, int* end);
-    void   set_exchange(ExchangeFn fn, void* user) { exchange_ = fn; exchange_user_ = user; }
+    // blocks, private / shared records and their owners for `world` ranks (the same on every rank: a pure function of the
+    // pedigree and the window tables)
+    Partition plan(int rank, int world);
+    // multi-process runs (cnF2freq.cpp:5297-5299, 6245-6254, 6344-6392): this rank sweeps its block of the plan, `fn` carries
+    // the collectives, the rank updates the records it owns.  Rows are printed for the rank's own block.
+    void   set_partition(int rank, int world, ExchangeFn fn, void* user);
+    const Partition& partition() const { return part_; }
+    // bytes of the collectives' buffers per iteration: [0] accumulators (reduce-scatter), [1] rows (all-gather), [2] hits;
+    // [3] = payload: what the shared records really occupy in them
+    void   exchange_bytes(size_t out[4]) const;
+    // update form: CNF2_UPDATE_PLAIN / CNF2_UPDATE_BOTH_FLOWS / CNF2_UPDATE_ONE_SCOUT of cnf2hip.h (0 = the fast form with mirrored
+    // certainty flows).  Until this is called the form is 0, or CNF2_UPDATE_BOTH_FLOWS (the bit-exact form) in a deterministic run
+    void   set_update_flags(uint32_t f) { update_flags_ = f; update_flags_set_ = true; }
     void   set_deterministic(bool d) { deterministic_ = d; }
     const std::vector<int>& pass_hits() const { return pass_hits_; }       // hitnnn of every chromosome's pass of the last iteration
     void   accumulators(double* haplobase, double* haplocount);            // [inds][M] as the last pass left them
     void   set_update(bool u) { opt.update = u; }
     void   set_print_rows(bool p) { opt.print_rows = p; }
-    void   sync_rows() { if (rows_stale_) pull_rows(); }   // host copies of the individuals' rows up to date
+    void   sync_rows();          // host copies of the individuals' rows up to date (multi-process: on every rank, a collective)
     double scalefactor() const { return scalefactor_; }
     int    last_hits() const { return last_hits_; }
     const std::vector<int>& descendants() const { return descendants_; }
@@ -104,7 +122,13 @@ private:
     int    block_begin_ = 0, block_end_ = -1;     // analysed individuals of this rank (-1: all)
     ExchangeFn exchange_ = nullptr;
     void*      exchange_user_ = nullptr;
+    Partition  part_;
+    bool       rows_partial_ = false;    // multi-process: other ranks hold newer rows of their private records
     bool       deterministic_ = false;
+    uint32_t   update_flags_ = 0;
+    bool       update_flags_set_ = false;
+    void       exchange(int op, void* buf, size_t count, size_t seg, const char* what);
+    void       gather_private_rows();
     std::vector<int> pass_hits_;
 };
 

@@ -181,10 +181,34 @@ int cnf2h_balanced_block(cnf2h_run* run, int rank, int world, int32_t* begin, in
     return rc;
 }
 
-int cnf2h_set_exchange(cnf2h_run* run, cnf2h_exchange_fn fn, void* user)
+int cnf2h_set_partition(cnf2h_run* run, int rank, int world, cnf2h_exchange_fn fn, void* user)
 {
     if (!run) return -2;
-    run->E->set_exchange(fn, user);
+    return guarded([&] { run->E->set_partition(rank, world, fn, user); });
+}
+
+int cnf2h_get_partition(cnf2h_run* run, int64_t* info10, int32_t* owned)
+{
+    if (!run || !info10) return -2;
+    const Partition& Q = run->E->partition();
+    size_t bytes[4];
+    run->E->exchange_bytes(bytes);
+    const bool set = !Q.bounds.empty();
+    info10[0] = set ? Q.bounds[Q.rank] : 0;
+    info10[1] = set ? Q.bounds[Q.rank + 1] : (int64_t)run->P.dous.size();
+    info10[2] = (int64_t)Q.owned.size();
+    info10[3] = (int64_t)Q.n_shared;
+    info10[4] = (int64_t)Q.seg_shared;
+    for (int i = 0; i < 4; i++) info10[5 + i] = (int64_t)bytes[i];
+    info10[9] = set ? (int64_t)Q.private_of[Q.rank].size() : 0;
+    if (owned) std::copy(Q.owned.begin(), Q.owned.end(), owned);
+    return 0;
+}
+
+int cnf2h_set_update_flags(cnf2h_run* run, uint32_t flags)
+{
+    if (!run) return -2;
+    run->E->set_update_flags(flags);
     return 0;
 }
 

@@ -1,7 +1,8 @@
 """Multi-GPU plumbing: individuals are independent units of the sweep (the reference's own
 dead MPI code partitions `dous` the same way, cnF2freq.cpp:5297-5299), so the path shards with
-no data-path collective; the only exchange is one gather of the per-individual results to
-rank 0 (RCCL over xGMI when the backend is nccl).  One process per GPU, torch.distributed."""
+no data-path collective; the only exchange of a sweep is one gather of the per-individual results to
+rank 0 (RCCL over xGMI when the backend is nccl).  Haplotyping iterations add the exchange of what the ranks' windows
+share (Transport).  One process per GPU, torch.distributed."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -93,23 +94,9 @@ class TiledGather:
         return t
 
 
-def allreduce_accumulators(infprobs, haplobase, haplocount):
-    """The one collective of a haplotyping iteration: ranks own disjoint blocks of analysed individuals but share
-    ancestors, whose per-record accumulators (infprobs [R, M, 2, 2], haplobase / haplocount [R, M]; what
-    moveinfprobs / movehaplos add up, cnF2freq.cpp:3577-3616) every rank holds a partial sum of.  One
-    all-reduce(sum) of the three slabs (the reference's dead MPI code reduces them per individual,
-    cnF2freq.cpp:6245-6254); every rank then runs the same update pass on the same numbers.  In place; tensors may
-    live on the GPU (nccl = RCCL) or on the host (gloo)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in (infprobs, haplobase, haplocount)]
-    for w in works:
-        w.wait()
-
-
 def balanced_blocks(costs, world):
-    """Boundaries [b_0 = 0, ..., b_world = n] of `world` contiguous blocks with near-equal cost (the rule of
-    Engine::balanced_block in csrc/host/cnf2_engine.cpp, for callers that hold the costs themselves)."""
+    """Boundaries [b_0 = 0, ..., b_world = n] of `world` contiguous blocks with near-equal cost (the cost-balanced starting
+    point of Engine::plan in csrc/host/cnf2_engine.cpp, for callers that hold the costs themselves)."""
     costs = np.asarray(costs, np.float64)
     n = len(costs)
     total = float(costs.sum())
@@ -122,72 +109,113 @@ def balanced_blocks(costs, world):
     return bounds
 
 
-class _DeviceSlab:
+class _DeviceBuffer:
     """A device address as an object torch.as_tensor() accepts (CUDA array interface; zero copy)."""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2)
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False), version=2)
 
 
-def device_slabs(d_inf, d_hb, d_hc, n_rec, n_markers, device=None):
-    """The three accumulator slabs at the device addresses the engine hands to its exchange callback, as flat float64
-    torch tensors that alias them."""
+def device_view(ptr, count, dtype, device):
+    """`count` elements of `dtype` (torch.float64 or torch.uint8) at device address `ptr` as a flat tensor that aliases them."""
     from . import capi
-    capi.require_single_hip_runtime()          # the addresses belong to the runtime libcnf2hip.so uses
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    return [torch.as_tensor(_DeviceSlab(p, n), device=dev)
-            for p, n in ((d_inf, n_rec * n_markers * 4), (d_hb, n_rec * n_markers), (d_hc, n_rec * n_markers))]
+    capi.require_single_hip_runtime()          # the address belongs to the runtime libcnf2hip.so uses
+    typestr = {torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_DeviceBuffer(ptr, count, typestr), device=device)
 
 
-def make_exchange(run):
-    """The exchange callback of a multi-process haplotyping run (cnf2host.h: cnf2h_set_exchange): one all-reduce(sum) of the
-    three accumulator slabs per iteration.  nccl (= RCCL): in place on the device addresses the engine hands over;
-    gloo (a transport that moves host memory, e.g. two test ranks sharing one GPU): through the host with
-    cnf2_download_accumulators / cnf2_upload_accumulators."""
-    from . import capi
-    backend = dist.get_backend() if dist.is_initialized() else None
-    L = capi.load()
-    ctx = run.context()
-    bufs = {}
+class Transport:
+    """The collectives of a multi-process haplotyping run (cnf2host.h: cnf2h_exchange_fn) over torch.distributed.  The engine
+    has packed what the ranks' windows share into one buffer of `world` equal segments; this object only moves it:
+      X_SUM_SEGMENTS     reduce-scatter(sum): segment `rank` of the buffer receives the sum over ranks of that segment
+      X_SUM_HITS         all-reduce(sum) of a few host integers (the hit counters of an update pass)
+      X_GATHER_SEGMENTS  all-gather: every rank's own segment to all
+    nccl (= RCCL over xGMI): in place on the engine's device buffer, wrapped zero-copy.  gloo (a transport for host
+    memory -- e.g. test ranks sharing one GPU): staged through pinned-size host tensors; gloo has no reduce-scatter, so the
+    sum is an all-reduce of which the rank keeps its segment.  `bytes_moved` counts what this rank handed to collectives."""
 
-    def exchange(d_inf, d_hb, d_hc, n_rec, n_markers):
-        if backend is None or dist.get_world_size() == 1:
-            return 0
-        if backend == "nccl":
-            allreduce_accumulators(*device_slabs(d_inf, d_hb, d_hc, n_rec, n_markers))
-            torch.cuda.synchronize()
-            return 0
-        if "inf" not in bufs:
-            bufs["inf"] = torch.zeros(n_rec * n_markers * 4, dtype=torch.float64)
-            bufs["hb"] = torch.zeros(n_rec * n_markers, dtype=torch.float64)
-            bufs["hc"] = torch.zeros(n_rec * n_markers, dtype=torch.float64)
+    def __init__(self, device, ctx=None, skip_single=True):
+        from . import host
+        self.host = host
+        self.skip_single = skip_single      # a world of one has nothing to exchange (False: run the collectives all the same)
+        self.ctx = ctx              # cnf2_ctx handle of the run (the gloo path stages the context's exchange buffer)
+        self.device = device if isinstance(device, torch.device) else (None if device is None else torch.device("cuda", int(device)))
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.bytes_moved = 0
+        self.calls = {0: 0, 1: 0, 2: 0}
+
+    def __call__(self, op, buf, count, seg):
         import ctypes as C
-        ptr = lambda t: C.c_void_p(t.data_ptr())
-        if L.cnf2_download_accumulators(ctx, ptr(bufs["inf"]), ptr(bufs["hb"]), ptr(bufs["hc"])) != 0:
-            return -1
-        allreduce_accumulators(bufs["inf"], bufs["hb"], bufs["hc"])
-        if L.cnf2_upload_accumulators(ctx, ptr(bufs["inf"]), ptr(bufs["hb"]), ptr(bufs["hc"])) != 0:
-            return -1
+        H = self.host
+        self.calls[op] += 1
+        if self.world == 1 and (self.skip_single or self.backend is None):
+            return 0
+        if op == H.X_SUM_HITS:
+            a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32)), shape=(count,))
+            t = torch.from_numpy(a.astype(np.int64))
+            if self.backend == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            a[:] = t.cpu().numpy().astype(np.int32)
+            self.bytes_moved += 8 * count
+            return 0
+        dtype = torch.float64 if op == H.X_SUM_SEGMENTS else torch.uint8
+        if count != seg * self.world:
+            raise ValueError("the buffer must hold world x seg elements")
+        if self.backend == "nccl":
+            if torch.cuda.current_device() != self.device.index:
+                raise RuntimeError("the transport's device %s is not torch's current device %d" % (self.device, torch.cuda.current_device()))
+            t = device_view(buf, count, dtype, self.device)
+            mine = t[self.rank * seg:(self.rank + 1) * seg]
+            if op == H.X_SUM_SEGMENTS:
+                dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM)
+            else:
+                dist.all_gather_into_tensor(t, mine)
+            torch.cuda.synchronize(self.device)
+        else:
+            itemsize = 8 if op == H.X_SUM_SEGMENTS else 1
+            L = None
+            if self.ctx is None:
+                # no context: `buf` is HOST memory (callers that stage the buffer themselves; the CPU tests)
+                ctype = C.c_double if op == H.X_SUM_SEGMENTS else C.c_uint8
+                h = torch.from_numpy(np.ctypeslib.as_array(C.cast(buf, C.POINTER(ctype)), shape=(count,)))
+            else:
+                # staged through the host: the engine's buffer is the context's exchange buffer (cnf2_exchange_buffer)
+                from . import capi
+                L = capi.load()
+                h = torch.empty(count, dtype=dtype)
+                if L.cnf2_exchange_download(self.ctx, C.c_void_p(h.data_ptr()), count * itemsize) != 0:
+                    raise RuntimeError("cnf2_exchange_download: " + L.cnf2_last_error(self.ctx).decode())
+            if op == H.X_SUM_SEGMENTS:
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            else:
+                parts = [torch.empty(seg, dtype=dtype) for _ in range(self.world)]
+                dist.all_gather(parts, h[self.rank * seg:(self.rank + 1) * seg].clone())
+                h.copy_(torch.cat(parts))
+            if L is not None and L.cnf2_exchange_upload(self.ctx, C.c_void_p(h.data_ptr()), count * itemsize) != 0:
+                raise RuntimeError("cnf2_exchange_upload: " + L.cnf2_last_error(self.ctx).decode())
+        self.bytes_moved += count * (8 if op == H.X_SUM_SEGMENTS else 1)
         return 0
-
-    return exchange
 
 
 def start_iterations(ped, device=0, has_prior=None, postmarkerdata=True, deterministic=False, quiet=True):
     """One rank's run of a multi-process haplotyping job (BASELINE config 5; the reference's dead MPI code: partition
-    cnF2freq.cpp:5297-5299, reduce 6245-6254, updates on the reduced slabs 6344-6392): the whole pedigree on every rank,
-    the rank's work-balanced block of analysed individuals, the all-reduce of the accumulators as the one exchange of
-    an iteration.  Returns the cnf2freq_amd.host.Run; call run.iteration() in step on every rank."""
+    cnF2freq.cpp:5297-5299, reduce 6245-6254, updates on the reduced values 6344-6392): the whole pedigree on every rank, the
+    rank's block of analysed individuals cut where the fewest records straddle, the accumulators of the records ranks share
+    summed by one reduce-scatter per iteration, every rank updating the records it owns, the shared records' new rows
+    all-gathered.  Returns the cnf2freq_amd.host.Run (run.block, run.plan, run.transport); call run.iteration() -- and
+    run.state() / run.dump(), which gather the whole state -- in step on every rank."""
     from . import host
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     run = host.Run(ped, has_prior=has_prior, quiet=quiet, device=device)
     if postmarkerdata:
         run.postmarkerdata()            # replicated: every rank infers the same genotypes from the same rows
-    b, e = run.balanced_block(rank, world)
-    run.set_block(b, e)
-    run.block = (b, e)
-    run.set_exchange(make_exchange(run))
+    run.transport = Transport(device, run.context())
+    run.plan = run.set_partition(rank, world, run.transport)
+    run.block = run.plan["block"]
     if deterministic:
         run.set_deterministic(True)
     return run

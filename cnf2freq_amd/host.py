@@ -10,10 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnf2host.so")
 
 SYMBOLS = ["cnf2h_create", "cnf2h_create_on", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration",
-           "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_exchange",
+           "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_partition", "cnf2h_get_partition", "cnf2h_set_update_flags",
            "cnf2h_set_deterministic", "cnf2h_context", "cnf2h_get_passes"]
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
+# int fn(void *user, int op, void *buf, size_t count, size_t seg) -- the transport of a multi-process run (cnf2host.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
+X_SUM_SEGMENTS, X_SUM_HITS, X_GATHER_SEGMENTS = 0, 1, 2
 
 _lib = None
 
@@ -31,7 +33,9 @@ def load():
         L.cnf2h_create_on.restype = vp
         L.cnf2h_set_block.argtypes = [vp, i32, i32]
         L.cnf2h_balanced_block.argtypes = [vp, i32, i32, vp, vp]
-        L.cnf2h_set_exchange.argtypes = [vp, EXCHANGE_FN, vp]
+        L.cnf2h_set_partition.argtypes = [vp, i32, i32, EXCHANGE_FN, vp]
+        L.cnf2h_get_partition.argtypes = [vp, vp, vp]
+        L.cnf2h_set_update_flags.argtypes = [vp, C.c_uint32]
         L.cnf2h_set_deterministic.argtypes = [vp, i32]
         L.cnf2h_context.argtypes = [vp]
         L.cnf2h_context.restype = vp
@@ -103,17 +107,33 @@ class Run:
         self._chk(self.L.cnf2h_balanced_block(self.h, rank, world, C.byref(b), C.byref(e)), "cnf2h_balanced_block")
         return b.value, e.value
 
-    def set_exchange(self, fn):
-        """fn(d_infprobs, d_haplobase, d_haplocount, n_rec, n_markers) -> 0: device addresses as ints (see cnf2host.h)."""
-        def tramp(_user, a, b, c, n_rec, n_markers):
+    def set_partition(self, rank, world, fn=None):
+        """Plans the multi-process run and sets this rank's block (cnf2host.h: cnf2h_set_partition).
+        fn(op, buf, count, seg) -> 0 is the transport: op one of X_SUM_SEGMENTS (buf = device address, count doubles),
+        X_SUM_HITS (buf = host address of int32[count]), X_GATHER_SEGMENTS (buf = device address, count bytes)."""
+        def tramp(_user, op, buf, count, seg):
             try:
-                return int(fn(a, b, c, n_rec, n_markers) or 0)
-            except Exception as e:            # an exception must not unwind through the C frames
+                return int(fn(op, buf, count, seg) or 0)
+            except Exception:                 # an exception must not unwind through the C frames
                 import traceback
                 traceback.print_exc()
                 return -1
-        self._exchange = EXCHANGE_FN(tramp)   # keep the trampoline alive
-        self._chk(self.L.cnf2h_set_exchange(self.h, self._exchange, None), "cnf2h_set_exchange")
+        self._exchange = EXCHANGE_FN(tramp if fn is not None else 0)   # keep the trampoline alive
+        self._chk(self.L.cnf2h_set_partition(self.h, rank, world, self._exchange, None), "cnf2h_set_partition")
+        return self.partition()
+
+    def partition(self):
+        info = np.zeros(10, np.int64)
+        self._chk(self.L.cnf2h_get_partition(self.h, _p(info), None), "cnf2h_get_partition")
+        owned = np.zeros(int(info[2]), np.int32)
+        self._chk(self.L.cnf2h_get_partition(self.h, _p(info), _p(owned) if len(owned) else None), "cnf2h_get_partition")
+        return dict(block=(int(info[0]), int(info[1])), owned=owned, n_shared=int(info[3]), segment_records=int(info[4]),
+                    bytes_accumulators=int(info[5]), bytes_rows=int(info[6]), bytes_hits=int(info[7]), bytes_payload=int(info[8]),
+                    n_private=int(info[9]))
+
+    def set_update_flags(self, flags):
+        """capi.UPDATE_BOTH_FLOWS (bit-exact fast form), capi.UPDATE_PLAIN (literal kernels), capi.UPDATE_ONE_SCOUT; 0 = default."""
+        self._chk(self.L.cnf2h_set_update_flags(self.h, flags), "cnf2h_set_update_flags")
 
     def set_deterministic(self, on=True):
         self._chk(self.L.cnf2h_set_deterministic(self.h, 1 if on else 0), "cnf2h_set_deterministic")

@@ -75,8 +75,15 @@ enum {
                                     per marker) instead of the tile-producer kernel's pass per tie combination; cross-check */
     CNF2_UPDATE_PLAIN = 1u << 13, /* cnf2_update_pass: the literal form -- one thread per (record, marker), every bisection step with its
                                     quadrature as the reference's cappedgd runs it -- instead of the scout / finish kernels, which
-                                    make the same decisions with a fraction of the gradient evaluations (cnf2_update.h).  Same
-                                    results to the bit: the yardstick of the fast form, and an A/B switch */
+                                    make the same decisions with a fraction of the gradient evaluations (cnf2_update.h).  The
+                                    yardstick of the fast form and an A/B switch: the fast form gives the same results TO THE
+                                    BIT only together with CNF2_UPDATE_BOTH_FLOWS; its default (one certainty flow per side, the
+                                    other its mirror image) is within rounding of this form, not bit-identical */
+    CNF2_UPDATE_BOTH_FLOWS = 1u << 16, /* cnf2_update_pass, fast form: run the certainty flow of BOTH allele values of a side, as
+                                    processinfprobs does (cnF2freq.cpp:4222-4290), instead of one flow and its mirror image
+                                    (DESIGN.md section 3.11).  The bit-exact form: equal to CNF2_UPDATE_PLAIN to the bit */
+    CNF2_UPDATE_ONE_SCOUT = 1u << 17, /* cnf2_update_pass, fast form: the certainties' scout in one pass instead of two (same
+                                    results to the bit; A/B switch, tools/ab_scout.py) */
     CNF2_DETERMINISTIC = 1u << 14, /* cnf2_sweep_accumulate: every analysed individual writes what its window members receive at a
                                     locus into a row of its own (336 B per individual x marker, allocated for the whole
                                     range) and one more kernel adds the rows of every record in ascending order of the
@@ -142,6 +149,8 @@ int cnf2_upload_pedigree(cnf2_ctx *ctx, int n_rec, const int32_t *par, const uin
  * out[0]=shiftignore out[1]=flag2ignore out[2]=founder out[3..9]=slot records (-1 none)
  * out[10..16]=tie group per slot (-1 = ancestor occupies a single slot). */
 int cnf2_window_info(cnf2_ctx *ctx, int ind, int32_t *out17);
+/* the same for every analysed individual in one call: out17_all[n_dous][17] */
+int cnf2_window_table(cnf2_ctx *ctx, int32_t *out17_all);
 
 /* The sweep: per-individual body of doit<> (cnF2freq.cpp:5294-5403) plus the per-locus
  * allele-2 dosage posterior row that genotypereporter accumulates (cnF2freq.cpp:5406-5553,
@@ -274,6 +283,33 @@ int cnf2_update_pass(cnf2_ctx *ctx, int chrom, const int32_t *children, const in
                      double *haplobase, double *haplocount, double scalefactor, double entropyfactor, int *hits_out,
                      uint32_t flags);
 int cnf2_download_rows(cnf2_ctx *ctx, int row0, int n, uint8_t *allele, double *sure, double *hw);
+/* cnf2_update_pass restricted to the listed records (ascending; n_recs may be 0), on the accumulators the context holds:
+ * the form a rank of a multi-process run uses -- every record's update reads only its own accumulators and rows
+ * (cnF2freq.cpp:6344-6368 loops over individuals), so ranks update the records they own and *hits_out counts those. */
+int cnf2_update_pass_records(cnf2_ctx *ctx, int chrom, const int32_t *recs, int n_recs, const int32_t *children,
+                             const int32_t *descendants, double scalefactor, double entropyfactor, int *hits_out, uint32_t flags);
+
+/* Exchange support of multi-process haplotyping runs (the reference's reduce calls,
+ * cnF2freq.cpp:6245-6254): what ranks exchange is the records their windows SHARE, packed -- not the [n_rec][M] slabs.
+ *  cnf2_exchange_buffer            a device staging buffer of at least `bytes` owned by the context (grows; the pointer is
+ *                                  valid until the next call with a larger size)
+ *  cnf2_pack_accumulators          d_packed[n][M][6] <- the context's accumulators of the listed records: per record
+ *                                  infprobs [M][2][2], then haplobase [M], then haplocount [M]
+ *  cnf2_unpack_accumulators        the reverse (overwrites the listed records' accumulators)
+ *  cnf2_pack_rows / _unpack_rows   the genotype rows of the listed records, cnf2_packed_row_bytes() per record:
+ *                                  sure [M][2] f64, haploweight [M] f64, alleles [M] u8 (a0 | a1 << 4), padded to 8 bytes
+ * d_packed are device pointers; the calls return when the copy is done. */
+int    cnf2_exchange_buffer(cnf2_ctx *ctx, size_t bytes, void **d_buf);
+/* the first `bytes` of the exchange buffer to / from host memory: for transports that move host memory (gloo, MPI without
+ * GPU support); a device-aware transport (RCCL) works on the buffer in place */
+int    cnf2_exchange_download(cnf2_ctx *ctx, void *host_dst, size_t bytes);
+int    cnf2_exchange_upload(cnf2_ctx *ctx, const void *host_src, size_t bytes);
+size_t cnf2_packed_accumulator_doubles(const cnf2_ctx *ctx);
+size_t cnf2_packed_row_bytes(const cnf2_ctx *ctx);
+int    cnf2_pack_accumulators(cnf2_ctx *ctx, const int32_t *recs, int n, double *d_packed);
+int    cnf2_unpack_accumulators(cnf2_ctx *ctx, const int32_t *recs, int n, const double *d_packed);
+int    cnf2_pack_rows(cnf2_ctx *ctx, const int32_t *recs, int n, void *d_packed);
+int    cnf2_unpack_rows(cnf2_ctx *ctx, const int32_t *recs, int n, const void *d_packed);
 /* Diagnostics of the last cnf2_update_pass (flow kernels; see cnf2_kernels.hip).  out16[0..3] for the genotype
  * certainties, out16[4..7] for the haplotype weights: flows; gradient evaluations the scout spent on them; flows that ended
  * in the scout; flows pinned to their clamp (no evaluation beyond the first).  out16[8..11] / out16[12..15] for the flows the

@@ -39,20 +39,49 @@ int cnf2h_postmarkerdata(cnf2h_run *run, int indcount);
  * update = 0 sweeps without the parameter updates */
 int cnf2h_iteration(cnf2h_run *run, const char *rows_path, int update);
 /* Multi-process runs (the reference's dead MPI code: partition cnF2freq.cpp:5297-5299, reduce
- * 6245-6254).  Every rank holds the whole pedigree (ancestors' rows replicated) and runs the same postmarkerdata;
- * cnf2h_set_block gives the rank its block [begin, end) of the analysed individuals (positions in dous); the exchange
- * callback is called once per iteration, after the rank's sweep, with the DEVICE addresses of the per-record accumulator
- * slabs (infprobs [n_rec][M][2][2], haplobase / haplocount [n_rec][M]) and must leave the sums over all ranks in
- * them (an all-reduce; 0 = ok).  Every rank then runs the same update passes on the same numbers, so rows, hit
- * counters and step size stay identical on all ranks without further exchange.  Rows are printed for the rank's block. */
-typedef int (*cnf2h_exchange_fn)(void *user, double *d_infprobs, double *d_haplobase, double *d_haplocount, size_t n_rec,
-                                 size_t n_markers);
+ * 6245-6254, updates on the reduced values 6344-6392).  Every rank holds the whole pedigree (ancestors' rows replicated)
+ * and runs the same postmarkerdata.  cnf2h_set_partition(rank, world, transport) plans the run -- the same plan on every
+ * rank, a pure function of the pedigree:
+ *   blocks    contiguous blocks of the analysed individuals (positions in dous) balanced by what the sweep kernels spend
+ *             on an individual (markers x (1 + tie combinations)), their boundaries moved by up to a quarter of a block to
+ *             where the fewest records are touched from both sides: families that fit in a block stay whole;
+ *   records   a record only one rank's windows touch is PRIVATE to that rank; a record several ranks touch is SHARED and
+ *             owned by one of them (the one with the fewest so far);
+ * and sets this rank's block.  An iteration then is: sweep + accumulators of the block; the accumulators of the SHARED
+ * records, packed by owner, summed by one reduce-scatter (nothing at all when no family straddles a boundary); per
+ * chromosome the update pass of the records the rank owns and one sum of the hit counters (the step-size control,
+ * cnF2freq.cpp:6373-6392, stays identical on all ranks); the new rows of the shared records from their owners to
+ * everybody by one all-gather.  The rows of private records stay on their rank until the whole state is asked for
+ * (cnf2h_get_state, cnf2h_dump, cnf2h_postmarkerdata, cnf2h_deserialize: collectives then -- call them on every rank).
+ * Rows are printed for the rank's block.
+ *
+ * The transport carries the collectives; the engine does all packing on the device.  op:
+ *   CNF2H_X_SUM_SEGMENTS     buf = DEVICE pointer, `count` doubles in `world` segments of `seg`: on return segment `rank`
+ *                            holds the sum over all ranks of that segment (a reduce-scatter; other segments undefined)
+ *   CNF2H_X_SUM_HITS         buf = HOST int32[count]: in-place sum over all ranks
+ *   CNF2H_X_GATHER_SEGMENTS  buf = DEVICE pointer, `count` BYTES in `world` segments of `seg`: every rank has filled its
+ *                            own segment; on return all segments are filled on every rank (an all-gather)
+ * 0 = ok.  cnf2freq_amd/dist.py holds the torch.distributed transport (RCCL on the device buffer in place; gloo staged
+ * through the host). */
+enum { CNF2H_X_SUM_SEGMENTS = 0, CNF2H_X_SUM_HITS = 1, CNF2H_X_GATHER_SEGMENTS = 2 };
+typedef int (*cnf2h_exchange_fn)(void *user, int op, void *buf, size_t count, size_t seg);
+int cnf2h_set_partition(cnf2h_run *run, int rank, int world, cnf2h_exchange_fn fn, void *user);
+/* the plan in numbers: info[0..1] this rank's block [begin, end); [2] records the rank owns; [3] shared records in all;
+ * [4] shared records per segment (the largest owner's); bytes per iteration of [5] the reduce-scatter buffer, [6] the
+ * all-gather buffer, [7] the hit counters; [8] the payload (what the shared records occupy in them); [9] private records of
+ * the rank.  owned (optional) receives the records the rank owns, ascending (info[2] entries). */
+int cnf2h_get_partition(cnf2h_run *run, int64_t *info10, int32_t *owned);
+/* a sub-range [begin, end) of the analysed individuals for this process's sweeps and rows (single-process use) */
 int cnf2h_set_block(cnf2h_run *run, int begin, int end);
-/* block `rank` of `world` contiguous blocks of dous balanced by what the sweep kernels spend on an individual: markers x
- * (1 + number of tie combinations); does not set it */
+/* block `rank` of `world` as cnf2h_set_partition would cut it; does not set it */
 int cnf2h_balanced_block(cnf2h_run *run, int rank, int world, int32_t *begin, int32_t *end);
-int cnf2h_set_exchange(cnf2h_run *run, cnf2h_exchange_fn fn, void *user);
-/* accumulators added in a fixed order (CNF2_DETERMINISTIC of cnf2hip.h): iterations reproduce to the bit */
+/* form of the update passes: 0 = fast kernels, one certainty flow per side and its mirror image (within rounding of the
+ * reference's form), or CNF2_UPDATE_BOTH_FLOWS (fast kernels, bit-exact form), CNF2_UPDATE_PLAIN (literal kernels),
+ * CNF2_UPDATE_ONE_SCOUT of cnf2hip.h.  Until this is called a run uses 0, or CNF2_UPDATE_BOTH_FLOWS once
+ * cnf2h_set_deterministic is on.  Nothing in the libraries reads the environment for this. */
+int cnf2h_set_update_flags(cnf2h_run *run, uint32_t flags);
+/* accumulators added in a fixed order (CNF2_DETERMINISTIC of cnf2hip.h) and the update passes in their bit-exact form
+ * (CNF2_UPDATE_BOTH_FLOWS): iterations reproduce to the bit */
 int cnf2h_set_deterministic(cnf2h_run *run, int on);
 /* the cnf2_ctx of the run (for callers that move the accumulators themselves: cnf2_download_accumulators, ...) */
 void *cnf2h_context(cnf2h_run *run);

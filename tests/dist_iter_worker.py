@@ -1,7 +1,8 @@
 """Worker of tests/test_dist_gpu.py::test_two_rank_iterations_equal_single_rank: one rank of a multi-process haplotyping
 run (BASELINE config 5's shape).  Launched through `python -m torch.distributed.run`; every rank holds the pedigree, sweeps
-its work-balanced block of analysed individuals on the GPU, and the per-record accumulators meet in one all-reduce per
-iteration (cnf2freq_amd.dist.start_iterations -> libcnf2host.so: cnf2h_set_block / cnf2h_set_exchange).
+its block of analysed individuals on the GPU, the accumulators of the records both ranks' windows touch meet in one
+reduce-scatter per iteration, every rank updates the records it owns and the shared records' new rows are all-gathered
+(cnf2freq_amd.dist.start_iterations -> libcnf2host.so: cnf2h_set_partition).
 usage: dist_iter_worker.py OUT_PREFIX BACKEND N_ITER"""
 import os
 import sys
@@ -18,9 +19,10 @@ from cnf2freq_amd import synth
 
 
 def make_ped():
-    # 5 families x 3 analysed children: with two ranks the split falls inside family 2 (its parents and grandparents
-    # collect evidence from both ranks); two chromosomes of different length
-    ped = synth.make_outbred3(5, 3, 17, 2, seed=77, missing=0.2)
+    # 3 families x 6 analysed children: with two ranks the split falls inside family 1, which is too big for the boundary
+    # to move around it (its parents and grandparents collect evidence from both ranks: shared records); families 0 and 2
+    # stay whole on their rank (private records: nothing of them is exchanged); two chromosomes
+    ped = synth.make_outbred3(3, 6, 17, 2, seed=77, missing=0.2)
     return ped
 
 
@@ -46,7 +48,9 @@ def main():
     st = run.state()
     ps = run.passes()
     np.savez("%s_rank%d.npz" % (prefix, rank), allele=st["allele"], sure=st["sure"], hw=st["hw"], hits=np.array(hits),
-             scalefactor=st["scalefactor"], haplobase=ps["haplobase"], haplocount=ps["haplocount"], block=np.array(run.block))
+             scalefactor=st["scalefactor"], haplobase=ps["haplobase"], haplocount=ps["haplocount"], block=np.array(run.block),
+             owned=run.plan["owned"], n_shared=run.plan["n_shared"], bytes_payload=run.plan["bytes_payload"],
+             bytes_moved=run.transport.bytes_moved, calls=np.array([run.transport.calls[k] for k in (0, 1, 2)]))
     run.close()
     if dist.is_initialized():
         dist.barrier()

@@ -78,7 +78,8 @@ def main():
                                     hb.data_ptr(), hc.data_ptr(), hz.data_ptr())
     ctx.sync()
     acc = [t.cpu() if staged else t for t in (inf, hb, hc)]
-    cdist.allreduce_accumulators(*acc)
+    for t in acc:                                   # caller-owned slabs (CNF2_ACC_DEVICE): the caller sums them as it likes
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if rank == 0:
         sizes = [cdist.shard_range(n, r, world) for r in range(world)]
         dos = np.concatenate([full[r, :b - a] for r, (a, b) in enumerate(sizes)])

@@ -28,8 +28,51 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
 
 #include "cnf2_update.h"
 #include "cnf2_variance.h"
+#include "host/cnf2_partition.h"
 
 extern "C" {
+
+// The plan of a multi-process run (csrc/host/cnf2_partition.h) for `world` ranks from the window tables the product derives:
+// bounds[world + 1]; owner[n_rec] = rank that updates the record (-1: no window touches it); shared[n_rec] = 1 where several
+// ranks' windows touch the record; returns the records per segment of the exchange buffer.
+int shim_partition(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const int32_t* row_of,
+                   const int32_t* dous, int n_dous, int n_markers, int world, int32_t* bounds, int32_t* owner, uint8_t* shared)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    std::vector<int32_t> table((size_t)n_dous * 17);
+    for (int j = 0; j < n_dous; j++) {
+        Window  w;
+        int32_t slot_rec[7];
+        derive_window(P, dous[j], &w, slot_rec);
+        int32_t* o = &table[(size_t)j * 17];
+        o[0] = w.shiftignore;
+        o[1] = w.flag2ignore;
+        o[2] = P.founder[dous[j]];
+        for (int i = 0; i < 7; i++) {
+            o[3 + i]  = slot_rec[i];
+            o[10 + i] = w.tie[i];
+        }
+    }
+    for (int r = 0; r < n_rec; r++) {
+        owner[r] = -1;
+        shared[r] = 0;
+    }
+    int seg = 0;
+    for (int q = 0; q < world; q++) {
+        const cnf2host::Partition Q = cnf2host::plan_partition(n_rec, n_dous, n_markers, table.data(), q, world);
+        if (q == 0) {
+            for (int k = 0; k <= world; k++) bounds[k] = Q.bounds[k];
+            for (int k = 0; k < world; k++)
+                for (int r : Q.shared_of[k]) shared[r] = 1;
+            seg = (int)Q.seg_shared;
+        }
+        for (int r : Q.owned) {
+            if (owner[r] >= 0) return -1;          // two ranks claim a record
+            owner[r] = q;
+        }
+    }
+    return seg;
+}
 
 int shim_founders(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,
                   const int32_t* row_of, uint8_t* out)

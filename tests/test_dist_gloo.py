@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 from cnf2freq_amd import dist as cdist
 from cnf2freq_amd import synth
-from conftest import oracle_ped
+from conftest import ROOT, oracle_ped
 
 
 def _free_port():
@@ -118,41 +118,126 @@ def test_marker_tiled_gather_single_process():
     assert torch.equal(out, src) and tg.root_bytes() == 0
 
 
-def _acc_worker(rank, world, port, q):
+def _transport_worker(rank, world, port, q):
+    import ctypes as C
     import torch
+    from cnf2freq_amd import host
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    R, M = 4, 5
-    g = torch.Generator().manual_seed(100 + rank)
-    parts = [torch.rand((R, M, 2, 2), generator=g, dtype=torch.float64), torch.rand((R, M), generator=g, dtype=torch.float64),
-             torch.rand((R, M), generator=g, dtype=torch.float64)]
-    mine = [p.clone() for p in parts]
-    cdist.allreduce_accumulators(*parts)
-    # every rank must hold the sum of all ranks' partial accumulators
-    want = [torch.zeros_like(p) for p in parts]
-    for r in range(world):
-        gr = torch.Generator().manual_seed(100 + r)
-        for w, shape in zip(want, [(R, M, 2, 2), (R, M), (R, M)]):
-            w += torch.rand(shape, generator=gr, dtype=torch.float64)
-    ok = all(torch.allclose(a, b, rtol=1e-14, atol=0) for a, b in zip(parts, want)) and not torch.equal(parts[0], mine[0])
+    T = cdist.Transport(None, ctx=None)          # no context: the buffers are host memory
+    seg = 7
+    ok = True
+    # X_SUM_SEGMENTS: segment `rank` must hold the sum over ranks of that segment
+    mine = np.random.RandomState(100 + rank).rand(world * seg)
+    buf = mine.copy()
+    ok &= T(host.X_SUM_SEGMENTS, buf.ctypes.data, world * seg, seg) == 0
+    want = sum(np.random.RandomState(100 + r).rand(world * seg) for r in range(world))
+    ok &= bool(np.allclose(buf[rank * seg:(rank + 1) * seg], want[rank * seg:(rank + 1) * seg], rtol=1e-14, atol=0))
+    # X_GATHER_SEGMENTS: every rank's own segment to all
+    rows = np.zeros(world * seg, np.uint8)
+    rows[rank * seg:(rank + 1) * seg] = 10 * (rank + 1) + np.arange(seg)
+    ok &= T(host.X_GATHER_SEGMENTS, rows.ctypes.data, world * seg, seg) == 0
+    ok &= bool(np.array_equal(rows, np.concatenate([10 * (r + 1) + np.arange(seg) for r in range(world)]).astype(np.uint8)))
+    # X_SUM_HITS
+    hits = np.array([rank + 1, 5], np.int32)
+    ok &= T(host.X_SUM_HITS, hits.ctypes.data, 2, 2) == 0
+    ok &= hits.tolist() == [world * (world + 1) // 2, 5 * world]
+    ok &= T.calls == {0: 1, 1: 1, 2: 1} and T.bytes_moved == world * seg * 9 + 16
     q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_accumulator_allreduce_two_ranks():
-    """The collective of a haplotyping iteration (shared-ancestor accumulator slabs, cnF2freq.cpp:6245-6254)."""
+def test_transport_collectives_two_ranks():
+    """The three collectives of a haplotyping iteration's exchange (cnf2host.h: the reduce-scatter of the shared records'
+    accumulators -- the reference reduces per individual, cnF2freq.cpp:6245-6254 --, the sum of the hit counters, the
+    all-gather of the shared records' rows) over gloo on host buffers."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_acc_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True and q.get(timeout=5) is True
+
+
+def _plan(shim, ped, world):
+    import ctypes as C
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    bounds = np.zeros(world + 1, np.int32)
+    owner = np.zeros(ped.n_rec, np.int32)
+    shared = np.zeros(ped.n_rec, np.uint8)
+    dous = np.ascontiguousarray(ped.dous, np.int32)
+    seg = shim.shim_partition(ped.n_rec, P(ped.par), P(ped.empty), P(ped.gen), P(ped.row_of), P(dous), len(dous), ped.n_markers,
+                              world, P(bounds), P(owner), P(shared))
+    assert seg >= 0, "two ranks claim a record"
+    return bounds, owner, shared, seg
+
+
+def test_partition_keeps_families_whole_and_shares_only_what_straddles():
+    """Engine::plan (csrc/host/cnf2_partition.h) on the CPU, through the host shim.  BASELINE config 5's shape -- disjoint
+    three-generation families -- must give blocks that cut between families: nothing shared, nothing to exchange.  A
+    pedigree in which every cut splits a family (two big half-sib families) must share exactly the records both sides'
+    windows touch, each owned by one of its touchers; the F2 design shares its two founders."""
+    import subprocess
+    import ctypes as C
+    from cnf2freq_amd import synth
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    csrc = os.path.join(ROOT, "cnf2freq_amd", "csrc")
+    so = os.path.join(shim_dir, "libcnf2hostshim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + csrc, "-o", so,
+                           os.path.join(shim_dir, "host_shim.cpp"), os.path.join(csrc, "cnf2_window.cpp")])
+    shim = C.CDLL(so)
+
+    def touched_by(ped, bounds):
+        """per rank the records its windows touch: the analysed individual, its parents and grandparents"""
+        out = []
+        for b, e in zip(bounds, bounds[1:]):
+            t = set()
+            for ind in ped.dous[b:e]:
+                t.add(int(ind))
+                for p in ped.par[ind]:
+                    if p >= 0:
+                        t.add(int(p))
+                        t.update(int(g) for g in ped.par[p] if g >= 0)
+            out.append(t)
+        return out
+
+    # (1) config 5's shape: 23 families of 3 analysed children over 2, 3, 4 and 8 ranks
+    ped = synth.make_outbred3(23, 3, 5, 1, seed=4, missing=0.2)
+    for world in (2, 3, 4, 8):
+        bounds, owner, shared, seg = _plan(shim, ped, world)
+        assert bounds[0] == 0 and bounds[-1] == len(ped.dous) and np.all(np.diff(bounds) >= 0)
+        assert np.all(bounds % 3 == 0), "a block boundary falls inside a family: %s" % bounds
+        assert shared.sum() == 0 and seg == 0
+        sizes = np.diff(bounds)
+        assert sizes.max() - sizes.min() <= 3 * 2, sizes             # balanced to within two families
+        t = touched_by(ped, bounds)
+        for q in range(world):
+            assert set(np.flatnonzero(owner == q)) == t[q]
+    # (2) one big family: every cut splits it -- the parents and grandparents are shared, the children private
+    big = synth.make_outbred3(1, 12, 5, 1, seed=5, missing=0.1)
+    bounds, owner, shared, seg = _plan(shim, big, 2)
+    assert 0 < bounds[1] < 12
+    t = touched_by(big, bounds)
+    both = t[0] & t[1]
+    assert set(np.flatnonzero(shared)) == both and len(both) == 6
+    assert all(owner[r] in (0, 1) for r in both) and abs(int((owner[list(both)] == 0).sum()) - 3) <= 1   # owners balanced
+    for q in range(2):
+        assert set(np.flatnonzero((owner == q) & (shared == 0))) == t[q] - both
+    assert seg == 3
+    # (3) the F2 design: private F1 parents, the two founders shared by every rank
+    f2 = synth.make_f2(40, 5, 1, seed=6)
+    bounds, owner, shared, seg = _plan(shim, f2, 4)
+    assert list(np.diff(bounds)) == [10, 10, 10, 10] and shared.sum() == 2 and seg == 1
+    # (4) a mix: private families and one family that is bigger than the tolerance lets a boundary move
+    mix = synth.make_outbred3(6, 2, 5, 1, seed=7, missing=0.1)
+    bounds, owner, shared, seg = _plan(shim, mix, 2)
+    assert bounds[1] == 6 and shared.sum() == 0
 
 
 def test_balanced_blocks_cover_and_balance():

@@ -76,14 +76,17 @@ def _row_blocks(path):
 
 
 def test_two_rank_iterations_equal_single_rank(tmp_path):
-    """BASELINE config 5's multi-GPU leg, correct before it is fast: 2 ranks x 3 haplotyping iterations (sweep of the
-    rank's block, ONE all-reduce of the accumulator slabs, the same update passes on every rank) on an outbred pedigree
-    whose families straddle the split = the single-rank run: genotypes and hit counters identical, certainties /
-    haplotype weights / haplobase / haplocount to 1e-9, both ranks bit-identical to each other, and the rows of the first
-    sweep (same parameters on both sides) equal to the character."""
+    """BASELINE config 5's multi-GPU leg, correct before it is fast: 2 ranks x 3 haplotyping iterations on an outbred pedigree
+    that mixes families private to a rank with one family that straddles the split (sweep of the rank's block, ONE
+    reduce-scatter of the SHARED records' accumulators, every rank updating the records it owns, one sum of the hit counters
+    per pass, ONE all-gather of the shared records' new rows) = the single-rank run: genotypes and hit counters identical,
+    certainties / haplotype weights / haplobase / haplocount to 1e-9, the gathered state bit-identical on both ranks, and the
+    rows of the first sweep (same parameters on both sides) equal to the character.  What is exchanged is the six shared
+    records, not the slabs."""
     import __graft_entry__ as g
     g.build()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_iter_worker
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     worker = os.path.join(ROOT, "tests", "dist_iter_worker.py")
     two, one = str(tmp_path / "two"), str(tmp_path / "one")
@@ -94,29 +97,42 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     r = subprocess.run([sys.executable, worker, one, "gloo", "3"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     z0, z1, z = np.load(two + "_rank0.npz"), np.load(two + "_rank1.npz"), np.load(one + "_rank0.npz")
+    ped = dist_iter_worker.make_ped()
+    M, R = ped.n_markers, ped.n_rec
     b0, b1 = z0["block"], z1["block"]
-    assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == 15 and 0 < b0[1] < 15 and b0[1] % 3 != 0, "the split should fall inside a family"
-    for k in ("allele", "sure", "hw", "hits", "scalefactor", "haplobase", "haplocount"):
+    assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == 18 and 6 < b0[1] < 12, "the split should fall inside family 1"
+    # the plan: family 1's two parents and four grandparents are shared, everything else the windows touch is private
+    assert z0["n_shared"] == 6 and z1["n_shared"] == 6
+    own0, own1 = set(z0["owned"].tolist()), set(z1["owned"].tolist())
+    assert not own0 & own1 and len(own0 | own1) == R, "every record of this pedigree is touched and owned exactly once"
+    # what travelled: 3 iterations x (6 shared records x (48 + 25) B x M in one reduce-scatter and one all-gather, 2 hit counters)
+    assert z0["bytes_payload"] == 6 * (M * 48 + ((M * 25 + 7) // 8) * 8) + 2 * 4
+    assert list(z0["calls"]) == [3, 6, 4]          # 3 reduce-scatters, 3 x 2 passes' hit sums, 3 all-gathers + the state's gather
+    assert z0["bytes_moved"] < 0.5 * 3 * R * M * 48, "the exchange must stay far below the full slabs"
+    for k in ("allele", "sure", "hw", "hits", "scalefactor"):
         assert np.array_equal(z0[k], z1[k], equal_nan=True), "ranks differ in " + k
     assert np.array_equal(z0["allele"], z["allele"])
     assert np.array_equal(z0["hits"], z["hits"]) and z["hits"].sum() > 0
     assert z0["scalefactor"] == z["scalefactor"]
     for k in ("sure", "hw"):
         np.testing.assert_allclose(z0[k], z[k], rtol=1e-9, atol=1e-12, err_msg=k)
-    # haplobase / haplocount as left behind: a slot that is homozygous with EQUAL certainties takes no part in the HAPLOS
-    # update (cnF2freq.cpp:1224-1239 compares the two certainties for equality).  Where the two sides of an individual
-    # collect the same evidence their certainties are equal up to the order of the additions, and one ulp decides
-    # whether the slot counts: such elements are left out (their haplotype weights agree all the same, see above).
+    # haplobase / haplocount as left behind, on the rank that owns the record: a slot that is homozygous with EQUAL
+    # certainties takes no part in the HAPLOS update (cnF2freq.cpp:1224-1239 compares the two certainties for equality).
+    # Where the two sides of an individual collect the same evidence their certainties are equal up to the order of the
+    # additions, and one ulp decides whether the slot counts: such elements are left out (their haplotype weights agree
+    # all the same, see above).
     knife = (z["allele"][..., 0] == z["allele"][..., 1]) & np.isclose(z["sure"][..., 0], z["sure"][..., 1], rtol=1e-9, atol=0)
     assert knife.sum() < 0.5 * knife.size
-    for k in ("haplobase", "haplocount"):
-        np.testing.assert_allclose(z0[k][~knife], z[k][~knife], rtol=1e-9, atol=1e-12, err_msg=k)
+    for zk in (z0, z1):
+        own = zk["owned"]
+        for k in ("haplobase", "haplocount"):
+            np.testing.assert_allclose(zk[k][own][~knife[own]], z[k][own][~knife[own]], rtol=1e-9, atol=1e-12, err_msg=k)
     want = _row_blocks(one + "_rows_it1_rank0.txt")
     got = dict(_row_blocks(two + "_rows_it1_rank0.txt"))
     got1 = _row_blocks(two + "_rows_it1_rank1.txt")
     assert not set(got) & set(got1)
     got.update(got1)
-    assert got == want and len(want) == 15 * 2
+    assert got == want and len(want) == 18 * 2
 
 
 def test_rccl_exchange_on_one_rank():

@@ -234,18 +234,13 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     for rnd in range(4):
         out = {}
         # mirror: the product's kernels (one flow per side where both values have evidence, the other its mirror image);
-        # flow: both values' flows as the reference runs them (CNF2_CERTAINTY_BOTH=1), the certainties' scout in two passes;
-        # flow1: that scout in one pass (CNF2_SCOUT_PASSES=1)
-        for name, flags, env in (("mirror", 0, {}), ("flow", 0, {"CNF2_CERTAINTY_BOTH": "1"}),
-                                 ("flow1", 0, {"CNF2_CERTAINTY_BOTH": "1", "CNF2_SCOUT_PASSES": "1"}), ("plain", capi.UPDATE_PLAIN, {})):
+        # flow: both values' flows as the reference runs them (CNF2_UPDATE_BOTH_FLOWS), the certainties' scout in two passes;
+        # flow1: that scout in one pass (CNF2_UPDATE_ONE_SCOUT).  The forms are flags of the call: nothing reads the environment
+        for name, flags in (("mirror", 0), ("flow", capi.UPDATE_BOTH_FLOWS),
+                            ("flow1", capi.UPDATE_BOTH_FLOWS | capi.UPDATE_ONE_SCOUT), ("plain", capi.UPDATE_PLAIN)):
             ctx = ctxs[name]
             acc = ctx.sweep_accumulate(desc, deterministic=True)
-            os.environ.update(env)
-            try:
-                hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
+            hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
             out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
         total_hits += sum(out["flow"][0])
         for name in ("flow", "flow1"):
@@ -314,44 +309,98 @@ def test_fixparents_scan_beyond_one_grid(libs):
     ctx.close()
 
 
-def test_exchange_callback_sees_the_device_slabs(libs):
-    """The exchange hook of a multi-process run (cnf2h_set_exchange): called once per iteration with the device addresses
-    of the accumulator slabs; torch tensors that alias them (cnf2freq_amd.dist.device_slabs -- what the RCCL all-reduce
-    works on) read the same numbers cnf2_download_accumulators copies out, and a change made through them reaches the
-    update pass."""
+def _children_of(ped):
+    children = np.zeros(ped.n_rec, np.int32)
+    for r in ped.dous:
+        for k in range(2):
+            if ped.par[r, k] >= 0:
+                children[ped.par[r, k]] += 1
+    return children
+
+
+@pytest.mark.parametrize("flags", ["mirror", "both"])
+def test_update_pass_by_record_lists_equals_the_whole_pass(libs, flags):
+    """cnf2_update_pass_records: a rank of a multi-process run updates the records it owns (cnF2freq.cpp:6344-6368 loops over
+    individuals; an individual's update reads only its own accumulators and rows).  Three disjoint lists -- one of them
+    empty -- over two chromosomes leave the rows, haplobase / haplocount and the hit counters of ONE pass over all records,
+    to the bit."""
+    capi, _ = libs
+    uf = capi.UPDATE_BOTH_FLOWS if flags == "both" else 0
+    ped = synth.make_outbred3(5, 4, 23, 2, seed=18, missing=0.2)
+    children = _children_of(ped)
+    rs = np.random.RandomState(5)
+    label = rs.randint(0, 2, ped.n_rec)
+    lists = [np.flatnonzero(label == 0).astype(np.int32), np.zeros(0, np.int32), np.flatnonzero(label == 1).astype(np.int32)]
+    out = []
+    for split in (False, True):
+        run_rows = []
+        ctx = capi.Context(0)
+        ctx.upload_for_updates(ped)
+        desc = ctx.descendants()
+        total = []
+        for rnd in range(2):
+            ctx.sweep_accumulate_keep(desc, deterministic=True)
+            for c in range(2):
+                if split:
+                    total.append(sum(ctx.update_pass_records(c, l, children, desc, 0.19, 1.0, flags=uf) for l in lists))
+                else:
+                    total.append(ctx.update_pass(c, children, desc, 0.19, 1.0, None, flags=uf))
+        acc = ctx.download_accumulators()
+        out.append((total, ctx.download_rows(1, ped.n_rec), acc))
+        ctx.close()
+    assert out[0][0] == out[1][0] and sum(out[0][0]) > 0
+    for x, y in zip(out[0][1], out[1][1]):
+        assert np.array_equal(x, y)
+    for k in ("infprobs", "haplobase", "haplocount"):
+        assert np.array_equal(out[0][2][k], out[1][2][k], equal_nan=True), k
+
+
+def test_pack_and_unpack_of_the_exchange(libs):
+    """The packers of a multi-process run's exchange (cnf2_pack_accumulators / cnf2_pack_rows and their reverse): listed
+    records' accumulators and rows to a packed device buffer and back, any order of records, against the plain downloads."""
     import torch
-    capi, host = libs
+    capi, _ = libs
     from cnf2freq_amd import dist as cdist
-    ped = synth.make_outbred3(3, 3, 12, 2, seed=12, missing=0.2)
-    seen = {}
-
-    def exchange(a, b, c, n_rec, n_markers):
-        ts = cdist.device_slabs(a, b, c, n_rec, n_markers, torch.device("cuda", 0))
-        got = capi.Context.accumulators_of(run.context(), n_rec, n_markers)
-        seen["same"] = all(np.array_equal(t.cpu().numpy(), got[k].ravel(), equal_nan=True)
-                           for t, k in zip(ts, ("infprobs", "haplobase", "haplocount")))
-        seen["calls"] = seen.get("calls", 0) + 1
-        seen["sum"] = float(ts[2].sum().item())
-        if zero:
-            for t in ts:
-                t.zero_()
-            torch.cuda.synchronize()
-        return 0
-
-    states = []
-    for zero in (False, True):
-        run = host.Run(ped)
-        run.postmarkerdata()
-        s0 = run.state()
-        run.set_exchange(exchange)
-        run.iteration()
-        states.append(run.state())
-        assert seen["same"] and seen["sum"] > 0
-        run.close()
-    assert seen["calls"] == 2
-    # with the evidence wiped by the callback nothing was learnt: the haplotype weights of the second run stay
-    assert np.abs(states[0]["hw"] - s0["hw"]).max() > 1e-4
-    assert np.abs(states[1]["hw"] - s0["hw"]).max() < np.abs(states[0]["hw"] - s0["hw"]).max()
+    ped = synth.make_outbred3(4, 3, 19, 2, seed=14, missing=0.2, random_hw=True, random_sure=True)
+    ctx = capi.Context(0)
+    ctx.upload_for_updates(ped)
+    desc = ctx.descendants()
+    ctx.sweep_accumulate_keep(desc)
+    acc = ctx.download_accumulators()
+    rows = ctx.download_rows(1, ped.n_rec)
+    M = ped.n_markers
+    recs = np.array([7, 2, 11, 3, ped.n_rec - 1], np.int32)
+    S, B = M * 6, ((M * 25 + 7) // 8) * 8
+    buf = ctx.exchange_buffer(len(recs) * max(S * 8, B))
+    ctx.pack_accumulators(recs, buf)
+    t = cdist.device_view(buf, len(recs) * S, torch.float64, torch.device("cuda", 0)).cpu().numpy().reshape(len(recs), S)
+    for i, r in enumerate(recs):
+        assert np.array_equal(t[i, :M * 4], acc["infprobs"][r].ravel())
+        assert np.array_equal(t[i, M * 4:M * 5], acc["haplobase"][r]) and np.array_equal(t[i, M * 5:], acc["haplocount"][r])
+    assert np.abs(t).sum() > 0
+    # scatter them onto other records: the accumulators of recs[i] land on dst[i]
+    dst = np.array([0, 1, 4, 5, 6], np.int32)
+    ctx.unpack_accumulators(dst, buf)
+    acc2 = ctx.download_accumulators()
+    for k in acc:
+        assert np.array_equal(acc2[k][dst], acc[k][recs]), k
+        keep = np.setdiff1d(np.arange(ped.n_rec), dst)
+        assert np.array_equal(acc2[k][keep], acc[k][keep]), k
+    # rows
+    ctx.pack_rows(recs, buf)
+    b = cdist.device_view(buf, len(recs) * B, torch.uint8, torch.device("cuda", 0)).cpu().numpy().reshape(len(recs), B)
+    for i, r in enumerate(recs):
+        assert np.array_equal(b[i, :M * 16].view(np.float64).reshape(M, 2), rows[1][r])
+        assert np.array_equal(b[i, M * 16:M * 24].view(np.float64), rows[2][r])
+        a8 = b[i, M * 24:M * 25]
+        assert np.array_equal(np.stack([a8 & 15, a8 >> 4], axis=1), rows[0][r])
+    ctx.unpack_rows(dst, buf)
+    rows2 = ctx.download_rows(1, ped.n_rec)
+    for x, y in zip(rows2, rows):
+        assert np.array_equal(x[dst], y[recs]) and np.array_equal(np.delete(x, dst, axis=0), np.delete(y, dst, axis=0))
+    # the window tables are derived again after rows changed (homozygous-everywhere flags): a sweep still runs
+    ctx.sweep()
+    ctx.close()
 
 
 def test_iterations_do_not_lose_the_withheld_genotypes(libs):

@@ -1,7 +1,7 @@
 """Clean A/B of the update pass's variants on one box: the same deterministic run (CNF2_DETERMINISTIC accumulators: the
-variants are bit-identical, so the trajectories are) repeated with different settings of an environment switch; per-iteration
-wall time of each.  usage: python tools/ab_scout.py [families=500] [snps=2500] [chroms=4] [iterations=30] [ENV=values,...]
-e.g. CNF2_SCOUT_PASSES=2,1"""
+variants are bit-identical, so the trajectories are) repeated with different update forms (flags of cnf2h_set_update_flags);
+per-iteration wall time of each.  usage: python tools/ab_scout.py [families=500] [snps=2500] [chroms=4] [iterations=30] [forms]
+forms = comma list of mirror, both, both_one_scout, plain (default: both,both_one_scout)"""
 import os
 import sys
 import time
@@ -10,21 +10,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 
-from cnf2freq_amd import host, synth
+from cnf2freq_amd import capi, host, synth
 
 fams = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 snps = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 chroms = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 30
-name, values = (sys.argv[5] if len(sys.argv) > 5 else "CNF2_SCOUT_PASSES=2,1").split("=")
-values = values.split(",")
+name = "form"
+values = (sys.argv[5] if len(sys.argv) > 5 else "both,both_one_scout").split(",")
+FORMS = {"mirror": 0, "both": capi.UPDATE_BOTH_FLOWS, "both_one_scout": capi.UPDATE_BOTH_FLOWS | capi.UPDATE_ONE_SCOUT,
+         "plain": capi.UPDATE_PLAIN}
 ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 times, states = {}, {}
 for rep in range(2):
     for v in values:
-        os.environ[name] = v
         run = host.Run(ped)
         run.set_deterministic(True)
+        run.set_update_flags(FORMS[v])
         run.postmarkerdata()
         t = []
         for it in range(iters):

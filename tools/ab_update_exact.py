@@ -10,10 +10,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-os.environ.setdefault("CNF2_CERTAINTY_BOTH", "1")      # the exact comparison is with both values' flows run (the mirror shortcut off)
 import torch  # noqa: F401
 
-from cnf2freq_amd import host, synth
+from cnf2freq_amd import capi, host, synth
 
 fams = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 snps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -24,6 +23,8 @@ runs = {}
 for name in ("fast", "literal"):
     r = host.Run(ped)
     r.set_deterministic(True)
+    # the exact comparison is with both values' flows run (the mirror shortcut off) against the literal kernels
+    r.set_update_flags(capi.UPDATE_BOTH_FLOWS if name == "fast" else capi.UPDATE_PLAIN)
     r.postmarkerdata()
     runs[name] = r
 flows = 0
@@ -31,10 +32,6 @@ t = {"fast": 0.0, "literal": 0.0}
 for it in range(iters):
     st = {}
     for name, r in runs.items():
-        if name == "literal":
-            os.environ["CNF2_UPDATE_PLAIN"] = "1"
-        else:
-            os.environ.pop("CNF2_UPDATE_PLAIN", None)
         t0 = time.time()
         r.iteration(None)
         t[name] += time.time() - t0

@@ -20,19 +20,12 @@ ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 run = host.Run(ped)
 run.postmarkerdata()
 cap = {}
-
-
-def ex(a, b, c, R, M):
-    if cap.get("arm"):
-        cap["acc"] = capi.Context.accumulators_of(run.context(), R, M)
-    return 0
-
-
-run.set_exchange(ex)
 for it in range(iters - 1):
     run.iteration(None)
 st = run.state()
-cap["arm"] = True
+# the accumulators the last iteration's updates will see: a sweep without updates leaves them in the context
+run.iteration(None, update=False)
+cap["acc"] = capi.Context.accumulators_of(run.context(), ped.n_rec, ped.n_markers)
 run.iteration(None)
 st2 = run.state()
 rs = np.random.RandomState(1)

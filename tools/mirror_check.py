@@ -1,4 +1,4 @@
-"""How far the mirrored certainty flows (default) move a run away from the form that runs both flows (CNF2_CERTAINTY_BOTH=1):
+"""How far the mirrored certainty flows (default) move a run away from the form that runs both flows (CNF2_UPDATE_BOTH_FLOWS):
 the same deterministic run both ways, states compared after every iteration.
 usage: python tools/mirror_check.py [families=200] [snps=1000] [chroms=2] [iterations=5]"""
 import os
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 
-from cnf2freq_amd import host, synth
+from cnf2freq_amd import capi, host, synth
 
 fams = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 snps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -16,33 +16,22 @@ chroms = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 runs = {}
-for name, env in (("mirror", None), ("both", "1")):
-    if env:
-        os.environ["CNF2_CERTAINTY_BOTH"] = env
-    else:
-        os.environ.pop("CNF2_CERTAINTY_BOTH", None)
+cap = {}
+for name, form in (("mirror", 0), ("both", capi.UPDATE_BOTH_FLOWS)):
     r = host.Run(ped)
     r.set_deterministic(True)
+    r.set_update_flags(form)
     r.postmarkerdata()
     if name == "both":
-        cap = {}
-
-        def ex(a, b, c, R, M, r=r):
-            if "acc" not in cap:
-                from cnf2freq_amd import capi
-                cap["acc"] = capi.Context.accumulators_of(r.context(), R, M)
-            return 0
-        r.set_exchange(ex)
+        # the accumulators of the first sweep, for the print-out below: a sweep without updates leaves them in the context
+        r.iteration(None, update=False)
+        cap["acc"] = capi.Context.accumulators_of(r.context(), ped.n_rec, ped.n_markers)
     runs[name] = r
 prev = runs["both"].state()
 a0, s0, _ = ped.dense()
 for it in range(iters):
     st = {}
-    for name, env in (("mirror", None), ("both", "1")):
-        if env:
-            os.environ["CNF2_CERTAINTY_BOTH"] = env
-        else:
-            os.environ.pop("CNF2_CERTAINTY_BOTH", None)
+    for name in ("mirror", "both"):
         runs[name].iteration(None)
         st[name] = runs[name].state()
     for k in ("sure", "hw"):
