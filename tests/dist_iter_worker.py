@@ -3,7 +3,7 @@ run (BASELINE config 5's shape).  Launched through `python -m torch.distributed.
 its block of analysed individuals on the GPU, the accumulators of the records both ranks' windows touch meet in one
 reduce-scatter per iteration, every rank updates the records it owns and the shared records' new rows are all-gathered
 (cnf2freq_amd.dist.start_iterations -> libcnf2host.so: cnf2h_set_partition).
-usage: dist_iter_worker.py OUT_PREFIX BACKEND N_ITER"""
+usage: dist_iter_worker.py OUT_PREFIX BACKEND N_ITER [deterministic=0]"""
 import os
 import sys
 
@@ -37,7 +37,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     ped = make_ped()
-    run = cdist.start_iterations(ped, device=local)
+    run = cdist.start_iterations(ped, device=local, deterministic=len(sys.argv) > 4 and sys.argv[4] == "1")
     hits = []
     for k in range(n_iter):
         rows = "%s_rows_it%d_rank%d.txt" % (prefix, k + 1, rank)

@@ -82,7 +82,9 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     per pass, ONE all-gather of the shared records' new rows) = the single-rank run: genotypes and hit counters identical,
     certainties / haplotype weights / haplobase / haplocount to 1e-9, the gathered state bit-identical on both ranks, and the
     rows of the first sweep (same parameters on both sides) equal to the character.  What is exchanged is the six shared
-    records, not the slabs."""
+    records, not the slabs.  The runs add their accumulators in a fixed order (CNF2_DETERMINISTIC), so the families that are
+    private to a rank -- nothing of them is exchanged, their sums are formed in the single-rank order -- must come out
+    BIT-IDENTICAL to the single-rank run; the straddling family's sums are two partial sums added, equal to rounding."""
     import __graft_entry__ as g
     g.build()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,10 +93,10 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     worker = os.path.join(ROOT, "tests", "dist_iter_worker.py")
     two, one = str(tmp_path / "two"), str(tmp_path / "one")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), worker, two, "gloo", "3"]
+           "127.0.0.1", "--master-port", str(_free_port()), worker, two, "gloo", "3", "1"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    r = subprocess.run([sys.executable, worker, one, "gloo", "3"], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, worker, one, "gloo", "3", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     z0, z1, z = np.load(two + "_rank0.npz"), np.load(two + "_rank1.npz"), np.load(one + "_rank0.npz")
     ped = dist_iter_worker.make_ped()
@@ -111,17 +113,28 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     assert z0["bytes_moved"] < 0.5 * 3 * R * M * 48, "the exchange must stay far below the full slabs"
     for k in ("allele", "sure", "hw", "hits", "scalefactor"):
         assert np.array_equal(z0[k], z1[k], equal_nan=True), "ranks differ in " + k
-    assert np.array_equal(z0["allele"], z["allele"])
     assert np.array_equal(z0["hits"], z["hits"]) and z["hits"].sum() > 0
     assert z0["scalefactor"] == z["scalefactor"]
-    for k in ("sure", "hw"):
-        np.testing.assert_allclose(z0[k], z[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    # families 0 and 2 (12 records each, private to rank 0 and rank 1): to the bit
+    fam = np.arange(R) // 12
+    private = fam != 1
+    for k in ("allele", "sure", "hw"):
+        assert np.array_equal(z0[k][private], z[k][private], equal_nan=True), "private families differ in " + k
+    # family 1: a side whose two allele values are tied (certainty 1/2 within the bisection's tolerance) is called by the
+    # last bits of its sums in any implementation ("ill-conditioned elements"): left out
+    tie = np.abs(z["sure"] - 0.5) < 2e-3
+    assert tie[~private].mean() < 0.2
+    ok = ~tie
+    assert np.array_equal(z0["allele"][ok], z["allele"][ok])
+    np.testing.assert_allclose(z0["sure"][ok], z["sure"][ok], rtol=1e-9, atol=1e-12, err_msg="sure")
+    np.testing.assert_allclose(z0["hw"], z["hw"], rtol=1e-9, atol=1e-12, err_msg="hw")
     # haplobase / haplocount as left behind, on the rank that owns the record: a slot that is homozygous with EQUAL
     # certainties takes no part in the HAPLOS update (cnF2freq.cpp:1224-1239 compares the two certainties for equality).
     # Where the two sides of an individual collect the same evidence their certainties are equal up to the order of the
     # additions, and one ulp decides whether the slot counts: such elements are left out (their haplotype weights agree
     # all the same, see above).
     knife = (z["allele"][..., 0] == z["allele"][..., 1]) & np.isclose(z["sure"][..., 0], z["sure"][..., 1], rtol=1e-9, atol=0)
+    knife |= tie.any(axis=2)
     assert knife.sum() < 0.5 * knife.size
     for zk in (z0, z1):
         own = zk["owned"]
