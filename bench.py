@@ -120,6 +120,8 @@ def parse():
                     help="tuning aid: OR into the sweep flags (2 = CNF2_NO_DOSAGE, forward pass only); not the metric")
     ap.add_argument("--no-merge-probe", action="store_true",
                     help="skip the extra CNF2_MERGE_MODES sweeps reported next to the headline (N = 1 only)")
+    ap.add_argument("--no-iteration-probe", action="store_true",
+                    help="skip the scaled config-5 haplotyping iterations reported next to the headline (rank 0, outside the timed region)")
     ap.add_argument("--no-gather", action="store_true", help="leave the posteriors on their GPUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each step's gather before the next sweep (default: the gather of step k runs "
@@ -185,6 +187,125 @@ def generate_on_gpu(ctx, args, rank, device, pos, starts):
         if i0 == 0:
             keep = packed.cpu().numpy()   # sample for the CPU baseline leg
     return keep
+
+
+def generate_outbred_on_gpu(n_fam, kids, snps_per_chrom, n_chrom, seed, missing, device):
+    """cnf2freq_amd.synth.make_outbred3's pedigree (BASELINE config 5's shape: per family 4 genotyped grandparents, 2 genotyped
+    parents, `kids` analysed children; founder allele-2 frequency U(0.1, 0.9) per SNP; Haldane crossovers; unphased genotypes,
+    `missing` of them withheld) drawn with torch on the GPU -- the numpy generator needs ~4 ms per record x 1 000 markers --
+    and handed back as host arrays in a synth.Pedigree (with .truth, the generator's allele-2 dosages)."""
+    from cnf2freq_amd import synth
+    pos, starts = synth.make_map(n_chrom, snps_per_chrom)
+    M = len(pos)
+    per = 6 + kids
+    R = n_fam * per
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    idx = torch.arange(R, device=device)
+    fam, k = idx // per, idx % per
+    base = fam * per
+    isp, isk = (k == 4) | (k == 5), k >= 6
+    par = torch.full((R, 2), -1, dtype=torch.int64, device=device)
+    par[isp, 0] = (base + 2 * (k - 4))[isp]
+    par[isp, 1] = (base + 2 * (k - 4) + 1)[isp]
+    par[isk, 0] = (base + 4)[isk]
+    par[isk, 1] = (base + 5)[isk]
+    d = np.diff(pos, prepend=pos[0])
+    rho = 0.5 * (1.0 - np.exp(-0.02 * np.maximum(d, 0.0)))
+    rho[np.asarray(starts[:-1])] = 0.5
+    rho_t = torch.tensor(rho, dtype=torch.float32, device=device)
+    freq = 0.1 + 0.8 * torch.rand(M, generator=g, device=device)
+    hap = torch.zeros((R, M, 2), dtype=torch.uint8, device=device)
+    gp = torch.nonzero(k < 4).squeeze(1)
+    hap[gp] = (1 + (torch.rand((len(gp), M, 2), generator=g, device=device) < freq[None, :, None])).to(torch.uint8)
+    for rows in (torch.nonzero(isp).squeeze(1), torch.nonzero(isk).squeeze(1)):
+        for side in range(2):
+            rec = (torch.rand((len(rows), M), generator=g, device=device) < rho_t).to(torch.int32)
+            strand = (torch.cumsum(rec, dim=1) & 1).to(torch.int64)
+            src = hap[par[rows, side]]                                   # [n][M][2]
+            hap[rows, :, side] = torch.gather(src, 2, strand.unsqueeze(2)).squeeze(2)
+    dosage = (hap == 2).sum(dim=2).to(torch.uint8)
+    allele = torch.zeros((R + 1, M, 2), dtype=torch.uint8, device=device)
+    allele[1:, :, 0] = torch.where(dosage == 2, 2, 1).to(torch.uint8)
+    allele[1:, :, 1] = torch.where(dosage == 0, 1, 2).to(torch.uint8)
+    miss = torch.rand((R, M), generator=g, device=device) < missing
+    allele[1:][miss] = 0
+    sure = torch.where(allele != 0, 0.02, 0.0).to(torch.float64)
+    fam_l, k_l = fam.tolist(), k.tolist()
+    names = [("G%d_%d" % (f, j)) if j < 4 else ("P%d_%d" % (f, j - 4)) if j < 6 else ("K%d_%d" % (f, j - 6)) for f, j in zip(fam_l, k_l)]
+    gen = torch.where(isk, 2, torch.where(isp, 1, 0)).to(torch.int32)
+    ped = synth.Pedigree(names, par.to(torch.int32).cpu().numpy(), gen.cpu().numpy(), np.zeros(R, np.uint8),
+                         np.arange(1, R + 1, dtype=np.int32), allele.cpu().numpy(), sure.cpu().numpy(), np.full((R + 1, M), 0.5),
+                         pos, starts, torch.nonzero(isk).squeeze(1).to(torch.int32).cpu().numpy())
+    ped.founder_flags()
+    ped.truth = dosage.cpu().numpy()
+    return ped
+
+
+def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warmup=2, timed=3):
+    """BASELINE config 5's unit of work at a fifth of its size, beside the headline (outside every timed region): haplotyping
+    iterations (sweep + HOT LOOP 2 accumulators, update passes, step-size control) of a 3-generation outbred pedigree with 20 %
+    missing genotypes -- `fams` families x 4 analysed children x `chroms` x `snps_per_chrom` markers -- through libcnf2host.so,
+    the accumulate sweep in 4 batches as at full size.  Reports the iteration's rate and where its wall time goes, and the
+    kernel time of sweep + accumulators against the plain sweep of the same windows (rows f1 / f4 of SURVEY.md section 8)."""
+    import ctypes as C
+    from cnf2freq_amd import capi, host
+    t_all = time.perf_counter()
+    ped = generate_outbred_on_gpu(fams, 4, snps_per_chrom, chroms, 2, 0.2, device)
+    n, M, R = len(ped.dous), ped.n_markers, ped.n_rec
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)          # the engine prints the reference's progress lines on stdout: to stderr while it runs
+    os.dup2(2, 1)
+    try:
+        run = host.Run(ped, device=local)
+        L = capi.load()
+        ctx = run.context()
+        L.cnf2_set_batch_jobs(ctx, max(1, n * chroms // 4))
+        t0 = time.perf_counter()
+        run.postmarkerdata()
+        t_pm = time.perf_counter() - t0
+        run.reserve()
+        for _ in range(warmup):
+            run.iteration()
+        laps, acc_ms, wall = [], [], []
+        ms = np.zeros(4, np.float32)
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            run.iteration()
+            wall.append(time.perf_counter() - t0)
+            laps.append(run.timing())
+            L.cnf2_last_kernel_ms(ctx, ms.ctypes.data_as(C.c_void_p), 4)
+            acc_ms.append(float(ms[0]))
+        # the plain sweep of the same windows on the same context (device outputs)
+        f = torch.empty((n, chroms, 8), dtype=torch.float64, device=device)
+        ll = torch.empty((n, chroms), dtype=torch.float64, device=device)
+        dos = torch.empty((n, M, 3), dtype=torch.float64, device=device)
+        sweep_ms = []
+        for _ in range(2):
+            rc = L.cnf2_sweep(ctx, 0, n, C.c_void_p(f.data_ptr()), C.c_void_p(ll.data_ptr()), C.c_void_p(dos.data_ptr()), capi.OUT_DEVICE)
+            if rc != 0:
+                raise RuntimeError(L.cnf2_last_error(ctx).decode())
+            L.cnf2_sync(ctx)
+            L.cnf2_last_kernel_ms(ctx, ms.ctypes.data_as(C.c_void_p), 4)
+            sweep_ms.append(float(ms[0]))
+        st = run.state()
+        run.close()
+    finally:
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    mean = lambda k: float(np.mean([l[k] for l in laps]))
+    it_s = float(np.mean(wall))
+    return {"workload": "3-generation outbred pedigree, %d families = %d individuals, %d analysed, 20%% of genotypes missing, "
+                        "%d chromosomes x %d SNPs (+1 dummy each): BASELINE config 5 at %d/2500 of its families"
+                        % (fams, R, n, chroms, snps_per_chrom, fams),
+            "iterations_timed": timed, "warmup": warmup, "iteration_s": it_s, "units_per_s": float(n) * M / it_s,
+            "sweep_accumulate_s": mean("sweep_accumulate_s"), "update_s": mean("update_s"), "host_s": mean("host_s"),
+            "sweep_accumulate_kernel_ms": float(np.mean(acc_ms)), "plain_sweep_kernel_ms": float(min(sweep_ms)),
+            "accumulate_over_sweep": float(np.mean(acc_ms)) / float(min(sweep_ms)),
+            "postmarkerdata_s": t_pm, "scalefactor": st["scalefactor"], "last_hits": st["hits"],
+            "probe_wall_s": time.perf_counter() - t_all}
 
 
 def host_cpu_share():
@@ -705,6 +826,16 @@ def main():
             except Exception as e:  # the baseline must never take the GPU line down
                 out["cpu_baseline"] = {"value": None, "unit": "individual*marker/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if not args.no_iteration_probe:
+            # the other unit of work of the path (BASELINE config 5: whole haplotyping iterations) into the driver-observed
+            # line; the headline's context is closed first so that the probe sees the memory a run of its own would
+            ctx.close()
+            del dosages, logliks, dosage, loglik, factors
+            torch.cuda.empty_cache()
+            try:
+                out["iteration_probe"] = iteration_probe(local, device)
+            except Exception as e:
+                out["iteration_probe"] = {"failed": repr(e)}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -38,9 +38,14 @@ void Engine::upload()
     children_.assign(P.inds.size(), 0);
     variances_.assign(P.inds.size() * (size_t)M, 0.0);
     lockstart_.assign(P.inds.size() * (size_t)(C > 0 ? C : 1), 0);
-    // the device buffers of the iterations now, not inside the first one (the batch buffer of the accumulate sweep is up to
-    // half of the free memory; its first hipMalloc takes seconds)
-    if (opt.update && N > 0) check(cnf2_reserve_accumulate(ctx, 0, N, 0), "cnf2_reserve_accumulate");
+}
+
+// the device buffers of the iterations now, not inside the first one (the batch buffer of the accumulate sweep is up to half of
+// the free memory; its first hipMalloc takes seconds).  Optional: an iteration allocates what it finds missing.
+void Engine::reserve()
+{
+    const int b0 = block_end_ < 0 ? 0 : block_begin_, b1 = block_end_ < 0 ? N : block_end_;
+    if (opt.update && b1 > b0) check(cnf2_reserve_accumulate(ctx, b0, b1, deterministic_ ? CNF2_DETERMINISTIC : 0), "cnf2_reserve_accumulate");
 }
 
 // rows travel in slabs of records: the staging copy stays bounded (config 4: 300 000 records x 200 080 markers would be
@@ -527,10 +532,16 @@ void Engine::iteration(FILE* out)
     // CNF2_TIMING=1: wall-clock of the steps of an iteration on stderr (tuning aid)
     const bool timing = getenv("CNF2_TIMING") != nullptr;
     auto       t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "  [iteration] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    // where the wall time of the iteration went (last_timing): [0] sweep + accumulators, [1] exchanges, [2] update passes,
+    // [3] everything else on the host (bookkeeping, likelihood lines, rows), [4] total
+    for (double& t : last_timing_) t = 0.0;
+    const auto t_start = t_prev;
+    auto lap = [&](const char* what, int slot = 3) {
+        const auto   now = std::chrono::steady_clock::now();
+        const double dt = std::chrono::duration<double>(now - t_prev).count();
+        last_timing_[slot] += dt;
+        last_timing_[4] = std::chrono::duration<double>(now - t_start).count();
+        if (timing) fprintf(stderr, "  [iteration] %-28s %.3f s\n", what, dt);
         t_prev = now;
     };
     const int R = (int)P.inds.size();
@@ -546,6 +557,7 @@ void Engine::iteration(FILE* out)
     const int b0 = block_end_ < 0 ? 0 : block_begin_, b1 = block_end_ < 0 ? N : block_end_, nb = b1 - b0;
     std::vector<double> factors((size_t)nb * C * 8), loglik((size_t)nb * C), dosage(opt.print_rows ? (size_t)nb * M * 3 : 0);
     const uint32_t rowflag = (opt.normalise ? 0 : CNF2_RAW_DOSAGE) | (deterministic_ ? CNF2_DETERMINISTIC : 0);
+    lap("children, descendants");
     if (N > 0) {
         if (opt.update)
             check(cnf2_sweep_accumulate(ctx, b0, b1, desc.data(), factors.data(), loglik.data(),
@@ -561,7 +573,7 @@ void Engine::iteration(FILE* out)
                              (opt.merge_modes ? CNF2_MERGE_MODES : 0) | rowflag),
                   "cnf2_sweep");
     }
-    lap("sweep + accumulators");
+    lap("sweep + accumulators", 0);
     const bool multi = part_.world > 1 && exchange_ != nullptr;
     const size_t S = cnf2_packed_accumulator_doubles(ctx), B = cnf2_packed_row_bytes(ctx);
     if (opt.update && N > 0 && multi && part_.seg_shared > 0) {
@@ -577,14 +589,18 @@ void Engine::iteration(FILE* out)
         check(cnf2_unpack_accumulators(ctx, part_.shared_of[part_.rank].data(), (int)part_.shared_of[part_.rank].size(),
                                        q + (size_t)part_.rank * part_.seg_shared * S),
               "cnf2_unpack_accumulators");
-        lap("exchange of the accumulators");
+        lap("exchange of the accumulators", 1);
     }
     pass_hits_.assign(C, 0);
+    std::vector<int32_t> wtab;                  // shiftignore / flag2ignore of every window for the likelihood lines: one call
+    if (!opt.quiet && N > 0) {
+        wtab.resize((size_t)N * 17);
+        check(cnf2_window_table(ctx, wtab.data()), "cnf2_window_table");
+    }
     for (int c = 0; c < C; c++) {
         if (!opt.quiet)
             for (int j = 0; j < nb; j++) {
-                int32_t w[17];
-                check(cnf2_window_info(ctx, b0 + j, w), "cnf2_window_info");
+                const int32_t* w = &wtab[(size_t)(b0 + j) * 17];
                 double mx = -1e15;               // the two printf of cnF2freq.cpp:5399-5401
                 for (int s = 0; s < 8; s++) mx = std::max(mx, factors[((size_t)j * C + c) * 8 + s]);
                 printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[b0 + j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
@@ -636,7 +652,7 @@ void Engine::iteration(FILE* out)
         last_hits_ = hits;
         pass_hits_[c] = hits;
         fprintf(stdout, "Scale factor now %lf, entropy %lf, hitnnn %d\n", scalefactor_, entropyfactor_, oldhits_);
-        lap("update pass");
+        lap("update pass", 2);
     }
     if (opt.update && N > 0 && multi) {
         // the new rows of the shared records from their owners to everybody (their next sweep reads them); the private
@@ -653,7 +669,7 @@ void Engine::iteration(FILE* out)
                 if (k != part_.rank)
                     check(cnf2_unpack_rows(ctx, part_.shared_of[k].data(), (int)part_.shared_of[k].size(), q + (size_t)k * part_.seg_shared * B),
                           "cnf2_unpack_rows");
-            lap("exchange of the shared rows");
+            lap("exchange of the shared rows", 1);
         }
         rows_partial_ = true;
     }

@@ -59,6 +59,11 @@ public:
 
     // tables -> device; remembers the rows as priors (cnF2freq.cpp:6664-6665).  Call once after the readers.
     void upload();
+    // allocates the device buffers of the iterations (of this process's block) now instead of inside the first iteration
+    void reserve();
+    // wall time of the last iteration by where it went: [0] sweep + accumulators, [1] exchanges, [2] update passes, [3] the rest
+    // on the host (bookkeeping, likelihood lines, rows), [4] total; seconds
+    const double* last_timing() const { return last_timing_; }
     // cnF2freq.cpp:3190-3412 as main calls it (CORRECTIONINFERENCE set), for individuals numbered below indcount
     void postmarkerdata(int indcount);
     // cnF2freq.cpp:7757-7832; returns false if the file cannot be opened
@@ -130,6 +135,7 @@ private:
     void       exchange(int op, void* buf, size_t count, size_t seg, const char* what);
     void       gather_private_rows();
     std::vector<int> pass_hits_;
+    double last_timing_[5] = {0, 0, 0, 0, 0};
 };
 
 }  // namespace cnf2host

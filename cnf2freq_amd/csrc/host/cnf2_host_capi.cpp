@@ -205,6 +205,19 @@ int cnf2h_get_partition(cnf2h_run* run, int64_t* info10, int32_t* owned)
     return 0;
 }
 
+int cnf2h_reserve(cnf2h_run* run)
+{
+    if (!run) return -2;
+    return guarded([&] { run->E->reserve(); });
+}
+
+int cnf2h_get_timing(cnf2h_run* run, double* out5)
+{
+    if (!run || !out5) return -2;
+    std::copy(run->E->last_timing(), run->E->last_timing() + 5, out5);
+    return 0;
+}
+
 int cnf2h_set_update_flags(cnf2h_run* run, uint32_t flags)
 {
     if (!run) return -2;

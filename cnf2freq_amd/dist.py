@@ -218,6 +218,7 @@ def start_iterations(ped, device=0, has_prior=None, postmarkerdata=True, determi
     run.block = run.plan["block"]
     if deterministic:
         run.set_deterministic(True)
+    run.reserve()                       # the rank's batch buffers now, not inside its first iteration
     return run
 
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnf2host.so")
 
 SYMBOLS = ["cnf2h_create", "cnf2h_create_on", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration",
-           "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_partition", "cnf2h_get_partition", "cnf2h_set_update_flags",
+           "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_partition", "cnf2h_get_partition", "cnf2h_set_update_flags", "cnf2h_reserve", "cnf2h_get_timing",
            "cnf2h_set_deterministic", "cnf2h_context", "cnf2h_get_passes"]
 
 # int fn(void *user, int op, void *buf, size_t count, size_t seg) -- the transport of a multi-process run (cnf2host.h)
@@ -36,6 +36,8 @@ def load():
         L.cnf2h_set_partition.argtypes = [vp, i32, i32, EXCHANGE_FN, vp]
         L.cnf2h_get_partition.argtypes = [vp, vp, vp]
         L.cnf2h_set_update_flags.argtypes = [vp, C.c_uint32]
+        L.cnf2h_reserve.argtypes = [vp]
+        L.cnf2h_get_timing.argtypes = [vp, vp]
         L.cnf2h_set_deterministic.argtypes = [vp, i32]
         L.cnf2h_context.argtypes = [vp]
         L.cnf2h_context.restype = vp
@@ -62,7 +64,10 @@ class Run:
 
     def __init__(self, ped, has_prior=None, quiet=True, device=0):
         self.L = load()
-        a, s, h = ped.dense()
+        if np.array_equal(ped.row_of, np.arange(1, ped.n_rec + 1)):
+            a, s, h = ped.allele[1:], ped.sure[1:], ped.hw[1:]       # one row per record already: no copies (bench-scale inputs)
+        else:
+            a, s, h = ped.dense()
         self.n_rec, self.M = ped.n_rec, ped.n_markers
         hp = (1 - np.asarray(ped.empty)).astype(np.uint8) if has_prior is None else np.ascontiguousarray(has_prior, np.uint8)
         args = [np.ascontiguousarray(ped.par, np.int32), np.ascontiguousarray(ped.empty, np.uint8),
@@ -130,6 +135,16 @@ class Run:
         return dict(block=(int(info[0]), int(info[1])), owned=owned, n_shared=int(info[3]), segment_records=int(info[4]),
                     bytes_accumulators=int(info[5]), bytes_rows=int(info[6]), bytes_hits=int(info[7]), bytes_payload=int(info[8]),
                     n_private=int(info[9]))
+
+    def reserve(self):
+        """The device buffers of the iterations now, not inside the first one (optional)."""
+        self._chk(self.L.cnf2h_reserve(self.h), "cnf2h_reserve")
+
+    def timing(self):
+        """Wall time of the last iteration by where it went (seconds)."""
+        t = np.zeros(5)
+        self._chk(self.L.cnf2h_get_timing(self.h, _p(t)), "cnf2h_get_timing")
+        return dict(sweep_accumulate_s=float(t[0]), exchange_s=float(t[1]), update_s=float(t[2]), host_s=float(t[3]), total_s=float(t[4]))
 
     def set_update_flags(self, flags):
         """capi.UPDATE_BOTH_FLOWS (bit-exact fast form), capi.UPDATE_PLAIN (literal kernels), capi.UPDATE_ONE_SCOUT; 0 = default."""

@@ -38,6 +38,12 @@ int cnf2h_postmarkerdata(cnf2h_run *run, int indcount);
 /* one doit<false, genotypereporter> (cnF2freq.cpp:8132): rows and pass lines appended to rows_path (NULL: not formatted at all);
  * update = 0 sweeps without the parameter updates */
 int cnf2h_iteration(cnf2h_run *run, const char *rows_path, int update);
+/* allocates the device buffers of the iterations now (the batch buffer of the accumulate sweep is up to half of the free
+ * memory: a first hipMalloc of that size takes seconds) instead of inside the first iteration; optional */
+int cnf2h_reserve(cnf2h_run *run);
+/* wall time of the last cnf2h_iteration by where it went, seconds: out5[0] sweep + accumulators, [1] exchanges (multi-process),
+ * [2] update passes, [3] the rest on the host (bookkeeping, likelihood lines, rows), [4] total */
+int cnf2h_get_timing(cnf2h_run *run, double *out5);
 /* Multi-process runs (the reference's dead MPI code: partition cnF2freq.cpp:5297-5299, reduce
  * 6245-6254, updates on the reduced values 6344-6392).  Every rank holds the whole pedigree (ancestors' rows replicated)
  * and runs the same postmarkerdata.  cnf2h_set_partition(rank, world, transport) plans the run -- the same plan on every
