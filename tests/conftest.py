@@ -15,6 +15,10 @@ GOLDEN_CASES = ["f2_implicit_f1", "outbred3_missing", "random_windows", "f2_unge
 
 # G13: trajectories (tests/golden/traj_<case>.npz): the four fixtures, a two-chromosome pedigree, tied windows
 TRAJ_CASES = GOLDEN_CASES + ["outbred3_two_chrom", "ail_ties"]
+# ... and the 10-iteration run (40 analysed x 2 x 100 markers) that takes the step-size control through its "good" and "bad"
+# branches (cnF2freq.cpp:6373-6392): compared with the product on the GPU only -- the CPU restatement of HOT LOOP 2 is
+# quadratic in the chromosome length (it re-sweeps per marker) and would need the better part of an hour for it
+TRAJ_CASES_LONG = ["outbred3_long"]
 
 
 def pytest_configure(config):
@@ -72,6 +76,7 @@ class TrajectoryChecker:
         self.ped, self.z = ped, z
         self.comp = pedigree_components(ped)
         self.tainted = np.zeros(ped.n_rec, bool)
+        self.log = []          # per iteration: (k, records compared, records in all, hit counters and scale factor compared)
 
     def check(self, k, st, rtol=1e-9, atol=1e-12, exact_hits=True):
         z = self.z
@@ -99,7 +104,17 @@ class TrajectoryChecker:
                 np.testing.assert_allclose(np.asarray(st[key])[keep], z["it%d_%s" % (k, key)][keep],
                                            rtol=max(rtol, 1e-8) if key == "haplobase" else rtol, atol=atol,
                                            err_msg="%s after iteration %d" % (key, k))
+        self.log.append((k, int(ok.sum()), int(len(ok)), not self.tainted.any()))
         return int(ok.sum())
+
+    def report(self, case, path=None):
+        """One line per case: how much of the pedigree was really compared after every iteration."""
+        line = "%s: " % case + ", ".join("it%d %d/%d%s" % (k, c, n, "" if full else " (hits not compared)") for k, c, n, full in self.log)
+        if path:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "a") as f:
+                f.write(line + "\n")
+        return line
 
 
 def oracle_ped(ped):

@@ -180,7 +180,13 @@ TRAJ_CASES["outbred3_two_chrom"] = (synth.make_outbred3, dict(n_fam=2, kids_per_
 # windows with tie groups (an ancestor in two slots), 3 analysed generations
 TRAJ_CASES["ail_ties"] = (synth.make_ail, dict(n_f1=4, n_per_gen=6, n_gen=3, markers_per_chrom=7, n_chrom=1, seed=5,
                                                chrom_cm=20.0, missing=0.05))
+# the step-size control (cnF2freq.cpp:6373-6392) over a longer run: 10 families x 4 analysed children, two chromosomes of
+# 100 markers, 10 iterations -- the scale factor grows ("good": fewer capped moves than the floor of N / 7) and shrinks
+# ("bad": more than in both previous passes) along the way.  Takes ~20 minutes of the reference's own update code.
+TRAJ_CASES["outbred3_long"] = (synth.make_outbred3, dict(n_fam=10, kids_per_fam=4, markers_per_chrom=100, n_chrom=2, seed=17,
+                                                         missing=0.05))
 TRAJ_ITERATIONS = 3
+TRAJ_ITERATIONS_OF = {"outbred3_long": 10}
 
 
 def traj_ped(name):
@@ -197,7 +203,8 @@ def generate_trajectory(name):
     out = {"in_" + k: v for k, v in ped_inputs(ped).items()}
     out.update(pm_allele=pm["allele"].astype(np.uint8), pm_sure=pm["sure"], pm_hw=pm["hw"],
                pm_descendants=pm["descendants"])
-    for k in range(1, TRAJ_ITERATIONS + 1):
+    n_iter = TRAJ_ITERATIONS_OF.get(name, TRAJ_ITERATIONS)
+    for k in range(1, n_iter + 1):
         st = R.iteration()
         out["it%d_allele" % k] = st["allele"].astype(np.uint8)
         for key in ("sure", "hw", "haplobase", "haplocount", "hits", "unstable"):
@@ -206,7 +213,8 @@ def generate_trajectory(name):
     path = os.path.join(os.path.dirname(__file__), "traj_" + name + ".npz")
     np.savez_compressed(path, **out)
     print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024), "hits",
-          [list(out["it%d_hits" % k]) for k in range(1, TRAJ_ITERATIONS + 1)])
+          [list(out["it%d_hits" % k]) for k in range(1, n_iter + 1)], "scale factors",
+          [float(out["it%d_scalefactor" % k]) for k in range(1, n_iter + 1)])
 
 
 def generate_update_units(seed=20261004):
@@ -324,5 +332,8 @@ if __name__ == "__main__":
     if "traj" in what:
         for name in TRAJ_CASES:
             generate_trajectory(name)
+    for name in what:                      # single trajectories by name: python make_golden.py traj:outbred3_long
+        if name.startswith("traj:"):
+            generate_trajectory(name[5:])
     if "units" in what:
         generate_update_units()

@@ -933,6 +933,49 @@ def test_sparse_rescaling_guard_on_data_that_loses_many_decades(capi):
     ctx.close()
 
 
+def test_states_the_reference_flushes_below_1e300_are_carried_here_without_effect(capi):
+    """Known deviation, bounded: adjustprobs sets a state whose normalised probability has fallen below 1e-300 to exactly 0
+    before it evaluates the emission (cnF2freq.cpp:1607-1611); the kernels carry such a value on (it is 1e-300 of the
+    vector: nothing of it reaches a double's 16 digits).  Adversarial but valid data that puts states into that band: a
+    stretch of markers at ONE map position (no transition between them, cnF2freq.cpp:2273, so nothing leaks back into a
+    state) at which a nearly phase-locked heterozygous parent and a homozygous child make the states that inherit the
+    parent's other strand lose a factor 2e-3 per marker -- (2e-3)^112 = 5e-303 -- followed by ordinary markers.  Likelihoods
+    and rows must still equal the oracle's (which applies the rule, bit-exact on the reference extract).  What is NOT
+    reproduced: data under which every OTHER state then becomes exactly impossible -- the reference
+    declares the individual impossible (MINFACTOR), the kernels return the likelihood of the 1e-303 state."""
+    ped = synth.make_outbred3(1, 2, 150, 1, seed=9, missing=0.0, chrom_cm=30.0)
+    ped.allele, ped.sure, ped.hw, ped.pos = ped.allele.copy(), ped.sure.copy(), ped.hw.copy(), ped.pos.copy()
+    kid = int(ped.dous[0])
+    p0, p1 = int(ped.par[kid, 0]), int(ped.par[kid, 1])
+    lo, hi = 10, 122                                        # 112 markers on one position
+    ped.pos[lo:hi] = ped.pos[lo]
+    for r, al in ((kid, (1, 1)), (p0, (1, 2)), (p1, (1, 1))):
+        ped.allele[ped.row_of[r], lo:hi] = al
+        ped.sure[ped.row_of[r], lo:hi] = 1e-3
+    ped.hw[ped.row_of[p0], lo:hi] = 0.999                   # strand 0 of the parent carries allele 1, almost surely
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    want = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    # the fixture does what it is built for: in the reference-layout store the smallest non-zero forward value of the
+    # stretch's end is far below anything a sum of 64 states resolves, and some states are below 1e-300
+    fw, _ = ctx.fwbw_store(0, 0)
+    end = fw[:, hi - 1, 0, :]
+    live = end[end > 0]
+    assert live.min() < 1e-290 or (end == 0).any(), "no state came near the reference's 1e-300 threshold: %g" % live.min()
+    np.testing.assert_allclose(got["factors"][:, 0], want["factors"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(got["loglik"][:, 0], want["factor"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-6, atol=1e-10)
+    # ... and through the accumulate mode (HOT LOOP 2 sees the same vectors)
+    desc = ctx.descendants()
+    acc = ctx.sweep_accumulate(desc)
+    ref = o.accumulate(ped.dous, ped.gen[ped.dous], desc)
+    for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
+        np.testing.assert_allclose(acc[k], ref[k], rtol=1e-6, atol=1e-10, equal_nan=True, err_msg=k)
+    ctx.close()
+
+
 def _four_founder_pedigree(n_kids, M, seed, empty_f1=True, empty_gp=False):
     """n_kids analysed children of two F1 parents with four distinct, heterozygous grandparents (no ancestor in two
     slots: no tie group).  empty_f1: the parents have no data (homozygous-everywhere blank rows); empty_gp: one
