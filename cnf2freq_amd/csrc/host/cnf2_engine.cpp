@@ -24,10 +24,27 @@ void Engine::upload()
     C = (int)P.chromstarts.size() - 1;
     // one row per individual (row 0 stays the blank row): the updates write rows in place, and postmarkerdata locks a
     // haplotype weight even in individuals without data, so rows cannot be shared the way a single sweep allows
-    build_tables(P, T, false);
+    // (the pedigree tables only; the rows go up in slabs straight from the individuals -- no second copy of every row on the
+    // host, which at config 4 would be half a terabyte)
+    const int R0 = (int)P.inds.size();
+    T = Tables();
+    T.par.assign((size_t)R0 * 2, -1);
+    T.gen.assign(R0, 0);
+    T.empty.assign(R0, 0);
+    T.row_of.assign(R0, 0);
+    T.dous.assign(P.dous.begin(), P.dous.end());
+    for (int r = 0; r < R0; r++) {
+        T.par[(size_t)r * 2]     = P.inds[r].pars[0];
+        T.par[(size_t)r * 2 + 1] = P.inds[r].pars[1];
+        T.gen[r]                 = P.inds[r].gen;
+        T.empty[r]               = P.inds[r].empty ? 1 : 0;
+        T.row_of[r]              = r + 1;
+    }
+    T.n_rows = R0 + 1;
     N = (int)T.dous.size();
     check(cnf2_upload_map(ctx, P.pos.data(), M, P.chromstarts.data(), C, nullptr), "cnf2_upload_map");
-    check(cnf2_upload_rows(ctx, T.n_rows, T.allele.data(), T.sure.data(), T.hw.data()), "cnf2_upload_rows");
+    check(cnf2_upload_rows(ctx, T.n_rows, nullptr, nullptr, nullptr), "cnf2_upload_rows");       // blank rows (row 0 stays blank)
+    push_rows();
     check(cnf2_upload_pedigree(ctx, (int)P.inds.size(), T.par.data(), T.empty.data(), T.gen.data(), T.row_of.data(),
                                T.dous.data(), N),
           "cnf2_upload_pedigree");
@@ -61,6 +78,7 @@ void Engine::push_rows()
     std::vector<double>  sure((size_t)std::min(R, slab) * M * 2), hw((size_t)std::min(R, slab) * M);
     for (int r0 = 0; r0 < R; r0 += slab) {
         const int k = std::min(slab, R - r0);
+#pragma omp parallel for schedule(static)
         for (int r = 0; r < k; r++) {
             const Individual& I = P.inds[r0 + r];
             std::copy(I.allele.begin(), I.allele.end(), allele.begin() + (size_t)r * M * 2);
@@ -82,6 +100,7 @@ void Engine::pull_rows()
     for (int r0 = 0; r0 < R; r0 += slab) {
         const int k = std::min(slab, R - r0);
         check(cnf2_download_rows(ctx, 1 + r0, k, allele.data(), sure.data(), hw.data()), "cnf2_download_rows");
+#pragma omp parallel for schedule(static)
         for (int r = 0; r < k; r++) {
             Individual& I = P.inds[r0 + r];
             std::copy(allele.begin() + (size_t)r * M * 2, allele.begin() + (size_t)(r + 1) * M * 2, I.allele.begin());
@@ -282,16 +301,25 @@ void Engine::postmarkerdata(int indcount)
     do {
         for (int r : recs) children_[r] = 0;
         // fixkid (cnF2freq.cpp:1470-1487): a child without a genotype takes the allele of a homozygous parent
-        for (int r : recs) {
-            Individual& I = P.inds[r];
-            for (int g = 0; g < M; g++) {
-                if (I.allele[g * 2] != UNKNOWN || I.allele[g * 2 + 1] != UNKNOWN) continue;
-                for (int p = 0; p < 2; p++) {
-                    if (I.pars[p] < 0) continue;
-                    const Individual& Q = P.inds[I.pars[p]];
-                    if (Q.allele[g * 2] == UNKNOWN || Q.allele[g * 2] != Q.allele[g * 2 + 1]) continue;
-                    I.allele[g * 2 + p] = Q.allele[g * 2];
-                    I.sure[g * 2 + p]   = 0.5;
+        // (markers do not see each other: blocks of markers in parallel, the records in ascending order inside a block --
+        // the order in which a parent filled in by its own fixkid is seen by its children stays the sequential one)
+        {
+            const int blk = 512, nblk = (M + blk - 1) / blk;
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int b = 0; b < nblk; b++) {
+                const int g0 = b * blk, g1 = std::min(M, g0 + blk);
+                for (int r : recs) {
+                    Individual& I = P.inds[r];
+                    for (int g = g0; g < g1; g++) {
+                        if (I.allele[g * 2] != UNKNOWN || I.allele[g * 2 + 1] != UNKNOWN) continue;
+                        for (int p = 0; p < 2; p++) {
+                            if (I.pars[p] < 0) continue;
+                            const Individual& Q = P.inds[I.pars[p]];
+                            if (Q.allele[g * 2] == UNKNOWN || Q.allele[g * 2] != Q.allele[g * 2 + 1]) continue;
+                            I.allele[g * 2 + p] = Q.allele[g * 2];
+                            I.sure[g * 2 + p]   = 0.5;
+                        }
+                    }
                 }
             }
         }
@@ -375,7 +403,15 @@ void Engine::postmarkerdata(int indcount)
         anyrem = 0;
         struct Fix { int r, g; uint8_t a0, a1; double s0, s1; };
         std::vector<Fix> fixes;
-        for (int r : recs) {
+        // every (record, marker) reads the frozen state only: records in parallel, each thread's corrections appended in
+        // record order afterwards (the messages of a run that is not quiet keep their order by running it on one thread)
+        std::vector<std::vector<Fix>> fixes_of(recs.size());
+        int any_sum = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : any_sum) if (opt.quiet)
+        for (size_t q_ = 0; q_ < recs.size(); q_++) {
+            const int r = recs[q_];
+            std::vector<Fix>& fixes = fixes_of[q_];
+            int& any = any_sum;
             Individual& I = P.inds[r];
             for (int g = 0; g < M; g++) {
                 const int known = (I.allele[g * 2] != UNKNOWN) + (I.allele[g * 2 + 1] != UNKNOWN);
@@ -409,6 +445,11 @@ void Engine::postmarkerdata(int indcount)
                         printf("Correction at %d, marker %d (%d;%d) (%lf;%lf)\n", I.n, g, fx.a0, fx.a1, fx.s0, fx.s1);
                 }
             }
+        }
+        any = any_sum;
+        for (auto& v : fixes_of) {
+            fixes.insert(fixes.end(), v.begin(), v.end());
+            std::vector<Fix>().swap(v);
         }
         for (const Fix& fx : fixes) {
             Individual& I = P.inds[fx.r];

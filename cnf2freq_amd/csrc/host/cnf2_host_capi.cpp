@@ -61,6 +61,7 @@ cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint
     P.chromstarts.assign(chromstarts, chromstarts + n_chrom + 1);
     P.index["0"] = -1;
     const size_t M = (size_t)n_markers;
+    P.inds.reserve(n_rec);
     for (int r = 0; r < n_rec; r++) {
         Individual I;
         I.n = r + 1;
@@ -78,7 +79,7 @@ cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint
             I.prior_sure = I.sure;
         }
         P.index[I.name] = r;
-        P.inds.push_back(I);
+        P.inds.push_back(std::move(I));
     }
     P.dous.assign(dous, dous + n_dous);
     if (cnf2_ctx_create(device, &run->ctx) != CNF2_OK) {

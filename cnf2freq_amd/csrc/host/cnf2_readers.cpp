@@ -233,6 +233,11 @@ void build_tables(const Pedigree& P, Tables& T, bool share_blank)
     T.sure.assign(M * 2, 0.0);
     T.hw.assign(M, 0.5);
     T.n_rows = 1;
+    if (!share_blank) {                      // every individual gets a row: no reallocation while they are appended
+        T.allele.reserve(((size_t)R + 1) * M * 2);
+        T.sure.reserve(((size_t)R + 1) * M * 2);
+        T.hw.reserve(((size_t)R + 1) * M);
+    }
     for (int r = 0; r < R; r++) {
         const Individual& I = P.inds[r];
         T.par[r * 2]     = I.pars[0];
