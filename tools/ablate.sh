@@ -3,7 +3,7 @@
 # kernel compiled out (-DCNF2_X_*), so its results are wrong and only kernel_ms means anything.
 # usage (GPU box): bash tools/ablate.sh NOLOAD NOSTORE NOMEM
 for v in "$@"; do
-    CNF2HIP_LIB=$PWD/cnf2freq_amd/libcnf2hip_x_$v.so timeout -k 10 150 python bench.py --steps 2 --warmup 1 --cpu-seconds 0 \
+    CNF2HIP_LIB=$PWD/cnf2freq_amd/libcnf2hip_x_$v.so timeout -k 10 150 python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe \
         > gpurun_out/ablate_$v.log 2>&1 || { echo "$v failed"; tail -3 gpurun_out/ablate_$v.log; continue; }
     python - "$v" <<'PY'
 import json, sys

@@ -1,3 +1,5 @@
+"""Diagnosis aid (GPU box): tests/dist_iter_worker.py with 2 ranks and with 1, after 1, 2 and 3 iterations: which elements of
+the state differ, in which records, and which rank owns them.  usage: python tools/diag_two_rank.py"""
 import os, sys, subprocess, socket
 import numpy as np
 ROOT="/root/repo"

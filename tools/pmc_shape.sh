@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$wl$i -- \
-        python3 $R/bench.py --workload $wl --inds 2000 --steps 1 --warmup 0 --cpu-seconds 0 --no-merge-probe > $out/$wl$i.log 2>&1 || echo "pass failed"
+        python3 $R/bench.py --workload $wl --inds 2000 --steps 1 --warmup 0 --cpu-seconds 0 --no-iteration-probe --no-merge-probe > $out/$wl$i.log 2>&1 || echo "pass failed"
 done
 done
 for wl in ${PMC_WORKLOADS:-f2 outbred}; do

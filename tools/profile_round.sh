@@ -10,10 +10,10 @@ out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- \
-    python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $out/stats.log 2>&1 || echo "stats pass failed"
+    python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe > $out/stats.log 2>&1 || echo "stats pass failed"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -- \
-        python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $out/$c.log 2>&1 || echo "$c pass failed"
+        python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe > $out/$c.log 2>&1 || echo "$c pass failed"
 done
 python3 - "$out" "$tag" "$R" <<'PY'
 import csv, glob, hashlib, json, os, sys
@@ -52,7 +52,7 @@ json.dump({"inds": inds, "markers": markers, "kernel": "cnf2::fb_fast_kernel<tru
            "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb,
            "bytes_per_unit": (fb + wb) / (inds * markers), "algorithmic_bytes_per_unit": 8248,
            "rocprof_kernel_avg_ms": avg_ms,
-           "source": "tools/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0" % tag},
+           "source": "tools/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe" % tag},
           open("%s/%s_hbm_traffic.json" % (out, tag), "w"), indent=1)
 print("kernel avg ms", avg_ms, "bytes/unit", (fb + wb) / (inds * markers))
 PY
@@ -63,7 +63,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT"; do
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/sq$i -- \
-        python3 $R/bench.py --inds 2000 --steps 1 --warmup 0 --cpu-seconds 0 > $out/sq$i.log 2>&1 || echo "sq pass $i failed"
+        python3 $R/bench.py --inds 2000 --steps 1 --warmup 0 --cpu-seconds 0 --no-iteration-probe > $out/sq$i.log 2>&1 || echo "sq pass $i failed"
 done
 python3 $R/profiles/pmc_summarize.py $out/sq1 $out/sq2 $out/sq3 $out/sq4 --units $((2000*50020)) --kernel fb_fast \
     > $out/${tag}_pmc_sq_summary_2000inds.txt

@@ -7,8 +7,8 @@ o=$R/gpurun_out/ev_$tag
 mkdir -p $o
 cd $R
 timeout -k 10 300 python bench.py > $o/${tag}_bench_f2.json.log 2> $o/bench_f2.err; echo "f2 exit $?"
-timeout -k 10 300 python bench.py --workload ail --cpu-seconds 0 > $o/${tag}_bench_ail.json.log 2> $o/bench_ail.err; echo "ail exit $?"
-timeout -k 10 300 python bench.py --workload outbred --cpu-seconds 0 > $o/${tag}_bench_outbred.json.log 2> $o/bench_outbred.err; echo "outbred exit $?"
+timeout -k 10 300 python bench.py --workload ail --cpu-seconds 0 --no-iteration-probe > $o/${tag}_bench_ail.json.log 2> $o/bench_ail.err; echo "ail exit $?"
+timeout -k 10 300 python bench.py --workload outbred --cpu-seconds 0 --no-iteration-probe > $o/${tag}_bench_outbred.json.log 2> $o/bench_outbred.err; echo "outbred exit $?"
 timeout -k 10 400 python bench.py --workload outbred --iterations 5 --warmup 2 > $o/${tag}_bench_iterations_outbred.json.log 2> $o/bench_iter.err; echo "iterations exit $?"
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --backend gloo --single-device --workload outbred --iterations 3 --warmup 1 --inds 2000 \

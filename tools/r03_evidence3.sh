@@ -13,8 +13,8 @@ bash tools/pmc_turn.sh $tag > $o/pmc_turn.log 2>&1
 cd $R
 timeout -k 10 100 python tools/turn_timing.py 250 2500 2 1000 3 lse valu > $o/${tag}_turn_timing_valu_form.log 2>&1
 timeout -k 10 300 python bench.py > $o/${tag}_bench_f2.json.log 2> $o/bench_f2.err; echo "f2 exit $?"
-timeout -k 10 300 python bench.py --workload ail --cpu-seconds 0 > $o/${tag}_bench_ail.json.log 2> $o/bench_ail.err; echo "ail exit $?"
-timeout -k 10 300 python bench.py --workload outbred --cpu-seconds 0 > $o/${tag}_bench_outbred.json.log 2> $o/bench_outbred.err; echo "outbred exit $?"
+timeout -k 10 300 python bench.py --workload ail --cpu-seconds 0 --no-iteration-probe > $o/${tag}_bench_ail.json.log 2> $o/bench_ail.err; echo "ail exit $?"
+timeout -k 10 300 python bench.py --workload outbred --cpu-seconds 0 --no-iteration-probe > $o/${tag}_bench_outbred.json.log 2> $o/bench_outbred.err; echo "outbred exit $?"
 timeout -k 10 300 python tools/iter_timing.py 2500 2500 4 2 0.013 flow det > $o/${tag}_iter_timing_config5_deterministic.log 2>&1; echo "det exit $?"
 grep "^iteration\|^reserve" $o/${tag}_iter_timing_config5_deterministic.log
 timeout -k 10 300 python tools/iter_timing.py 2500 2500 4 2 0.013 > $o/${tag}_iter_timing_config5.log 2>&1; echo "iter exit $?"
