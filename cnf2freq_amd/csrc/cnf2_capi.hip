@@ -359,10 +359,14 @@ static int blank_rows(cnf2_ctx* ctx)
     HIP_TRY(ctx, hipMemset(ctx->d_allele8, 0, cnt));
     HIP_TRY(ctx, hipMemset(ctx->d_sure, 0, cnt * sizeof(double2)));
     // haploweight of an individual without data is 0.5 (getind, cnF2freq.cpp:2491)
-    std::vector<double> half((size_t)ctx->n_markers, 0.5);
-    for (int r = 0; r < ctx->n_rows; r++)
-        HIP_TRY(ctx, hipMemcpy(ctx->d_hw + (size_t)r * ctx->n_markers, half.data(), sizeof(double) * ctx->n_markers,
-                               hipMemcpyHostToDevice));
+    // (one row from the host, then the filled part copied onto the rest, doubling: ~log2(rows) copies instead of one per row)
+    const size_t        M = (size_t)ctx->n_markers;
+    std::vector<double> half(M, 0.5);
+    HIP_TRY(ctx, hipMemcpy(ctx->d_hw, half.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+    for (size_t filled = 1; filled < (size_t)ctx->n_rows; filled *= 2) {
+        const size_t k = std::min(filled, (size_t)ctx->n_rows - filled);
+        HIP_TRY(ctx, hipMemcpy(ctx->d_hw + filled * M, ctx->d_hw, sizeof(double) * M * k, hipMemcpyDeviceToDevice));
+    }
     return CNF2_OK;
 }
 

@@ -61,9 +61,10 @@ cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint
     P.chromstarts.assign(chromstarts, chromstarts + n_chrom + 1);
     P.index["0"] = -1;
     const size_t M = (size_t)n_markers;
-    P.inds.reserve(n_rec);
+    P.inds.resize(n_rec);
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < n_rec; r++) {
-        Individual I;
+        Individual& I = P.inds[r];
         I.n = r + 1;
         I.name = "r" + std::to_string(r);
         I.gen = gen[r];
@@ -78,9 +79,8 @@ cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint
             I.prior_allele = I.allele;
             I.prior_sure = I.sure;
         }
-        P.index[I.name] = r;
-        P.inds.push_back(std::move(I));
     }
+    for (int r = 0; r < n_rec; r++) P.index[P.inds[r].name] = r;
     P.dous.assign(dous, dous + n_dous);
     if (cnf2_ctx_create(device, &run->ctx) != CNF2_OK) {
         g_err = cnf2_last_error(nullptr);
