@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from cnf2freq_amd import synth
-from conftest import GOLDEN_CASES, load_golden, oracle_ped
+from conftest import GOLDEN_CASES, load_golden, oracle_accumulate_threaded, oracle_ped
 
 pytestmark = pytest.mark.gpu
 
@@ -939,15 +939,16 @@ def test_states_the_reference_flushes_below_1e300_are_carried_here_without_effec
     vector: nothing of it reaches a double's 16 digits).  Adversarial but valid data that puts states into that band: a
     stretch of markers at ONE map position (no transition between them, cnF2freq.cpp:2273, so nothing leaks back into a
     state) at which a nearly phase-locked heterozygous parent and a homozygous child make the states that inherit the
-    parent's other strand lose a factor 2e-3 per marker -- (2e-3)^112 = 5e-303 -- followed by ordinary markers.  Likelihoods
+    parent's other strand lose a factor ~1e-2 per marker -- 2e-230 after 112 markers, measured; 1e-311 after 152 -- followed by
+    ordinary markers.  Likelihoods
     and rows must still equal the oracle's (which applies the rule, bit-exact on the reference extract).  What is NOT
     reproduced: data under which every OTHER state then becomes exactly impossible -- the reference
     declares the individual impossible (MINFACTOR), the kernels return the likelihood of the 1e-303 state."""
-    ped = synth.make_outbred3(1, 2, 150, 1, seed=9, missing=0.0, chrom_cm=30.0)
+    ped = synth.make_outbred3(1, 2, 190, 1, seed=9, missing=0.0, chrom_cm=30.0)
     ped.allele, ped.sure, ped.hw, ped.pos = ped.allele.copy(), ped.sure.copy(), ped.hw.copy(), ped.pos.copy()
     kid = int(ped.dous[0])
     p0, p1 = int(ped.par[kid, 0]), int(ped.par[kid, 1])
-    lo, hi = 10, 122                                        # 112 markers on one position
+    lo, hi = 10, 162                                        # 152 markers on one position
     ped.pos[lo:hi] = ped.pos[lo]
     for r, al in ((kid, (1, 1)), (p0, (1, 2)), (p1, (1, 1))):
         ped.allele[ped.row_of[r], lo:hi] = al
@@ -963,14 +964,14 @@ def test_states_the_reference_flushes_below_1e300_are_carried_here_without_effec
     fw, _ = ctx.fwbw_store(0, 0)
     end = fw[:, hi - 1, 0, :]
     live = end[end > 0]
-    assert live.min() < 1e-290 or (end == 0).any(), "no state came near the reference's 1e-300 threshold: %g" % live.min()
+    assert live.min() < 1e-300 or (end == 0).any(), "no state fell below the reference's 1e-300 threshold: %g" % live.min()
     np.testing.assert_allclose(got["factors"][:, 0], want["factors"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(got["loglik"][:, 0], want["factor"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(got["dosage"], want["dosage"], rtol=1e-6, atol=1e-10)
     # ... and through the accumulate mode (HOT LOOP 2 sees the same vectors)
     desc = ctx.descendants()
     acc = ctx.sweep_accumulate(desc)
-    ref = o.accumulate(ped.dous, ped.gen[ped.dous], desc)
+    ref = oracle_accumulate_threaded(o, ped, desc, 0, ped.n_markers - 1)
     for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
         np.testing.assert_allclose(acc[k], ref[k], rtol=1e-6, atol=1e-10, equal_nan=True, err_msg=k)
     ctx.close()
