@@ -9,7 +9,43 @@
 #include <algorithm>
 #include <map>
 
+#include <sched.h>
+
 namespace cnf2host {
+
+// Threads the host loops may use: the CPUs this process may really run on -- the affinity mask AND the cgroup's CPU quota (a
+// container with 16 CPUs' worth of quota on a 200-thread host must not start 200 threads: they would be throttled to a
+// crawl, and so would everything after them).  OMP_NUM_THREADS, when set, is respected as an upper bound.
+int host_threads()
+{
+    static int n = 0;
+    if (n > 0) return n;
+    int k = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) k = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                   // cgroup v2: "<quota> <period>" or "max <period>"
+        char   q[64];
+        double period = 0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+            k = std::min(k, std::max(1, (int)(atof(q) / period + 0.5)));
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+        double quota = -1, period = 0;
+        if (fscanf(g, "%lf", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lf", &period) != 1) period = 0;
+            fclose(h);
+        }
+        if (quota > 0 && period > 0) k = std::min(k, std::max(1, (int)(quota / period + 0.5)));
+    }
+    if (const char* e = getenv("OMP_NUM_THREADS")) {
+        const int v = atoi(e);
+        if (v > 0) k = std::min(k, v);
+    }
+    n = std::max(1, std::min(k, 64));
+    return n;
+}
 
 Engine::Engine(Pedigree& ped, cnf2_ctx* c, const EngineOptions& o) : P(ped), ctx(c), opt(o) {}
 
@@ -78,7 +114,7 @@ void Engine::push_rows()
     std::vector<double>  sure((size_t)std::min(R, slab) * M * 2), hw((size_t)std::min(R, slab) * M);
     for (int r0 = 0; r0 < R; r0 += slab) {
         const int k = std::min(slab, R - r0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (int r = 0; r < k; r++) {
             const Individual& I = P.inds[r0 + r];
             std::copy(I.allele.begin(), I.allele.end(), allele.begin() + (size_t)r * M * 2);
@@ -100,7 +136,7 @@ void Engine::pull_rows()
     for (int r0 = 0; r0 < R; r0 += slab) {
         const int k = std::min(slab, R - r0);
         check(cnf2_download_rows(ctx, 1 + r0, k, allele.data(), sure.data(), hw.data()), "cnf2_download_rows");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (int r = 0; r < k; r++) {
             Individual& I = P.inds[r0 + r];
             std::copy(allele.begin() + (size_t)r * M * 2, allele.begin() + (size_t)(r + 1) * M * 2, I.allele.begin());
@@ -305,7 +341,7 @@ void Engine::postmarkerdata(int indcount)
         // the order in which a parent filled in by its own fixkid is seen by its children stays the sequential one)
         {
             const int blk = 512, nblk = (M + blk - 1) / blk;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
             for (int b = 0; b < nblk; b++) {
                 const int g0 = b * blk, g1 = std::min(M, g0 + blk);
                 for (int r : recs) {
@@ -407,7 +443,7 @@ void Engine::postmarkerdata(int indcount)
         // record order afterwards (the messages of a run that is not quiet keep their order by running it on one thread)
         std::vector<std::vector<Fix>> fixes_of(recs.size());
         int any_sum = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : any_sum) if (opt.quiet)
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : any_sum) num_threads(host_threads()) if (opt.quiet)
         for (size_t q_ = 0; q_ < recs.size(); q_++) {
             const int r = recs[q_];
             std::vector<Fix>& fixes = fixes_of[q_];

@@ -53,6 +53,9 @@ struct EngineError : std::runtime_error {
 enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2 };
 typedef int (*ExchangeFn)(void* user, int op, void* buf, size_t count, size_t seg);
 
+// threads the host loops may use: affinity mask and cgroup CPU quota (cnf2_engine.cpp)
+int host_threads();
+
 class Engine {
 public:
     Engine(Pedigree& ped, cnf2_ctx* ctx, const EngineOptions& opt);

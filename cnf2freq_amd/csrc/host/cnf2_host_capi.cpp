@@ -62,7 +62,7 @@ cnf2h_run* cnf2h_create_on(int device, int n_rec, const int32_t* par, const uint
     P.index["0"] = -1;
     const size_t M = (size_t)n_markers;
     P.inds.resize(n_rec);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
     for (int r = 0; r < n_rec; r++) {
         Individual& I = P.inds[r];
         I.n = r + 1;
