@@ -78,7 +78,14 @@ class TrajectoryChecker:
         self.tainted = np.zeros(ped.n_rec, bool)
         self.log = []          # per iteration: (k, records compared, records in all, hit counters and scale factor compared)
 
-    def check(self, k, st, rtol=1e-9, atol=1e-12, exact_hits=True):
+    def check(self, k, st, rtol=1e-9, atol=1e-12, exact_hits=True, hits_slack=None, values=True):
+        """hits_slack: compare the hit counters (within that many) and the scale factor (exactly) even when components are
+        tainted -- for long runs, where an excused element moves a counter by a hit or two but must not move the step size.
+        values=False: past the horizon up to which two runs that differ by rounding can be compared element by element
+        (a knife-edge decision -- a slot whose two certainties are equal but for their last bits takes part in the HAPLOS
+        update or does not, cnF2freq.cpp:1224-1239 -- flips and moves its haplobase by O(1)): genotypes must still be
+        identical on the untainted records and all but a per cent of their certainties within 1e-6 (measured on the
+        10-iteration golden: 99.4 % after the tenth)."""
         z = self.z
         flagged = z["it%d_unstable" % k].astype(bool)
         differs = ~np.isclose(np.asarray(st["sure"]), z["it%d_sure" % k], rtol=rtol, atol=atol) | \
@@ -86,11 +93,19 @@ class TrajectoryChecker:
         bad = (flagged & differs).any(axis=(1, 2))
         self.tainted |= np.isin(self.comp, np.unique(self.comp[bad]))
         ok = ~self.tainted
-        if not self.tainted.any():
+        if hits_slack is not None:
+            assert np.abs(np.asarray(st["hits"]) - z["it%d_hits" % k]).max() <= hits_slack, (k, st["hits"], z["it%d_hits" % k])
+            np.testing.assert_allclose(st["scalefactor"], float(z["it%d_scalefactor" % k]), rtol=1e-12)
+        elif not self.tainted.any():
             if exact_hits:
                 assert np.array_equal(st["hits"], z["it%d_hits" % k]), (k, st["hits"], z["it%d_hits" % k])
             np.testing.assert_allclose(st["scalefactor"], float(z["it%d_scalefactor" % k]), rtol=1e-15 if exact_hits else 0.25)
         assert np.array_equal(np.asarray(st["allele"])[ok], z["it%d_allele" % k][ok]), k
+        if not values:
+            close = np.isclose(np.asarray(st["sure"])[ok], z["it%d_sure" % k][ok], rtol=1e-6, atol=1e-9)
+            assert close.mean() > 0.99, (k, close.mean())
+            self.log.append((k, int(ok.sum()), int(len(ok)), hits_slack is not None))
+            return int(ok.sum())
         # haplobase / haplocount as left behind: a slot that is homozygous with EQUAL certainties takes no part in the HAPLOS
         # update (cnF2freq.cpp:1224-1239 compares the two certainties for equality), and certainties that are equal by
         # symmetry are equal to the bit or not depending on the order of the additions behind them: left out
@@ -102,9 +117,9 @@ class TrajectoryChecker:
                 # haplobase is rewritten as (hb - c w + c (1 - s) w) / (1 - s) with 1 - s down to 5e-6 (cnF2freq.cpp:4667-4675):
                 # rounding of the weight w is amplified by up to 1 / (1 - s)
                 np.testing.assert_allclose(np.asarray(st[key])[keep], z["it%d_%s" % (k, key)][keep],
-                                           rtol=max(rtol, 1e-8) if key == "haplobase" else rtol, atol=atol,
+                                           rtol=max(10 * rtol, 1e-8) if key == "haplobase" else rtol, atol=atol,
                                            err_msg="%s after iteration %d" % (key, k))
-        self.log.append((k, int(ok.sum()), int(len(ok)), not self.tainted.any()))
+        self.log.append((k, int(ok.sum()), int(len(ok)), hits_slack is not None or not self.tainted.any()))
         return int(ok.sum())
 
     def report(self, case, path=None):
