@@ -1,6 +1,6 @@
 #!/bin/sh
 # Register / scratch / LDS use of the gfx950 kernels, from the code objects' metadata notes.
-# usage: tools/kernel_resources.sh [name filter]      (compiles the .hip files of cnf2freq_amd/csrc for the device only)
+# usage: [CNF2_EXTRA_FLAGS="-D..."] tools/kernel_resources.sh [name filter]      (compiles the .hip files of cnf2freq_amd/csrc for the device only)
 FILTER=${1:-.}
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d /tmp/cnf2res.XXXXXX)
@@ -8,7 +8,7 @@ trap 'rm -rf "$TMP"' EXIT
 for f in "$HERE"/cnf2freq_amd/csrc/cnf2_kernels.hip "$HERE"/cnf2freq_amd/csrc/cnf2_update_kernels.hip; do
     b=$(basename "$f" .hip)
     (cd "$HERE/cnf2freq_amd/csrc" && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics --cuda-device-only \
-        --no-gpu-bundle-output -c -o "$TMP/$b.o" "$f" 2>/dev/null)
+        --no-gpu-bundle-output $CNF2_EXTRA_FLAGS -c -o "$TMP/$b.o" "$f" 2>/dev/null)
     /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$TMP/$b.o"
 done | python3 -c '
 import re, sys, subprocess
