@@ -1169,6 +1169,17 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
             ctx->spill_bytes = capd * sizeof(double);
             if (rc) return rc;
         }
+        // CNF2_DETERMINISTIC: the per-individual rows (336 B per individual x marker) are taken out of what is free BEFORE the
+        // batch buffer is sized -- and allocated now, also by cnf2_reserve_accumulate -- so that the batch buffer cannot
+        // leave them without memory
+        const size_t part_need = (flags & CNF2_DETERMINISTIC) ? (size_t)n * M * 42 : 0;
+        if (part_need) {
+            const size_t have = ctx->part_cap * sizeof(double);
+            if (part_need * sizeof(double) > free_b / 2 + have)
+                return fail(ctx, CNF2_ERR_NOMEM, "CNF2_DETERMINISTIC needs %zu MB for the per-individual rows", (part_need * 8) >> 20);
+            if ((rc = ensure(ctx, &ctx->d_part, &ctx->part_cap, part_need))) return rc;
+            free_b -= (part_need * sizeof(double) > have) ? part_need * sizeof(double) - have : 0;
+        }
         // weights: 512 doubles per (job, marker); batch = what fits in half of the rest
         const size_t per_job = (size_t)mlen * 512;
         size_t       batch = (free_b - (size_t)grid_cap * per_blk) / 2 / (per_job * sizeof(double));
@@ -1221,10 +1232,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         q.max_len   = mlen;
         std::vector<int32_t> gather;               // CNF2_DETERMINISTIC: rec_start[R + 1], then ind * 8 + slot per record
         if (flags & CNF2_DETERMINISTIC) {
-            const size_t need = (size_t)n * M * 42;
-            if (need * sizeof(double) > free_b / 2)
-                return fail(ctx, CNF2_ERR_NOMEM, "CNF2_DETERMINISTIC needs %zu MB for the per-individual rows", (need * 8) >> 20);
-            if ((rc = ensure(ctx, &ctx->d_part, &ctx->part_cap, need))) return rc;
+            const size_t need = part_need;                    // allocated above, before the batch buffer was sized
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_part, 0, need * sizeof(double), ctx->stream));
             q.part = ctx->d_part;
             std::vector<int32_t> count(R + 1, 0);

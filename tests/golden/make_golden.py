@@ -183,14 +183,15 @@ TRAJ_CASES["ail_ties"] = (synth.make_ail, dict(n_f1=4, n_per_gen=6, n_gen=3, mar
 # the step-size control (cnF2freq.cpp:6373-6392) over a longer run: 10 families x 4 analysed children, two chromosomes of
 # 100 markers, 10 iterations -- the scale factor grows ("good": fewer capped moves than the floor of N / 7) and shrinks
 # ("bad": more than in both previous passes) along the way.  Takes ~20 minutes of the reference's own update code.
-TRAJ_CASES["outbred3_long"] = (synth.make_outbred3, dict(n_fam=10, kids_per_fam=4, markers_per_chrom=100, n_chrom=2, seed=17,
-                                                         missing=0.05))
+# Not part of the default run (python make_golden.py regenerates everything else in a few minutes): python make_golden.py traj_long
+TRAJ_CASES_LONG = {"outbred3_long": (synth.make_outbred3, dict(n_fam=10, kids_per_fam=4, markers_per_chrom=100, n_chrom=2, seed=17,
+                                                              missing=0.05))}
 TRAJ_ITERATIONS = 3
 TRAJ_ITERATIONS_OF = {"outbred3_long": 10}
 
 
 def traj_ped(name):
-    ctor, kw = TRAJ_CASES[name]
+    ctor, kw = TRAJ_CASES[name] if name in TRAJ_CASES else TRAJ_CASES_LONG[name]
     return make_f2_ungenotyped() if ctor is None else ctor(**kw)
 
 
@@ -332,7 +333,10 @@ if __name__ == "__main__":
     if "traj" in what:
         for name in TRAJ_CASES:
             generate_trajectory(name)
-    for name in what:                      # single trajectories by name: python make_golden.py traj:outbred3_long
+    if "traj_long" in what:                # ~40 minutes of the reference's own update code on one core
+        for name in TRAJ_CASES_LONG:
+            generate_trajectory(name)
+    for name in what:                      # single trajectories by name: python make_golden.py traj:outbred3_two_chrom
         if name.startswith("traj:"):
             generate_trajectory(name[5:])
     if "units" in what:
