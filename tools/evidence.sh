@@ -7,6 +7,7 @@
 #            rank and as a 2-rank gloo rehearsal on this one GPU, bench.py --gpus 2 without a launcher
 #   iter     rocprofv3 kernel stats of the iteration probe; CNF2_TIMING laps of config 5's setup and first iterations
 #   config5  config 5 end to end, 100 iterations (tools/run_config5.py): ~3 minutes
+#   c4       one of config 4's 8 shards on this GPU: 12 500 individuals x 200 080 markers (80 chromosomes x 2 501), 2 steps
 # Everything lands in gpurun_out/ev_<tag>/; copy what is to be judged into profiles/.
 tag=${1:-rXX}
 parts=${2:-"tests profile bench iter"}
@@ -44,6 +45,9 @@ PY
     cd $R
     CNF2_TIMING=1 timeout -k 10 400 python tools/run_config5.py 2500 2500 4 6 > $o/${tag}_config5_setup_and_6_iterations_timing.log 2>&1; echo "timing exit $?"
     grep "postmarkerdata\|upload\|^iteration" $o/${tag}_config5_setup_and_6_iterations_timing.log | head -20 ;;
+c4)
+    cd $R
+    timeout -k 10 600 python bench.py --inds 12500 --chroms 80 --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe --no-merge-probe > $o/${tag}_bench_c4_shard_12500x200080.json.log 2> $o/bench_c4.err; echo "c4 exit $?"; summ $o/${tag}_bench_c4_shard_12500x200080.json.log ;;
 config5)
     cd $R
     timeout -k 10 700 python tools/run_config5.py 2500 2500 4 100 600 > $o/${tag}_config5_100_iterations.log 2>&1; echo "config5 exit $?"
