@@ -184,8 +184,10 @@ TRAJ_CASES["ail_ties"] = (synth.make_ail, dict(n_f1=4, n_per_gen=6, n_gen=3, mar
 # 100 markers, 10 iterations -- the scale factor grows ("good": fewer capped moves than the floor of N / 7) and shrinks
 # ("bad": more than in both previous passes) along the way.  Takes ~20 minutes of the reference's own update code.
 # Not part of the default run (python make_golden.py regenerates everything else in a few minutes): python make_golden.py traj_long
+# (everybody genotyped, as in outbred3_two_chrom: no allele nothing is known about, so no element of the run is rounding noise in
+# the reference itself and every record can be compared)
 TRAJ_CASES_LONG = {"outbred3_long": (synth.make_outbred3, dict(n_fam=10, kids_per_fam=4, markers_per_chrom=100, n_chrom=2, seed=17,
-                                                              missing=0.05))}
+                                                              missing=0.0))}
 TRAJ_ITERATIONS = 3
 TRAJ_ITERATIONS_OF = {"outbred3_long": 10}
 

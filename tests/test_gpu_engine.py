@@ -219,14 +219,17 @@ def test_iterations_follow_the_reference_trajectory(libs, case, tmp_path):
         # probabilities is absolute (1e-10) next to the relative 1e-9
         if case in TRAJ_CASES_LONG:
             # two runs that differ by rounding stay together element by element for four iterations (measured on this golden,
-            # tools/diag_trajectory.py: 4e-15, 1e-10, 8e-9, 1e-7 relative), then a knife-edge decision flips; the step-size
-            # control, the hit counters (an excused element is worth a hit or two) and the genotypes stay those of the
-            # reference through all ten
-            compared = chk.check(k, st, rtol=(1e-9, 1e-9, 1e-8, 1e-6)[min(k, 4) - 1], atol=1e-10, hits_slack=4, values=k <= 4)
+            # tools/diag_trajectory.py: 2e-15, 1e-10, 8e-9, 4e-8 relative; 1.5e-6 after the fifth), then a handful of haplotype
+            # weights drifts (16 - 18 of 20 200 beyond 1e-6 from iteration 8 on, after a knife-edge decision has moved one
+            # haplobase by 1.5); the step-size control, EVERY hit counter and every genotype stay those of the reference
+            # through all ten iterations, and so do all certainties to 2e-7
+            compared = chk.check(k, st, rtol=(1e-9, 1e-9, 1e-8, 1e-6)[min(k, 4) - 1], atol=1e-10, hits_slack=0, values=k <= 4)
+            np.testing.assert_allclose(st["sure"], z["it%d_sure" % k], rtol=0, atol=1e-6)
+            assert (np.abs(st["hw"] - z["it%d_hw" % k]) > 1e-6).sum() <= 40
         else:
             compared = chk.check(k, st, rtol=1e-9, atol=1e-10)
     print(chk.report(case, os.path.join(ROOT, "gpurun_out", "trajectory_compared.txt")))
-    assert compared == ped.n_rec or case in ["random_windows"] + TRAJ_CASES_LONG
+    assert compared == ped.n_rec or case == "random_windows"
     assert compared >= ped.n_rec // 2
     run.close()
 
