@@ -175,3 +175,46 @@ def test_tied_accumulate_and_turn_scan_in_batches(capi):
     assert np.array_equal(raw, raw_whole, equal_nan=True) and np.array_equal(lse, lse_whole, equal_nan=True)
     _check_accumulators(got, ped, oracle_ped(ped), desc)
     ctx.close()
+
+
+def test_accumulator_invariants_at_full_chromosome_length(capi):
+    """Size-independent properties of HOT LOOP 2's accumulators (cnF2freq.cpp:5416-5577 with moveinfprobs / movehaplos
+    3577-3616) at BASELINE config 5's chromosome length (2 501 markers, 20 % missing genotypes), where the oracle would need
+    hours: every path of an analysed child carries one allele value per side of the child and of each parent and passes
+    through ONE grandparent of each parent, and a child's contributions are normalised to its own total, so with every
+    descendant count 1
+      * a child's infprobs sum to 1 on either side at every marker,
+      * a parent's sum to its number of analysed children over both sides,
+      * the two grandparents of a parent together collect that number as well,
+      * haplocount is a whole number of children, 0 <= haplobase <= haplocount,
+    whatever the batching (batches of 64 jobs here) and the grid (one block for half of the comparisons).  Verified on the
+    oracle at small size first (this test's derivation)."""
+    fams, kids, per = 40, 4, 10
+    ped = synth.make_outbred3(fams, kids, 2500, 2, seed=23, missing=0.2)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = np.ones(ped.n_rec, np.int32)
+    ctx.set_batch_jobs(64)
+    got = ctx.sweep_accumulate(desc, deterministic=True)
+    ctx.set_grid_reserve(ONE_BLOCK)
+    ctx.set_batch_jobs(0)
+    one = ctx.sweep_accumulate(desc, deterministic=True)
+    ctx.set_grid_reserve(0)
+    for k in ("infprobs", "haplobase", "haplocount", "homozyg", "dosage", "loglik"):
+        assert np.array_equal(got[k], one[k], equal_nan=True), "batches of 64 jobs and one block of one batch differ in " + k
+    inf = got["infprobs"]                                     # [R][M][2][2]
+    assert np.all(np.isfinite(inf)) and np.all(inf >= 0)
+    base = np.arange(fams) * per
+    kid = (base[:, None] + 6 + np.arange(kids)[None, :]).ravel()
+    np.testing.assert_allclose(inf[kid].sum(axis=3), 1.0, rtol=0, atol=1e-9)
+    for p in range(2):
+        np.testing.assert_allclose(inf[base + 4 + p].sum(axis=(2, 3)), float(kids), rtol=0, atol=1e-8)
+        pair = inf[base + 2 * p].sum(axis=(2, 3)) + inf[base + 2 * p + 1].sum(axis=(2, 3))
+        np.testing.assert_allclose(pair, float(kids), rtol=0, atol=1e-8)
+    hc, hb = got["haplocount"], got["haplobase"]
+    assert np.array_equal(hc, np.round(hc)) and hc.min() >= 0 and hc.max() <= kids
+    assert np.all(hb >= 0) and np.all(hb <= hc + 1e-12)
+    assert (hc > 0).mean() > 0.2
+    # the rows that come with it are distributions
+    assert np.allclose(got["dosage"].sum(axis=2), 1.0, atol=1e-12)
+    ctx.close()
