@@ -840,6 +840,7 @@ __device__ __forceinline__ void emission_from_row_t(const double* row, const Fas
 
 // Running state of the backward pass of one lane (kept in one struct so that the per-marker body can be
 // instantiated for even and odd markers without a merge of differently-defined values between them).
+#define CNF2_LI_K __attribute__((always_inline))
 struct BwdState {
     double b[8];          // beta
     double am[8];         // alpha-minus of the row in flight (HALF: of the even marker of the pair)
@@ -1132,6 +1133,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 S.fexpo += ex;
             }
             double n_tot = 0.0, n_a1 = 0.0, n_b1 = 0.0, n_2 = 0.0;
+#ifdef CNF2_X_FUSEDACC   /* timing ablation only (tools/ablate_fused_acc.sh): results are wrong */
+            double x_av[2], x_sb[2], x_t0[2], x_t1[2], x_cf[2];
+#endif
 #pragma unroll
             for (int f = 0; f < 2; f++) {
                 // the lane's own line (its low bits index that half of the tables) and the line held in the registers:
@@ -1153,12 +1157,69 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 n_a1 += a1 * sb;
                 n_b1 += av * sb1;
                 n_2 += a1 * sb1;
+#ifdef CNF2_X_FUSEDACC
+                if (STOREW == 1) {
+                    // the two HOMOZYGOUS probe contractions of phase B: stand-in tables of the same shape in the same row
+                    const double* H0 = row + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
+                    double        t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        t0 += wj[j] * H0[j];
+                        t1 += wj[j] * H0[j ^ 1];
+                    }
+                    x_av[f] = av;
+                    x_sb[f] = sb;
+                    x_t0[f] = t0;
+                    x_t1[f] = t1;
+                    x_cf[f] = cf;
+                }
+#endif
             }
             const double sc0   = ODD ? xm * S.inv_even : xm;
             const double scale = chain_on ? ldexp(sc0 * S.fmant * S.bmant, xe + S.fexpo + S.bexpo) : 0.0;
             double q2 = scale * n_2;
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
+#ifdef CNF2_X_FUSEDACC
+            if (STOREW == 1 && (!TIED || cur_combo == 0)) {
+                // phase B of acc_tile_kernel formed here: v (sum over s2), z (over s0 and s2), u (over the 32 lanes of a half)
+                double*   wp = p.wbuf + ((size_t)job * p.wstride + ml) * 160;
+                const int e0 = (c.s1 << 3) | c.lo;
+                double    uu[16];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const double k = scale * x_cf[f];
+                    double       v = k * x_sb[f], z0 = k * x_t0[f], z1 = k * x_t1[f];
+                    v += lane_xor32(v);
+                    z0 += lane_xor32(z0);
+                    z1 += lane_xor32(z1);
+                    z0 += lane_xor8(z0);
+                    z1 += lane_xor8(z1);
+                    if (c.s2 == 0) wp[(f * 2 + c.s0) * 16 + e0] = v;
+                    if (c.s2 == 0 && c.s0 == 0) {
+                        wp[96 + (f * 2 + 0) * 16 + e0] = z0;
+                        wp[96 + (f * 2 + 1) * 16 + e0] = z1;
+                    }
+                    const double ka = scale * x_av[f];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) uu[f * 8 + j] = wj[j] * ka;
+                }
+                auto halve = [&](double a, double b, bool bit, int which) CNF2_LI_K {
+                    const double keep = bit ? b : a, send = bit ? a : b;
+                    return keep + (which == 0 ? lane_xor1(send) : (which == 1 ? lane_xor2(send) : (which == 2 ? lane_xor4(send) : lane_xor8(send))));
+                };
+                double h8[8], h4[4], h2[2];
+#pragma unroll
+                for (int k = 0; k < 8; k++) h8[k] = halve(uu[2 * k], uu[2 * k + 1], (lane & 1) != 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) h4[k] = halve(h8[2 * k], h8[2 * k + 1], (lane & 2) != 0, 1);
+#pragma unroll
+                for (int k = 0; k < 2; k++) h2[k] = halve(h4[2 * k], h4[2 * k + 1], (lane & 4) != 0, 2);
+                double h1v = halve(h2[0], h2[1], (lane & 8) != 0, 3);
+                h1v += lane_xor16(h1v);
+                if ((lane & 16) == 0) wp[64 + ((lane >> 3) & 1) * 16 + (c.s2 << 3) + (lane & 7)] = h1v;
+            }
+#else
             if (STOREW == 1 && (!TIED || cur_combo == 0)) {
                 // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta for the batched HOT LOOP 2 kernel
                 // (the same in every tie combination)
@@ -1169,6 +1230,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                     __builtin_nontemporal_store(v, (d2v*)(wp + k * 128 + lane * 2));
                 }
             }
+#endif
             // this marker's own emission is only needed for the beta step: formed here, after the sums, so
             // that it does not occupy registers across them
             double e[8];
@@ -3103,7 +3165,19 @@ __global__ __launch_bounds__(64 * APT_WAVES, 2) void acc_tile_kernel(AccParams q
                     xn[2 * k + 1] = v2.y;
                 }
             }
+#ifdef CNF2_X_FUSEDACC   /* timing ablation only: the contractions come from the sweep (160 doubles per marker) */
             for (int mj = 0; mj < nvalid; mj++) {
+                const double* wp = p.wbuf + ((size_t)job * p.wstride + (ml0 + mj)) * 160;
+                double*       vuz = L + APT_VUZ + mj * APT_VSTRIDE;
+                vuz[lane] = wp[lane];
+                vuz[64 + lane] = wp[64 + lane];
+                if (lane < 32) vuz[128 + lane] = wp[128 + lane];
+            }
+            (void)xn;
+            for (int mj = 0; mj < 0; mj++) {
+#else
+            for (int mj = 0; mj < nvalid; mj++) {
+#endif
                 double x[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[k] = xn[k];
