@@ -7,6 +7,21 @@
 #include "cnf2_device.h"
 #include "cnf2_update.h"
 
+// Waves per SIMD the scout kernels are compiled for.  They hold one flow per lane and wait for each other's longest lanes and
+// for their scattered loads (34 % of the wave cycles in s_waitcnt): at 4 waves per SIMD (<= 128 VGPRs: 2 - 20 of them spilled,
+// outside the bisection loops) they are 9 - 19 % faster than at the 3 the compiler's own 140 - 167 registers allow
+// (tools/ab_update.sh, profiles/r04_h_ab_update_occupancy.log).  The finish kernels do not gain (certainty_finish fits 128
+// registers without a spill and runs the same 4.6 ms; haploweight_finish is at 123 already): left to the compiler.
+#ifndef CNF2_SCOUT_WAVES
+#define CNF2_SCOUT_WAVES 4
+#endif
+#define CNF2_SCOUT_OCC __attribute__((amdgpu_waves_per_eu(CNF2_SCOUT_WAVES, CNF2_SCOUT_WAVES)))
+#ifdef CNF2_FINISH_WAVES
+#define CNF2_FINISH_OCC __attribute__((amdgpu_waves_per_eu(CNF2_FINISH_WAVES, CNF2_FINISH_WAVES)))
+#else
+#define CNF2_FINISH_OCC
+#endif
+
 namespace cnf2 {
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -387,7 +402,7 @@ __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* f
 #define FLOW_SCOUT_STEPS 8      /* steps of the first scout pass (2: +5 %, 3: +2.5 %, 5: +2 %, 12: -0.3 %, 16: +0.6 % on 40 iterations, tools/ab_scout.py) */
 #endif
 template <bool TWO_PASSES>
-__global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+__global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
                                                               double* flow_out, FlowTodo* todo)
 {
     const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, un
 
 // Second scout pass: the flows the first left scouting, 64 of them per wavefront and round (persistent, the finish pass's
 // supply); a flow ends here or its slot is rewritten for the finish pass.
-__global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, unsigned long long* next, FlowTodo* todo,
+__global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, unsigned long long* next, FlowTodo* todo,
                                                               unsigned long long item0, unsigned long long n_items, double* flow_out)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
@@ -506,7 +521,7 @@ __global__ __launch_bounds__(64) void certainty_scout2_kernel(UpdateParams u, un
     flow_stats(u.stats, 0u, (unsigned)evals_all, n_done, 0u);
 }
 
-__global__ __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
+__global__ CNF2_FINISH_OCC __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
                                                               unsigned long long n_items, double* flow_out)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
@@ -610,7 +625,7 @@ __device__ __forceinline__ bool haplo_item(const UpdateParams& u, unsigned long 
     return u.anyinfo[(size_t)r * u.n_chrom + c] && hw != 0.0 && hw != 1.0 && u.row_of[r] != 0;          // cnF2freq.cpp:4591
 }
 
-__global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
+__global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
                                                                 HaploTodo* todo)
 {
     const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(256) void haploweight_scout_kernel(UpdateParams u, 
     flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
 }
 
-__global__ __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
+__global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
                                                                 unsigned long long n_items)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};

@@ -30,7 +30,10 @@ t_up = time.time() - t
 t = time.time()
 run.postmarkerdata()
 t_pm = time.time() - t
-print("upload %.1f s, postmarkerdata %.1f s" % (t_up, t_pm), flush=True)
+t = time.time()
+run.reserve()               # the batch buffers of the iterations now (a first hipMalloc of ~100 GB takes seconds on a fresh device)
+t_res = time.time() - t
+print("upload %.1f s, postmarkerdata %.1f s, reserve %.1f s" % (t_up, t_pm, t_res), flush=True)
 s0 = run.state()
 acc0 = synth.dosage_accuracy(ped, s0)          # the withheld genotypes against the generator's truth, before any iteration
 print("withheld genotypes before the iterations: %s" % json.dumps(acc0), flush=True)
@@ -53,7 +56,7 @@ out = {
     "config": "BASELINE config 5: outbred 3-generation, 20%% missing, %d analysed of %d individuals, %d markers, %d iterations, 1 GPU"
               % (n, R, M, len(t_it)),
     "iterations_requested": iters, "iterations_done": len(t_it), "units_per_iteration": n * M,
-    "upload_s": t_up, "postmarkerdata_s": t_pm, "iteration_s_mean": float(np.mean(t_it)), "iteration_s_first": t_it[0],
+    "upload_s": t_up, "postmarkerdata_s": t_pm, "reserve_s": t_res, "iteration_s_mean": float(np.mean(t_it)), "iteration_s_first": t_it[0],
     "iterations_total_s": float(np.sum(t_it)), "state_download_s": t_pull,
     "units_per_s_per_iteration": n * M / float(np.mean(t_it)),
     "locked_weights": locked,
