@@ -35,7 +35,7 @@ SYMBOLS = [
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
-    "cnf2_set_grid_reserve", "cnf2_set_batch_jobs", "cnf2_window_table", "cnf2_update_pass_records", "cnf2_exchange_buffer", "cnf2_exchange_download", "cnf2_exchange_upload",
+    "cnf2_set_grid_reserve", "cnf2_set_batch_jobs", "cnf2_window_table", "cnf2_update_pass_records", "cnf2_exchange_buffer", "cnf2_exchange_download", "cnf2_exchange_upload", "cnf2_exchange_read", "cnf2_exchange_write",
     "cnf2_packed_accumulator_doubles", "cnf2_packed_row_bytes", "cnf2_pack_accumulators", "cnf2_unpack_accumulators",
     "cnf2_pack_rows", "cnf2_unpack_rows",
 ]
@@ -133,6 +133,8 @@ def load():
         L.cnf2_exchange_buffer.argtypes = [vp, C.c_size_t, vp]
         L.cnf2_exchange_download.argtypes = [vp, vp, C.c_size_t]
         L.cnf2_exchange_upload.argtypes = [vp, vp, C.c_size_t]
+        L.cnf2_exchange_read.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+        L.cnf2_exchange_write.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
         L.cnf2_packed_accumulator_doubles.argtypes = [vp]
         L.cnf2_packed_accumulator_doubles.restype = C.c_size_t
         L.cnf2_packed_row_bytes.argtypes = [vp]

@@ -1645,25 +1645,30 @@ int cnf2_exchange_buffer(cnf2_ctx* ctx, size_t bytes, void** d_buf)
     return CNF2_OK;
 }
 
-int cnf2_exchange_download(cnf2_ctx* ctx, void* host_dst, size_t bytes)
+int cnf2_exchange_read(cnf2_ctx* ctx, size_t offset, void* host_dst, size_t bytes)
 {
-    if (!ctx || !host_dst) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
-    if (bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "more than the exchange buffer holds");
+    if (!ctx || (!host_dst && bytes)) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (offset + bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "beyond the exchange buffer");
+    if (!bytes) return CNF2_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(host_dst, ctx->d_xbuf, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(host_dst, ctx->d_xbuf + offset, bytes, hipMemcpyDeviceToHost));
     return CNF2_OK;
 }
 
-int cnf2_exchange_upload(cnf2_ctx* ctx, const void* host_src, size_t bytes)
+int cnf2_exchange_write(cnf2_ctx* ctx, size_t offset, const void* host_src, size_t bytes)
 {
-    if (!ctx || !host_src) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
-    if (bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "more than the exchange buffer holds");
+    if (!ctx || (!host_src && bytes)) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (offset + bytes > ctx->xbuf_cap || !ctx->d_xbuf) return fail(ctx, CNF2_ERR_ARG, "beyond the exchange buffer");
+    if (!bytes) return CNF2_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_xbuf, host_src, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_xbuf + offset, host_src, bytes, hipMemcpyHostToDevice));
     return CNF2_OK;
 }
+
+int cnf2_exchange_download(cnf2_ctx* ctx, void* host_dst, size_t bytes) { return cnf2_exchange_read(ctx, 0, host_dst, bytes); }
+int cnf2_exchange_upload(cnf2_ctx* ctx, const void* host_src, size_t bytes) { return cnf2_exchange_write(ctx, 0, host_src, bytes); }
 
 size_t cnf2_packed_accumulator_doubles(const cnf2_ctx* ctx) { return ctx ? (size_t)ctx->n_markers * 6 : 0; }
 size_t cnf2_packed_row_bytes(const cnf2_ctx* ctx) { return ctx ? (((size_t)ctx->n_markers * 25 + 7) & ~(size_t)7) : 0; }

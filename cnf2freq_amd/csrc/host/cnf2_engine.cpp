@@ -683,16 +683,43 @@ void Engine::iteration(FILE* out)
                 printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[b0 + j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
                        P.inds[T.dous[b0 + j]].gen < 2 ? 2 : 8);
             }
+        // multi-process runs with a spool directory: ranks > 0 write the rows of their block to a file, rank 0 appends the
+        // files behind its own rows in rank order -- the order of a single-process run -- and removes them
+        const bool spool = multi && !opt.spool_dir.empty() && opt.print_rows;
+        auto spool_name = [&](int rank) {
+            return opt.spool_dir + "/cnf2_rows_it" + std::to_string(iteration_no_) + "_chrom" + std::to_string(c + 1) + "_rank" +
+                   std::to_string(rank) + ".txt";
+        };
+        FILE* rows_out = out;
+        if (spool && part_.rank > 0) {
+            rows_out = fopen(spool_name(part_.rank).c_str(), "w");
+            if (!rows_out) throw EngineError(CNF2_ERR_STATE, "cannot write " + spool_name(part_.rank));
+        }
         for (int j = 0; j < nb && opt.print_rows; j++) {            // cnF2freq.cpp:6183-6188
-            fprintf(out, "%s:%d\n", P.inds[T.dous[b0 + j]].name.c_str(), c + 1);
+            fprintf(rows_out, "%s:%d\n", P.inds[T.dous[b0 + j]].name.c_str(), c + 1);
             const double ll = loglik[(size_t)j * C + c];
             const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
             if (!skipped)
                 for (int m = P.chromstarts[c]; m < P.chromstarts[c + 1]; m++) {
                     const double* d = &dosage[((size_t)j * M + m) * 3];
-                    fprintf(out, "%.5lf\t%.5lf\t%.5lf\n", d[0], d[1], d[2]);
+                    fprintf(rows_out, "%.5lf\t%.5lf\t%.5lf\n", d[0], d[1], d[2]);
                 }
-            fprintf(out, "\n");
+            fprintf(rows_out, "\n");
+        }
+        if (spool) {
+            if (part_.rank > 0) fclose(rows_out);
+            exchange(X_BARRIER, nullptr, 0, 0, "the barrier behind the spooled rows");
+            if (part_.rank == 0) {
+                std::vector<char> buf(1 << 20);
+                for (int r = 1; r < part_.world; r++) {
+                    FILE* f = fopen(spool_name(r).c_str(), "r");
+                    if (!f) throw EngineError(CNF2_ERR_STATE, "cannot read " + spool_name(r));
+                    size_t k;
+                    while ((k = fread(buf.data(), 1, buf.size(), f)) > 0) fwrite(buf.data(), 1, k, out);
+                    fclose(f);
+                    remove(spool_name(r).c_str());
+                }
+            }
         }
         fflush(out);
         lap("likelihood lines / rows");
@@ -751,6 +778,7 @@ void Engine::iteration(FILE* out)
         rows_partial_ = true;
     }
     if (opt.update && N > 0) rows_stale_ = true;
+    iteration_no_++;
 }
 
 void Engine::dump(FILE* out, int limit)

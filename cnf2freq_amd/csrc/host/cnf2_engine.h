@@ -32,6 +32,10 @@ struct EngineOptions {
     bool update = true;         // false: iterations only sweep and print (parity aid, not a reference mode)
     bool dump_all = true;       // false: only the last iteration dumps (large runs; the reference always dumps)
     bool print_rows = true;     // false: rows of this iteration are not formatted at all (large runs, non-final iterations)
+    // multi-process runs: directory through which the ranks' rows reach rank 0, which then writes ONE output in the order of
+    // a single-process run (per chromosome the rows of every analysed individual, then the pass lines); empty: every rank
+    // writes the rows of its own block to its own output
+    std::string spool_dir;
 };
 
 // A call into libcnf2hip.so failed (out of memory, launch error, bad state).  The command line turns it into the
@@ -49,8 +53,10 @@ struct EngineError : std::runtime_error {
 //   X_SUM_HITS         buf = HOST int32[count]: in-place sum over all ranks (the hit counters of an update pass)
 //   X_GATHER_SEGMENTS  buf = device, `count` bytes in segments of `seg`: every rank has filled its own segment; on return
 //                      all segments are filled on every rank (an all-gather)
+//   X_BARRIER          nothing to move: returns when every rank has called it (the rows of the ranks' blocks are spooled to
+//                      files and collected by rank 0, EngineOptions::spool_dir)
 // Returns 0 on success.
-enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2 };
+enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2, X_BARRIER = 3 };
 typedef int (*ExchangeFn)(void* user, int op, void* buf, size_t count, size_t seg);
 
 // threads the host loops may use: affinity mask and cgroup CPU quota (cnf2_engine.cpp)
@@ -138,6 +144,7 @@ private:
     void       exchange(int op, void* buf, size_t count, size_t seg, const char* what);
     void       gather_private_rows();
     std::vector<int> pass_hits_;
+    int    iteration_no_ = 0;              // iterations run so far (names of the spooled row files)
     double last_timing_[5] = {0, 0, 0, 0, 0};
 };
 

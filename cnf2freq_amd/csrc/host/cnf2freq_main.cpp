@@ -1,7 +1,7 @@
 // cnf2freq_main.cpp -- drop-in command line for the PlantImpute invocation of the reference
 // (demo.sh:37):
 //   cnF2freq --mapfile F --pedfile F --genfile F --output F --count N [--limit n] [--capmarker n] [--tmppath d]
-//            [--deserialize F]
+//            [--deserialize F] [--gpus N]
 // Flag names and semantics follow main() (cnF2freq.cpp:7954-7972, 8083-8195): postmarkerdata, an optional
 // --deserialize of an earlier dump, then --count rounds of which the first only dumps and every later one runs a
 // haplotyping sweep (doit) before its dump.  Rows of the last round go to --output, earlier ones to stdout; every
@@ -10,12 +10,20 @@
 // allele-2 dosage posterior ("%.5lf" tab separated, genotypereporter, cnF2freq.cpp:3499-3538) and a blank line
 // (cnF2freq.cpp:6183-6188).
 //
+// --gpus N (not a flag of the reference, whose MPI code is dead: cnF2freq.cpp:5297-5299, 6245-6254): the process reads the
+// files, forks N ranks -- before anything has touched a GPU --, rank r takes GPU r, its block of the analysed individuals and
+// the records it owns (cnf2_partition.h), the ranks exchange through shared memory (cnf2_shm_transport.h), and rank 0
+// writes ONE output in the order of a single-GPU run: the other ranks' rows reach it through files in --tmppath.
+//
 // Everything numeric goes through the C ABI of include/cnf2hip.h (host bookkeeping in cnf2_engine.cpp); this program
 // has no compute path of its own and fails if no GPU is present.  Out of scope: the toulbar2
 // bridge and the haplotype inversions it decides, all non-PlantImpute readers.
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -23,6 +31,7 @@
 
 #include "cnf2_engine.h"
 #include "cnf2_readers.h"
+#include "cnf2_shm_transport.h"
 #include "cnf2hip.h"
 
 using namespace cnf2host;
@@ -41,6 +50,8 @@ struct Options {
     bool        dump_all = true;      // --dump-last-only: large runs
     bool        rows_all = true;      // --rows-last-only: large runs (rows of non-final rounds are not formatted)
     bool        parse_only = false;   // print the parsed tables and stop (no GPU needed; used by tests)
+    int         gpus = 1;             // --gpus N: N ranks, one GPU each
+    bool        single_device = false;   // --single-device: every rank on GPU 0 (rehearsal of --gpus N on a one-GPU box)
 };
 
 static bool parse(int argc, char** argv, Options& o)
@@ -79,12 +90,88 @@ static bool parse(int argc, char** argv, Options& o)
         else if (a == "--dump-last-only") o.dump_all = false;
         else if (a == "--rows-last-only") o.rows_all = false;
         else if (a == "--parse-only") o.parse_only = true;
+        else if (a == "--gpus") o.gpus = atoi(val().c_str());
+        else if (a == "--single-device") o.single_device = true;
         else {
             fprintf(stderr, "unsupported option %s (this build covers the PlantImpute path only)\n", a.c_str());
             return false;
         }
     }
     return true;
+}
+
+// One rank of a run: GPU `rank` (or 0), the whole pedigree, its block of the analysed individuals.  rank 0 writes the output.
+static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmRegion* region)
+{
+    if (rank > 0) {
+        // what is identical on every rank (progress lines, pass lines, dumps) is written by rank 0 only
+        if (!freopen("/dev/null", "w", stdout)) return 3;
+    }
+    cnf2_ctx* ctx = nullptr;
+    const int device = (world > 1 && !opt.single_device) ? rank : 0;
+    if (cnf2_ctx_create(device, &ctx) != CNF2_OK) {
+        fprintf(stderr, "cnf2_ctx_create(device %d): %s%s\n", device, cnf2_last_error(nullptr),
+                world > 1 ? " (--gpus N needs N GPUs; --single-device rehearses it on one)" : "");
+        if (world > 1) return 3;
+        abort();
+    }
+    EngineOptions eo;
+    eo.quiet = opt.quiet;
+    eo.merge_modes = opt.merge_modes;
+    eo.normalise = opt.normalise;
+    eo.update = opt.update;
+    eo.dump_all = opt.dump_all;
+    if (world > 1) eo.spool_dir = opt.tmppath;
+    ShmTransport T;
+    // any failure below the C ABI ends the run the way the reference ends on every failure (cnF2freq.cpp:21-25)
+    try {
+    Engine E(P, ctx, eo);
+    E.upload();
+    if (opt.preprocess) E.postmarkerdata(opt.limit);                 // cnF2freq.cpp:8083-8085
+    if (!opt.deserialize.empty() && !E.deserialize(opt.deserialize.c_str())) {
+        fprintf(stderr, "cannot open %s\n", opt.deserialize.c_str());
+        abort();
+    }
+    if (world > 1) {
+        T.R = region;
+        T.ctx = ctx;
+        T.rank = rank;
+        E.set_partition(rank, world, ShmTransport::call, &T);
+        const Partition& Q = E.partition();
+        if (rank == 0) {
+            size_t xb[4];
+            E.exchange_bytes(xb);
+            fprintf(stderr, "%d ranks: blocks", world);
+            for (int r = 0; r < world; r++) fprintf(stderr, " [%d, %d)", Q.bounds[r], Q.bounds[r + 1]);
+            fprintf(stderr, "; %zu shared records, %zu bytes exchanged per iteration\n", Q.n_shared, xb[3]);
+        }
+    }
+
+    FILE* out = stdout;
+    if (rank > 0) out = fopen("/dev/null", "w");
+    else if (!opt.output.empty()) out = fopen(opt.output.c_str(), "w");
+    if (!out) { fprintf(stderr, "cannot open output\n"); abort(); }
+
+    for (int it = 0; it < opt.count; it++) {
+        const bool early = it < 1;                       // cnF2freq.cpp:8131
+        if (!early) {
+            E.set_print_rows(opt.rows_all || it == opt.count - 1);
+            E.iteration((it == opt.count - 1) ? out : stdout);
+        }
+        fflush(stdout);
+        fflush(out);
+        if (opt.dump_all || it == opt.count - 1) E.dump(out, opt.limit);        // (gathers the ranks' rows: every rank calls it)
+        fflush(stdout);
+        fflush(out);
+    }
+    if (out != stdout) fclose(out);
+    } catch (const EngineError& e) {
+        fprintf(stderr, "%s\n", e.what());
+        if (world > 1) return 4;                          // the parent stops the other ranks and aborts
+        abort();
+    }
+    cnf2_ctx_destroy(ctx);
+    return 0;
 }
 
 int main(int argc, char** argv)
@@ -134,51 +221,52 @@ int main(int argc, char** argv)
         return 0;
     }
 
-    cnf2_ctx* ctx = nullptr;
-    if (cnf2_ctx_create(0, &ctx) != CNF2_OK) {
-        fprintf(stderr, "cnf2_ctx_create: %s\n", cnf2_last_error(nullptr));
-        abort();
+    if (opt.gpus < 1 || opt.gpus > 64) {
+        fprintf(stderr, "--gpus must be between 1 and 64\n");
+        return 2;
     }
-    EngineOptions eo;
-    eo.quiet = opt.quiet;
-    eo.merge_modes = opt.merge_modes;
-    eo.normalise = opt.normalise;
-    eo.update = opt.update;
-    eo.dump_all = opt.dump_all;
     // main() trims dous only after postmarkerdata (cnF2freq.cpp:8083, 8124); the analysed list is fixed at upload here,
     // and postmarkerdata does not read it
     if ((int)P.dous.size() > opt.limit) P.dous.resize(opt.limit);
-    // any failure below the C ABI ends the run the way the reference ends on every failure (cnF2freq.cpp:21-25)
-    try {
-    Engine E(P, ctx, eo);
-    E.upload();
-    if (opt.preprocess) E.postmarkerdata(opt.limit);                 // cnF2freq.cpp:8083-8085
-    if (!opt.deserialize.empty() && !E.deserialize(opt.deserialize.c_str())) {
-        fprintf(stderr, "cannot open %s\n", opt.deserialize.c_str());
+    if (opt.gpus == 1) return run_rank(opt, P, 0, 1, nullptr);
+
+    // N ranks: the region and the fork come before any HIP call of this process
+    ShmRegion* region = shm_region_create(opt.gpus, (size_t)64 << 20);
+    if (!region) {
+        fprintf(stderr, "cannot map the shared region of %d ranks\n", opt.gpus);
         abort();
     }
-
-    FILE* out = stdout;
-    if (!opt.output.empty()) out = fopen(opt.output.c_str(), "w");
-    if (!out) { fprintf(stderr, "cannot open output\n"); abort(); }
-
-    for (int it = 0; it < opt.count; it++) {
-        const bool early = it < 1;                       // cnF2freq.cpp:8131
-        if (!early) {
-            E.set_print_rows(opt.rows_all || it == opt.count - 1);
-            E.iteration((it == opt.count - 1) ? out : stdout);
+    fflush(stdout);
+    fflush(stderr);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < opt.gpus; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            perror("fork");
+            for (pid_t k : kids) kill(k, SIGKILL);
+            abort();
         }
-        fflush(stdout);
-        fflush(out);
-        if (opt.dump_all || it == opt.count - 1) E.dump(out, opt.limit);
-        fflush(stdout);
-        fflush(out);
+        if (pid == 0) {
+            const int rc = run_rank(opt, P, r, opt.gpus, region);
+            fflush(stdout);
+            fflush(stderr);
+            _exit(rc);
+        }
+        kids.push_back(pid);
     }
-    if (out != stdout) fclose(out);
-    } catch (const EngineError& e) {
-        fprintf(stderr, "%s\n", e.what());
-        abort();
+    // a rank that fails would leave the others waiting at a barrier: the first failure ends them all
+    int failed = 0;
+    for (size_t left = kids.size(); left > 0; left--) {
+        int         st = 0;
+        const pid_t pid = wait(&st);
+        if (pid < 0) break;
+        if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0) && !failed) {
+            failed = 1;
+            fprintf(stderr, "a rank ended abnormally: stopping the others\n");
+            for (pid_t k : kids)
+                if (k != pid) kill(k, SIGKILL);
+        }
     }
-    cnf2_ctx_destroy(ctx);
+    if (failed) abort();                                  // the reference ends every failure this way (cnF2freq.cpp:21-25)
     return 0;
 }

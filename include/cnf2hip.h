@@ -304,6 +304,9 @@ int    cnf2_exchange_buffer(cnf2_ctx *ctx, size_t bytes, void **d_buf);
  * GPU support); a device-aware transport (RCCL) works on the buffer in place */
 int    cnf2_exchange_download(cnf2_ctx *ctx, void *host_dst, size_t bytes);
 int    cnf2_exchange_upload(cnf2_ctx *ctx, const void *host_src, size_t bytes);
+/* ... and any byte range of it (transports that stage the buffer in chunks: the shared-memory transport of `cnF2freq --gpus N`) */
+int    cnf2_exchange_read(cnf2_ctx *ctx, size_t offset, void *host_dst, size_t bytes);
+int    cnf2_exchange_write(cnf2_ctx *ctx, size_t offset, const void *host_src, size_t bytes);
 size_t cnf2_packed_accumulator_doubles(const cnf2_ctx *ctx);
 size_t cnf2_packed_row_bytes(const cnf2_ctx *ctx);
 int    cnf2_pack_accumulators(cnf2_ctx *ctx, const int32_t *recs, int n, double *d_packed);
