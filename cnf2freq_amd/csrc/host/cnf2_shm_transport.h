@@ -59,8 +59,27 @@ struct ShmTransport {
     cnf2_ctx*  ctx = nullptr;
     int        rank = 0;
     size_t     bytes_moved = 0;
+    // where the engine's buffer is: the context's exchange buffer on the device, or (host_buf: the CPU self-test of
+    // tests/shim) plain host memory
+    unsigned char* host_buf = nullptr;
 
     void wait() { pthread_barrier_wait(&R->barrier); }
+    int  xread(size_t offset, void* dst, size_t bytes)
+    {
+        if (host_buf) {
+            memcpy(dst, host_buf + offset, bytes);
+            return CNF2_OK;
+        }
+        return cnf2_exchange_read(ctx, offset, dst, bytes);
+    }
+    int xwrite(size_t offset, const void* src, size_t bytes)
+    {
+        if (host_buf) {
+            memcpy(host_buf + offset, src, bytes);
+            return CNF2_OK;
+        }
+        return cnf2_exchange_write(ctx, offset, src, bytes);
+    }
 
     // every collective works on the engine's exchange buffer (cnf2_exchange_buffer): `buf` is its device address, which
     // cnf2_exchange_read / _write address by offset
@@ -74,7 +93,7 @@ struct ShmTransport {
             const size_t n = std::min(chunk, seg - off);
             for (int q = 0; q < W; q++) {
                 // round q: all ranks publish their values of rank q's segment part; rank q sums
-                if (cnf2_exchange_read(ctx, ((size_t)q * seg + off) * sizeof(double), R->slot(rank), n * sizeof(double)) != CNF2_OK) return -1;
+                if (xread(((size_t)q * seg + off) * sizeof(double), R->slot(rank), n * sizeof(double)) != CNF2_OK) return -1;
                 wait();
                 if (q == rank) {
                     acc.assign(n, 0.0);
@@ -82,7 +101,7 @@ struct ShmTransport {
                         const double* v = (const double*)R->slot(r);
                         for (size_t i = 0; i < n; i++) acc[i] += v[i];
                     }
-                    if (cnf2_exchange_write(ctx, ((size_t)q * seg + off) * sizeof(double), acc.data(), n * sizeof(double)) != CNF2_OK) return -1;
+                    if (xwrite(((size_t)q * seg + off) * sizeof(double), acc.data(), n * sizeof(double)) != CNF2_OK) return -1;
                 }
                 wait();
                 bytes_moved += n * sizeof(double);
@@ -96,10 +115,10 @@ struct ShmTransport {
         const int W = R->world;
         for (size_t off = 0; off < seg; off += R->slot_bytes) {
             const size_t n = std::min(R->slot_bytes, seg - off);
-            if (cnf2_exchange_read(ctx, (size_t)rank * seg + off, R->slot(rank), n) != CNF2_OK) return -1;
+            if (xread((size_t)rank * seg + off, R->slot(rank), n) != CNF2_OK) return -1;
             wait();
             for (int r = 0; r < W; r++)
-                if (r != rank && cnf2_exchange_write(ctx, (size_t)r * seg + off, R->slot(r), n) != CNF2_OK) return -1;
+                if (r != rank && xwrite((size_t)r * seg + off, R->slot(r), n) != CNF2_OK) return -1;
             wait();
             bytes_moved += n;
         }

@@ -21,6 +21,24 @@ TRAJ_CASES = GOLDEN_CASES + ["outbred3_two_chrom", "ail_ties"]
 TRAJ_CASES_LONG = ["outbred3_long"]
 
 
+def build_host_shim():
+    """tests/shim/libcnf2hostshim.so: the product's host-side headers (emission tables, window derivation, accumulator
+    algebra, update math, the partition plan, the executable's shared-memory transport) behind a C interface for the CPU
+    tests.  Linked against libcnf2hip.so for the two C-ABI calls the transport's device path names (never made here)."""
+    import ctypes
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    csrc = os.path.join(ROOT, "cnf2freq_amd", "csrc")
+    pkg = os.path.join(ROOT, "cnf2freq_amd")
+    so = os.path.join(shim_dir, "libcnf2hostshim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                           "-o", so, os.path.join(shim_dir, "host_shim.cpp"), os.path.join(csrc, "cnf2_window.cpp"),
+                           "-L" + pkg, "-lcnf2hip", "-Wl,-rpath," + pkg, "-lpthread"])
+    return ctypes.CDLL(so)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

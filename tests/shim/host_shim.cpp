@@ -29,6 +29,9 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
 #include "cnf2_update.h"
 #include "cnf2_variance.h"
 #include "host/cnf2_partition.h"
+#include "host/cnf2_shm_transport.h"
+#include <sys/wait.h>
+#include <unistd.h>
 
 extern "C" {
 
@@ -72,6 +75,58 @@ int shim_partition(int n_rec, const int32_t* par, const uint8_t* empty, const in
         }
     }
     return seg;
+}
+
+// The shared-memory transport of `cnF2freq --gpus N` (csrc/host/cnf2_shm_transport.h) on HOST buffers: `world` forked ranks run
+// the reduce-scatter, the all-gather, the hit-counter sum and a barrier on seeded data with slots of `slot_bytes` (small slots
+// force the chunked path) and check what they receive; returns the number of ranks that failed.
+int shim_shm_transport_selftest(int world, int seg_doubles, int seg_bytes, int slot_bytes)
+{
+    using namespace cnf2host;
+    ShmRegion* R = shm_region_create(world, (size_t)slot_bytes);
+    if (!R) return -1;
+    auto value = [](int rank, size_t i) { return (double)((rank + 1) * 1000003 % 9973) + 0.25 * (double)(i % 1000) + (double)i * 1e-3; };
+    std::vector<pid_t> kids;
+    for (int rank = 0; rank < world; rank++) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            ShmTransport T;
+            T.R = R;
+            T.rank = rank;
+            int bad = 0;
+            // reduce-scatter of world x seg_doubles doubles
+            std::vector<double> d((size_t)world * seg_doubles);
+            for (size_t i = 0; i < d.size(); i++) d[i] = value(rank, i);
+            T.host_buf = (unsigned char*)d.data();
+            bad |= ShmTransport::call(&T, X_SUM_SEGMENTS, d.data(), d.size(), (size_t)seg_doubles) != 0;
+            for (int i = 0; i < seg_doubles; i++) {
+                double want = 0;
+                for (int r = 0; r < world; r++) want += value(r, (size_t)rank * seg_doubles + i);
+                bad |= d[(size_t)rank * seg_doubles + i] != want;
+            }
+            // all-gather of world x seg_bytes bytes
+            std::vector<unsigned char> b((size_t)world * seg_bytes, 0);
+            for (int i = 0; i < seg_bytes; i++) b[(size_t)rank * seg_bytes + i] = (unsigned char)(rank * 37 + i * 7);
+            T.host_buf = b.data();
+            bad |= ShmTransport::call(&T, X_GATHER_SEGMENTS, b.data(), b.size(), (size_t)seg_bytes) != 0;
+            for (int r = 0; r < world; r++)
+                for (int i = 0; i < seg_bytes; i++) bad |= b[(size_t)r * seg_bytes + i] != (unsigned char)(r * 37 + i * 7);
+            // hit counters, barrier
+            int32_t h[2] = {rank + 1, 5};
+            bad |= ShmTransport::call(&T, X_SUM_HITS, h, 2, 2) != 0;
+            bad |= h[0] != world * (world + 1) / 2 || h[1] != 5 * world;
+            bad |= ShmTransport::call(&T, X_BARRIER, nullptr, 0, 0) != 0;
+            _exit(bad ? 1 : 0);
+        }
+        kids.push_back(pid);
+    }
+    int failed = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        failed += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+    }
+    return failed;
 }
 
 int shim_founders(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen,

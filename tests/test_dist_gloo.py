@@ -165,6 +165,20 @@ def test_transport_collectives_two_ranks():
     assert q.get(timeout=5) is True and q.get(timeout=5) is True
 
 
+def _shim():
+    from conftest import build_host_shim
+    return build_host_shim()
+
+
+def test_shared_memory_transport_of_the_executable():
+    """The transport of `cnF2freq --gpus N` (csrc/host/cnf2_shm_transport.h: forked ranks, a shared region, a process-shared
+    barrier) on host buffers, world sizes 2, 3 and 8: reduce-scatter, all-gather, hit counters, barrier -- with slots smaller
+    than a segment (the chunked path) and larger."""
+    shim = _shim()
+    for world, seg_d, seg_b, slot in ((2, 1000, 777, 1 << 20), (3, 1000, 777, 512), (8, 64, 4099, 1024), (2, 1, 1, 8)):
+        assert shim.shim_shm_transport_selftest(world, seg_d, seg_b, slot) == 0, (world, seg_d, seg_b, slot)
+
+
 def _plan(shim, ped, world):
     import ctypes as C
     P = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -183,15 +197,8 @@ def test_partition_keeps_families_whole_and_shares_only_what_straddles():
     three-generation families -- must give blocks that cut between families: nothing shared, nothing to exchange.  A
     pedigree in which every cut splits a family (two big half-sib families) must share exactly the records both sides'
     windows touch, each owned by one of its touchers; the F2 design shares its two founders."""
-    import subprocess
-    import ctypes as C
     from cnf2freq_amd import synth
-    shim_dir = os.path.join(ROOT, "tests", "shim")
-    csrc = os.path.join(ROOT, "cnf2freq_amd", "csrc")
-    so = os.path.join(shim_dir, "libcnf2hostshim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + csrc, "-o", so,
-                           os.path.join(shim_dir, "host_shim.cpp"), os.path.join(csrc, "cnf2_window.cpp")])
-    shim = C.CDLL(so)
+    shim = _shim()
 
     def touched_by(ped, bounds):
         """per rank the records its windows touch: the analysed individual, its parents and grandparents"""

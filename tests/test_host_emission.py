@@ -17,10 +17,8 @@ CSRC = os.path.join(ROOT, "cnf2freq_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def shim():
-    so = os.path.join(SHIM_DIR, "libcnf2hostshim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + CSRC, "-o", so,
-                           os.path.join(SHIM_DIR, "host_shim.cpp"), os.path.join(CSRC, "cnf2_window.cpp")])
-    return C.CDLL(so)
+    from conftest import build_host_shim
+    return build_host_shim()
 
 
 def _p(a):

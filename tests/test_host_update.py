@@ -21,10 +21,8 @@ D = C.c_double
 
 @pytest.fixture(scope="module")
 def shim():
-    so = os.path.join(SHIM_DIR, "libcnf2hostshim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + CSRC, "-o", so,
-                           os.path.join(SHIM_DIR, "host_shim.cpp"), os.path.join(CSRC, "cnf2_window.cpp")])
-    L = C.CDLL(so)
+    from conftest import build_host_shim
+    L = build_host_shim()
     IP = C.POINTER(C.c_int)
     L.shim_cap_step.argtypes = [D, D, D, IP, C.c_int]
     L.shim_cap_step.restype = D

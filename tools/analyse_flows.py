@@ -8,10 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 
-so = os.path.join(ROOT, "tests", "shim", "libcnf2hostshim.so")
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "cnf2freq_amd", "csrc"), "-o", so,
-                       os.path.join(ROOT, "tests", "shim", "host_shim.cpp"), os.path.join(ROOT, "cnf2freq_amd", "csrc", "cnf2_window.cpp")])
-L = C.CDLL(so)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import build_host_shim  # noqa: E402
+L = build_host_shim()
 D = C.c_double
 L.shim_certainty_flow_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, D, C.c_int, D, C.c_int, D, C.c_void_p, C.POINTER(C.c_int), C.POINTER(D), C.POINTER(D)]
 z = np.load(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "flows_sample.npz"))
