@@ -31,6 +31,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def host_cpu_share():
+    """CPUs this process may really use: affinity mask and cgroup quota, not the host's count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def requested_gpus(argv):
     """--gpus N of the command line, read without argparse's exit paths (the full parser runs in the ranks)."""
     for i, a in enumerate(argv):
@@ -56,7 +79,7 @@ def launch_ranks(argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_share() // n)))      # the ranks share this process's CPU quota
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     trace = os.environ.get("CNF2_BENCH_PARENT_TRACE")
@@ -306,29 +329,6 @@ def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warm
             "accumulate_over_sweep": float(np.mean(acc_ms)) / float(min(sweep_ms)),
             "postmarkerdata_s": t_pm, "scalefactor": st["scalefactor"], "last_hits": st["hits"],
             "probe_wall_s": time.perf_counter() - t_all}
-
-
-def host_cpu_share():
-    """CPUs this process may really use: affinity mask and cgroup quota, not the host's count."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
-            else:
-                q = int(txt[0])
-                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, int(q / per + 0.5)))
-        except Exception:
-            pass
-    return n
 
 
 def cpu_baseline(sample_packed, pos, starts, args):

@@ -16,9 +16,11 @@ namespace cnf2host {
 // Threads the host loops may use: the CPUs this process may really run on -- the affinity mask AND the cgroup's CPU quota (a
 // container with 16 CPUs' worth of quota on a 200-thread host must not start 200 threads: they would be throttled to a
 // crawl, and so would everything after them).  OMP_NUM_THREADS, when set, is respected as an upper bound.
+static int g_host_threads = 0;
+void set_host_threads(int n) { g_host_threads = n > 0 ? n : 0; }
 int host_threads()
 {
-    static int n = 0;
+    int& n = g_host_threads;
     if (n > 0) return n;
     int k = 1;
     cpu_set_t set;

@@ -59,8 +59,10 @@ struct EngineError : std::runtime_error {
 enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2, X_BARRIER = 3 };
 typedef int (*ExchangeFn)(void* user, int op, void* buf, size_t count, size_t seg);
 
-// threads the host loops may use: affinity mask and cgroup CPU quota (cnf2_engine.cpp)
-int host_threads();
+// threads the host loops may use: affinity mask and cgroup CPU quota (cnf2_engine.cpp); set_host_threads(n) fixes the number
+// (several ranks of one process group share the CPUs: `cnF2freq --gpus N` gives every rank its N-th), 0 = find out again
+int  host_threads();
+void set_host_threads(int n);
 
 class Engine {
 public:

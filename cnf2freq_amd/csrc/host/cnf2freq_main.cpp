@@ -236,6 +236,8 @@ int main(int argc, char** argv)
         fprintf(stderr, "cannot map the shared region of %d ranks\n", opt.gpus);
         abort();
     }
+    // the ranks share this process's CPUs (affinity mask and cgroup quota): each gets its N-th for its host loops
+    set_host_threads(std::max(1, host_threads() / opt.gpus));
     fflush(stdout);
     fflush(stderr);
     std::vector<pid_t> kids;
