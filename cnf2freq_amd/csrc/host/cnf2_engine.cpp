@@ -262,6 +262,67 @@ static double sureval_from(int what, int /*count*/, double oddsproduct)
 
 void Engine::postmarkerdata(int indcount)
 {
+    const bool multi = part_.world > 1 && exchange_ != nullptr;
+    if (!multi) {
+        postmarkerdata_local(indcount);
+        return;
+    }
+    sync_rows();
+    if (part_.rank == 0) {
+        const int saved = host_threads();
+        if (root_threads_ > 0) set_host_threads(root_threads_);
+        postmarkerdata_local(indcount);
+        set_host_threads(saved);
+    }
+    broadcast_state();
+}
+
+// rank 0's rows, descendant counts and lock positions to every rank (host memory, in slabs), then up to the devices
+void Engine::broadcast_state()
+{
+    const int    R = (int)P.inds.size();
+    const size_t per = (size_t)M * 26;
+    const int    slab = (int)std::max<size_t>(1, ROW_SLAB_BYTES / per);
+    std::vector<unsigned char> buf((size_t)std::min(R, slab) * per);
+    for (int r0 = 0; r0 < R; r0 += slab) {
+        const int k = std::min(slab, R - r0);
+        if (part_.rank == 0)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+            for (int r = 0; r < k; r++) {
+                const Individual& I = P.inds[r0 + r];
+                unsigned char*    q = buf.data() + (size_t)r * per;
+                memcpy(q, I.sure.data(), (size_t)M * 16);
+                memcpy(q + (size_t)M * 16, I.hw.data(), (size_t)M * 8);
+                memcpy(q + (size_t)M * 24, I.allele.data(), (size_t)M * 2);
+            }
+        exchange(X_BCAST_HOST, buf.data(), (size_t)k * per, 0, "the broadcast of the rows after postmarkerdata");
+        if (part_.rank != 0)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+            for (int r = 0; r < k; r++) {
+                Individual&          I = P.inds[r0 + r];
+                const unsigned char* q = buf.data() + (size_t)r * per;
+                memcpy(I.sure.data(), q, (size_t)M * 16);
+                memcpy(I.hw.data(), q + (size_t)M * 16, (size_t)M * 8);
+                memcpy(I.allele.data(), q + (size_t)M * 24, (size_t)M * 2);
+            }
+    }
+    std::vector<int32_t> meta((size_t)R + lockstart_.size());
+    if (part_.rank == 0) {
+        std::copy(descendants_.begin(), descendants_.end(), meta.begin());
+        std::copy(lockstart_.begin(), lockstart_.end(), meta.begin() + R);
+    }
+    exchange(X_BCAST_HOST, meta.data(), meta.size() * sizeof(int32_t), 0, "the broadcast of the descendant counts");
+    if (part_.rank != 0) {
+        std::copy(meta.begin(), meta.begin() + R, descendants_.begin());
+        std::copy(meta.begin() + R, meta.end(), lockstart_.begin());
+        T = Tables();
+        T.dous.assign(P.dous.begin(), P.dous.end());
+        push_rows();
+    }
+}
+
+void Engine::postmarkerdata_local(int indcount)
+{
     sync_rows();                // the genotype inference below works on the host copies of the rows
     const int R = (int)P.inds.size();
     // individuals the reference's loops reach: numbers 1 .. indcount - 1

@@ -55,8 +55,10 @@ struct EngineError : std::runtime_error {
 //                      all segments are filled on every rank (an all-gather)
 //   X_BARRIER          nothing to move: returns when every rank has called it (the rows of the ranks' blocks are spooled to
 //                      files and collected by rank 0, EngineOptions::spool_dir)
+//   X_BCAST_HOST       buf = HOST, `count` bytes: on return every rank holds rank 0's bytes (the state postmarkerdata leaves,
+//                      which rank 0 computes for all)
 // Returns 0 on success.
-enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2, X_BARRIER = 3 };
+enum { X_SUM_SEGMENTS = 0, X_SUM_HITS = 1, X_GATHER_SEGMENTS = 2, X_BARRIER = 3, X_BCAST_HOST = 4 };
 typedef int (*ExchangeFn)(void* user, int op, void* buf, size_t count, size_t seg);
 
 // threads the host loops may use: affinity mask and cgroup CPU quota (cnf2_engine.cpp); set_host_threads(n) fixes the number
@@ -75,8 +77,12 @@ public:
     // wall time of the last iteration by where it went: [0] sweep + accumulators, [1] exchanges, [2] update passes, [3] the rest
     // on the host (bookkeeping, likelihood lines, rows), [4] total; seconds
     const double* last_timing() const { return last_timing_; }
-    // cnF2freq.cpp:3190-3412 as main calls it (CORRECTIONINFERENCE set), for individuals numbered below indcount
+    // cnF2freq.cpp:3190-3412 as main calls it (CORRECTIONINFERENCE set), for individuals numbered below indcount.  In a
+    // multi-process run (set_partition called first) rank 0 does it for all -- the host loops of N ranks would share the
+    // CPUs of one, i.e. take N times as long each -- and broadcasts the rows, descendant counts and lock positions it
+    // leaves (the variances stay on rank 0); set_root_threads(n) lets it use n threads while the others wait
     void postmarkerdata(int indcount);
+    void set_root_threads(int n) { root_threads_ = n; }
     // cnF2freq.cpp:7757-7832; returns false if the file cannot be opened
     bool deserialize(const char* path);
     // one doit<false, genotypereporter>(out, true): rows of every chromosome and analysed individual to `out`
@@ -145,6 +151,9 @@ private:
     bool       update_flags_set_ = false;
     void       exchange(int op, void* buf, size_t count, size_t seg, const char* what);
     void       gather_private_rows();
+    void       postmarkerdata_local(int indcount);
+    void       broadcast_state();
+    int        root_threads_ = 0;
     std::vector<int> pass_hits_;
     int    iteration_no_ = 0;              // iterations run so far (names of the spooled row files)
     double last_timing_[5] = {0, 0, 0, 0, 0};

@@ -139,10 +139,23 @@ struct ShmTransport {
         return 0;
     }
 
+    int bcast_host(unsigned char* h, size_t count)
+    {
+        for (size_t off = 0; off < count; off += R->slot_bytes) {
+            const size_t n = std::min(R->slot_bytes, count - off);
+            if (rank == 0) memcpy(R->slot(0), h + off, n);
+            wait();
+            if (rank != 0) memcpy(h + off, R->slot(0), n);
+            wait();
+        }
+        return 0;
+    }
+
     static int call(void* user, int op, void* buf, size_t count, size_t seg)
     {
         ShmTransport* T = (ShmTransport*)user;
         switch (op) {
+        case X_BCAST_HOST: return T->bcast_host((unsigned char*)buf, count);
         case X_SUM_SEGMENTS: return T->sum_segments(count, seg);
         case X_SUM_HITS: return T->sum_hits((int32_t*)buf, count);
         case X_GATHER_SEGMENTS: return T->gather_segments(count, seg);

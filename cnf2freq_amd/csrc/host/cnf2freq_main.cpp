@@ -127,16 +127,19 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
     try {
     Engine E(P, ctx, eo);
     E.upload();
+    if (world > 1) {
+        T.R = region;
+        T.ctx = ctx;
+        T.rank = rank;
+        E.set_partition(rank, world, ShmTransport::call, &T);
+        E.set_root_threads(host_threads() * world);          // rank 0 infers the genotypes for all while the others wait
+    }
     if (opt.preprocess) E.postmarkerdata(opt.limit);                 // cnF2freq.cpp:8083-8085
     if (!opt.deserialize.empty() && !E.deserialize(opt.deserialize.c_str())) {
         fprintf(stderr, "cannot open %s\n", opt.deserialize.c_str());
         abort();
     }
     if (world > 1) {
-        T.R = region;
-        T.ctx = ctx;
-        T.rank = rank;
-        E.set_partition(rank, world, ShmTransport::call, &T);
         const Partition& Q = E.partition();
         if (rank == 0) {
             size_t xb[4];

@@ -144,7 +144,7 @@ class Transport:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.bytes_moved = 0
-        self.calls = {0: 0, 1: 0, 2: 0, 3: 0}
+        self.calls = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
 
     def __call__(self, op, buf, count, seg):
         import ctypes as C
@@ -154,6 +154,18 @@ class Transport:
             return 0
         if op == H.X_BARRIER:
             dist.barrier()
+            return 0
+        if op == H.X_BCAST_HOST:
+            # host bytes of rank 0 to every rank, in place (through the GPU for nccl, which moves device memory only)
+            t = torch.from_numpy(np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(count,)))
+            if self.backend == "nccl":
+                d = t.to(self.device)
+                dist.broadcast(d, src=0)
+                if self.rank != 0:
+                    t.copy_(d.cpu())
+            else:
+                dist.broadcast(t, src=0)
+            self.bytes_moved += count
             return 0
         if op == H.X_SUM_HITS:
             a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32)), shape=(count,))
@@ -214,11 +226,11 @@ def start_iterations(ped, device=0, has_prior=None, postmarkerdata=True, determi
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     run = host.Run(ped, has_prior=has_prior, quiet=quiet, device=device)
-    if postmarkerdata:
-        run.postmarkerdata()            # replicated: every rank infers the same genotypes from the same rows
     run.transport = Transport(device, run.context())
     run.plan = run.set_partition(rank, world, run.transport)
     run.block = run.plan["block"]
+    if postmarkerdata:
+        run.postmarkerdata()            # rank 0 infers the genotypes for all and broadcasts the rows it leaves
     if deterministic:
         run.set_deterministic(True)
     run.reserve()                       # the rank's batch buffers now, not inside its first iteration

@@ -15,7 +15,7 @@ SYMBOLS = ["cnf2h_create", "cnf2h_create_on", "cnf2h_destroy", "cnf2h_last_error
 
 # int fn(void *user, int op, void *buf, size_t count, size_t seg) -- the transport of a multi-process run (cnf2host.h)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
-X_SUM_SEGMENTS, X_SUM_HITS, X_GATHER_SEGMENTS, X_BARRIER = 0, 1, 2, 3
+X_SUM_SEGMENTS, X_SUM_HITS, X_GATHER_SEGMENTS, X_BARRIER, X_BCAST_HOST = 0, 1, 2, 3, 4
 
 _lib = None
 

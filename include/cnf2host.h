@@ -70,9 +70,12 @@ int cnf2h_get_timing(cnf2h_run *run, double *out5);
  *   CNF2H_X_BARRIER          nothing to move: returns when every rank has called it (used by the `cnF2freq --gpus N`
  *                            executable, whose ranks spool their rows to files for rank 0; runs through this C ABI never
  *                            receive it)
+ *   CNF2H_X_BCAST_HOST       buf = HOST pointer, `count` bytes: on return every rank holds rank 0's bytes (cnf2h_postmarkerdata
+ *                            of a run whose partition is set: rank 0 does the genotype inference for all and broadcasts
+ *                            the rows, descendant counts and lock positions it leaves)
  * 0 = ok.  cnf2freq_amd/dist.py holds the torch.distributed transport (RCCL on the device buffer in place; gloo staged
  * through the host); csrc/host/cnf2_shm_transport.h the one of the executable (forked ranks, staged through shared memory). */
-enum { CNF2H_X_SUM_SEGMENTS = 0, CNF2H_X_SUM_HITS = 1, CNF2H_X_GATHER_SEGMENTS = 2, CNF2H_X_BARRIER = 3 };
+enum { CNF2H_X_SUM_SEGMENTS = 0, CNF2H_X_SUM_HITS = 1, CNF2H_X_GATHER_SEGMENTS = 2, CNF2H_X_BARRIER = 3, CNF2H_X_BCAST_HOST = 4 };
 typedef int (*cnf2h_exchange_fn)(void *user, int op, void *buf, size_t count, size_t seg);
 int cnf2h_set_partition(cnf2h_run *run, int rank, int world, cnf2h_exchange_fn fn, void *user);
 /* the plan in numbers: info[0..1] this rank's block [begin, end); [2] records the rank owns; [3] shared records in all;

@@ -50,7 +50,8 @@ def main():
     np.savez("%s_rank%d.npz" % (prefix, rank), allele=st["allele"], sure=st["sure"], hw=st["hw"], hits=np.array(hits),
              scalefactor=st["scalefactor"], haplobase=ps["haplobase"], haplocount=ps["haplocount"], block=np.array(run.block),
              owned=run.plan["owned"], n_shared=run.plan["n_shared"], bytes_payload=run.plan["bytes_payload"],
-             bytes_moved=run.transport.bytes_moved, calls=np.array([run.transport.calls[k] for k in (0, 1, 2)]))
+             bytes_buffers=run.plan["bytes_accumulators"] + run.plan["bytes_rows"] + run.plan["bytes_hits"],
+             bytes_moved=run.transport.bytes_moved, calls=np.array([run.transport.calls[k] for k in (0, 1, 2, 4)]))
     run.close()
     if dist.is_initialized():
         dist.barrier()

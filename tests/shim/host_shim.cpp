@@ -116,6 +116,12 @@ int shim_shm_transport_selftest(int world, int seg_doubles, int seg_bytes, int s
             bad |= ShmTransport::call(&T, X_SUM_HITS, h, 2, 2) != 0;
             bad |= h[0] != world * (world + 1) / 2 || h[1] != 5 * world;
             bad |= ShmTransport::call(&T, X_BARRIER, nullptr, 0, 0) != 0;
+            // broadcast of rank 0's host bytes
+            std::vector<unsigned char> hb((size_t)seg_bytes * 3 + 5);
+            for (size_t i = 0; i < hb.size(); i++) hb[i] = (unsigned char)(rank == 0 ? i * 13 + 1 : 0xEE);
+            T.host_buf = nullptr;
+            bad |= ShmTransport::call(&T, X_BCAST_HOST, hb.data(), hb.size(), 0) != 0;
+            for (size_t i = 0; i < hb.size(); i++) bad |= hb[i] != (unsigned char)(i * 13 + 1);
             _exit(bad ? 1 : 0);
         }
         kids.push_back(pid);

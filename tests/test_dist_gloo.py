@@ -143,7 +143,11 @@ def _transport_worker(rank, world, port, q):
     hits = np.array([rank + 1, 5], np.int32)
     ok &= T(host.X_SUM_HITS, hits.ctypes.data, 2, 2) == 0
     ok &= hits.tolist() == [world * (world + 1) // 2, 5 * world]
-    ok &= T.calls == {0: 1, 1: 1, 2: 1, 3: 0} and T.bytes_moved == world * seg * 9 + 16
+    # X_BCAST_HOST: rank 0's host bytes to every rank
+    state = (np.arange(1000) * (7 if rank == 0 else 0) % 251).astype(np.uint8)
+    ok &= T(host.X_BCAST_HOST, state.ctypes.data, 1000, 0) == 0
+    ok &= bool(np.array_equal(state, (np.arange(1000) * 7 % 251).astype(np.uint8)))
+    ok &= T.calls == {0: 1, 1: 1, 2: 1, 3: 0, 4: 1} and T.bytes_moved == world * seg * 9 + 16 + 1000
     q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -109,8 +109,10 @@ def test_two_rank_iterations_equal_single_rank(tmp_path):
     assert not own0 & own1 and len(own0 | own1) == R, "every record of this pedigree is touched and owned exactly once"
     # what travelled: 3 iterations x (6 shared records x (48 + 25) B x M in one reduce-scatter and one all-gather, 2 hit counters)
     assert z0["bytes_payload"] == 6 * (M * 48 + ((M * 25 + 7) // 8) * 8) + 2 * 4
-    assert list(z0["calls"]) == [3, 6, 4]          # 3 reduce-scatters, 3 x 2 passes' hit sums, 3 all-gathers + the state's gather
-    assert z0["bytes_moved"] < 0.5 * 3 * R * M * 48, "the exchange must stay far below the full slabs"
+    # 3 reduce-scatters, 3 x 2 passes' hit sums, 3 all-gathers + the state's gather; postmarkerdata ran on rank 0 only and
+    # its result came by 2 broadcasts (the rows in one slab, the descendant counts and lock positions)
+    assert list(z0["calls"]) == [3, 6, 4, 2]
+    assert z0["bytes_buffers"] < 0.5 * R * M * 48, "6 of 36 records are shared here: the buffers are a fraction of the slabs"
     for k in ("allele", "sure", "hw", "hits", "scalefactor"):
         assert np.array_equal(z0[k], z1[k], equal_nan=True), "ranks differ in " + k
     assert np.array_equal(z0["hits"], z["hits"]) and z["hits"].sum() > 0
