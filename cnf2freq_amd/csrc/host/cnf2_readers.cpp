@@ -98,6 +98,53 @@ static double binom_half_pdf(int n, int k)
     return exp(lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0) - n * 0.69314718055994530942);
 }
 
+// The tokens of a genotype file, as fscanf("%254s") delivers them (runs of non-whitespace, cut after 254 characters), read
+// through one large buffer: a genotype file of 25000 individuals x 10000 markers is 250M tokens, and a libc call (or two)
+// per token is half a minute of a run whose 100 iterations take two.
+struct TokenReader {
+    FILE*             in;
+    std::vector<char> buf;
+    size_t            at = 0, end = 0;
+    bool              eof = false;
+    explicit TokenReader(FILE* f) : in(f), buf((size_t)4 << 20) {}
+    static bool space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }       // isspace() of the C locale
+    bool refill()                                                                    // keeps [at, end), appends to it
+    {
+        if (eof) return false;
+        if (at) {
+            memmove(buf.data(), buf.data() + at, end - at);
+            end -= at;
+            at = 0;
+        }
+        const size_t got = fread(buf.data() + end, 1, buf.size() - end, in);
+        end += got;
+        if (!got) eof = true;
+        return got != 0;
+    }
+    // the next token: [tok, tok + n), valid until the next call; false at the end of the file
+    bool next(const char*& tok, size_t& n)
+    {
+        for (;;) {
+            while (at < end && space(buf[at])) at++;
+            if (at < end || !refill()) break;
+        }
+        if (at >= end) return false;
+        size_t e = at;
+        for (;;) {
+            while (e < end && e - at < 254 && !space(buf[e])) e++;
+            if (e < end || e - at >= 254) break;
+            const size_t len = e - at;                                               // the token runs into the buffer's end
+            const bool   more = refill();                                            // moves the token to the front
+            e = at + len;
+            if (!more) break;
+        }
+        tok = buf.data() + at;
+        n = e - at;
+        at = e;
+        return true;
+    }
+};
+
 // cnF2freq.cpp:6542-6667
 bool read_alpha_gen(FILE* in, Pedigree& P)
 {
@@ -108,18 +155,27 @@ bool read_alpha_gen(FILE* in, Pedigree& P)
         P.inds[haplo].allele[x * 2] = P.inds[haplo].allele[x * 2 + 1] = 9;
         P.inds[haplo].sure[x * 2] = P.inds[haplo].sure[x * 2 + 1] = 0.0;
     }
-    char me[255];
-    while (fscanf(in, "%254s", me) == 1) {
-        const int ime = P.getind(me);
+    TokenReader  tokens(in);
+    const char*  tok;
+    size_t       toklen;
+    while (tokens.next(tok, toklen)) {
+        const int ime = P.getind(std::string(tok, toklen));
         if (ime < 0) return false;
         const bool doublehaplo = (P.inds[ime].pars[1] == P.getind("haplo"));
         P.inds[ime].empty = false;
         int data = 0;
         for (size_t x = 0; x < M; x++) {
             char datastr[255];
-            if (fscanf(in, "%254s", datastr) != 1) datastr[0] = 0;
-            int data2 = 0;
-            const int numread = sscanf(datastr, "%d/%d", &data, &data2);
+            int  data2 = 0, numread;
+            if (!tokens.next(tok, toklen)) toklen = 0;
+            if (toklen == 1 && tok[0] >= '0' && tok[0] <= '9') {                      // what nearly every token is
+                data = tok[0] - '0';
+                numread = 1;
+            } else {
+                memcpy(datastr, tok, toklen);
+                datastr[toklen] = 0;
+                numread = sscanf(datastr, "%d/%d", &data, &data2);
+            }
             Individual& I = P.inds[ime];
             I.hw[x] = 0.5;
             if (numread == 1) {                         // cnF2freq.cpp:6565-6588

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -197,8 +198,12 @@ int main(int argc, char** argv)
     if (!opt.genfile.empty()) {
         FILE* f = fopen(opt.genfile.c_str(), "rt");
         fprintf(stderr, "Reading genotype file %s\n", opt.genfile.c_str());
+        const auto t0 = std::chrono::steady_clock::now();
         if (!read_alpha_gen(f, P)) { fprintf(stderr, "cannot read genotypes\n"); abort(); }
         fclose(f);
+        if (getenv("CNF2_TIMING"))
+            fprintf(stderr, "  [read] genotype file                     %.3f s\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     // after ALL files are read: the genotype reader is token based, so capping earlier would misalign
     // it (the reference's own notifier runs before the map exists, cnF2freq.cpp:7965-7969)

@@ -68,3 +68,53 @@ def test_capmarker(exe, tmp_path):
     head, _, inds = parse(exe, tmp_path, ("--capmarker", "5"))
     assert head == "markers 5 chromstarts 0 4 5"
     assert len(inds["A"]["geno"]) == 5
+
+
+def test_genotype_tokens_across_the_read_buffer(exe, tmp_path):
+    """The genotype reader takes its tokens from a 4 MB buffer (cnf2_readers.cpp TokenReader) and must deliver what
+    fscanf("%254s") + sscanf("%d/%d") deliver (cnF2freq.cpp:6551-6563): any run of blanks, tabs, CR and LF separates tokens,
+    a token that is not a number leaves `data` at the previous token's value (it is declared outside the marker loop) and goes
+    down the read-count branch, a file that ends inside a line leaves the rest of the line to that branch too.  8 MB of
+    tokens of every kind, with separators of random width, so that tokens of several characters straddle the buffer's end."""
+    import random
+    rng = random.Random(5)
+    M, N = 3000, 700
+    (tmp_path / "t.map").write_text("\n".join(str(i) for i in range(M)) + "\n")
+    (tmp_path / "t.ped").write_text("")
+    kinds = ["0", "1", "2", "9", "5/1", "1/0", "12", "0/0", "007"]
+    seps = [" ", "  ", "\t", " \t ", "\r\n ", "\n"]
+    expect = {"0": "11/0.02/0.02", "1": "12/0.02/0.02", "2": "22/0.02/0.02", "9": "00/0/0", "12": "00/0/0", "0/0": "00/0/0",
+              "1/0": "11/0/0.5", "007": "00/0/0"}
+    rows, parts = [], []
+    for i in range(N):
+        toks = [rng.choice(kinds) for _ in range(M)]
+        if i == N - 1:
+            toks = toks[:M - 5]                                   # the file ends inside the last line
+        rows.append(toks)
+        parts.append("i%d" % i)
+        for t in toks:
+            parts.append(rng.choice(seps))
+            parts.append(t)
+        parts.append("\r\n" if i < N - 1 else "")
+    blob = "".join(parts).encode()
+    assert len(blob) > (4 << 20) + (2 << 20)                 # at least one refill inside the tokens
+    (tmp_path / "t.gen").write_bytes(blob)
+    _, _, inds = parse(exe, tmp_path)
+    n51 = 0
+    for i, toks in enumerate(rows):
+        got = inds["i%d" % i]["geno"]
+        assert len(got) == M
+        for x, t in enumerate(toks):
+            if t == "5/1":
+                a, s1, s2 = got[x].split("/")
+                assert a == "11" and abs(float(s1) - 0.00212119) < 1e-7 and abs(float(s2) - 0.47464) < 1e-5, (i, x, got[x])
+                n51 += 1
+            else:
+                assert got[x] == expect[t], (i, x, t, got[x])
+    assert n51 > 100000
+    # past the end of the file: sscanf of an empty token reads nothing, `data` stays at the last token's value and data2 is 0
+    last = rows[-1][-1]
+    carried = int(last.split("/")[0])
+    tail = inds["i%d" % (N - 1)]["geno"][M - 5:]
+    assert len(set(tail)) == 1
+    assert (tail[0] == "00/0/0") == (carried == 0)
