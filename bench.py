@@ -733,7 +733,19 @@ def main():
                 traffic = tj.get("bytes_per_launch")
         except Exception:
             traffic = None
-        # size-independent checks on the full output of the last step (outside the timed region):
+        # outside the timed region: the outputs are overwritten with NaN and the sweep is run once more -- the waves of a
+        # launch take their jobs from a counter, and a job nobody took would leave the previous step's (equal) values in
+        # place unnoticed.  Every output must be written again and the likelihoods must equal the timed step's to the bit.
+        ll_timed = loglik.clone()
+        for t in (loglik, dosage, factors):
+            t.fill_(float("nan"))
+        ctx.sweep_device(0, n, factors.data_ptr(), loglik.data_ptr(), dosage.data_ptr(),
+                         (capi.FULL_SPILL if args.full_spill else 0) | args.extra_flags)
+        ctx.sync()
+        every_output_rewritten = bool(torch.equal(loglik, ll_timed) and not torch.isnan(dosage).any().item()
+                                      and not torch.isnan(factors).any().item())
+        del ll_timed
+        # size-independent checks on the full output of that step:
         # every row is a distribution, every likelihood is finite and negative, and the logsumexp
         # identity between per-mode and total likelihoods holds
         rs = dosage.sum(dim=2)
@@ -744,6 +756,7 @@ def main():
             "rows_nonnegative": bool((dosage >= 0).all().item()),
             "loglik_finite_negative": bool((torch.isfinite(loglik) & (loglik < 0)).all().item()),
             "logsumexp_identity": bool(((lse - loglik).abs() < 1e-9 * loglik.abs().clamp(min=1.0)).all().item()),
+            "every_output_rewritten": every_output_rewritten,
         }
         del rs, fmx, lse
         ll = loglik.cpu().numpy()

@@ -23,6 +23,7 @@ UPDATE_BOTH_FLOWS = 1 << 16       # both allele values' certainty flows (the bit
 UPDATE_ONE_SCOUT = 1 << 17        # the certainties' scout in one pass (A/B)
 DETERMINISTIC = 16384
 TURN_VALU = 32768
+STATIC_JOBS = 1 << 18             # wave w sweeps jobs w, w + waves, ... instead of taking jobs from the launch's counter (A/B)
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
 
@@ -247,7 +248,7 @@ class Context:
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
-              merge_modes=False, xpose=False, log_paths=False, ties_general=False):
+              merge_modes=False, xpose=False, log_paths=False, ties_general=False, static_jobs=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
@@ -255,7 +256,7 @@ class Context:
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
         flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
                  | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0)
-                 | (LOG_PATHS if log_paths else 0) | (TIES_GENERAL if ties_general else 0))
+                 | (LOG_PATHS if log_paths else 0) | (TIES_GENERAL if ties_general else 0) | (STATIC_JOBS if static_jobs else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
         out = dict(factors=factors, loglik=loglik, dosage=dos)

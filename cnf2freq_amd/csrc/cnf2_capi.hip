@@ -66,6 +66,8 @@ struct cnf2_ctx {
     int32_t* d_lexp = nullptr;                 // binary exponents of the fast kernel's likelihoods: [n][C][8] then [n][C]
     size_t   lexp_cap = 0;
     unsigned long long* d_clock = nullptr;     // [4] clock stamps of the last plain fast-kernel launch
+    int*     d_jobnext = nullptr;              // [4] job counters of the fast-kernel launches in flight (KernelParams::job_next)
+    size_t   jobnext_cap = 0;
     size_t   clock_cap = 0;
     double* d_scratch = nullptr;     // small parity buffers
     size_t  scratch_cap = 0;
@@ -216,6 +218,7 @@ void cnf2_ctx_destroy(cnf2_ctx* ctx)
     (void)hipFree(ctx->d_loglik);
     (void)hipFree(ctx->d_lexp);
     (void)hipFree(ctx->d_clock);
+    (void)hipFree(ctx->d_jobnext);
     (void)hipFree(ctx->d_dosage);
     (void)hipFree(ctx->d_scratch);
     (void)hipFree(ctx->d_slot_rec);
@@ -540,6 +543,7 @@ static int ready(cnf2_ctx* ctx)
         if ((rc = ensure(ctx, &ctx->d_clock, &ctx->clock_cap, (size_t)4))) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_clock, 0, 4 * sizeof(unsigned long long), ctx->stream));
     }
+    if ((rc = ensure(ctx, &ctx->d_jobnext, &ctx->jobnext_cap, (size_t)4))) return rc;
     return CNF2_OK;
 }
 
@@ -557,6 +561,7 @@ static void base_params(cnf2_ctx* ctx, KernelParams* p)
     p->n_chrom   = ctx->n_chrom;
     p->fexp      = ctx->d_lexp;
     p->lexp      = ctx->d_lexp + ctx->windows.size() * (size_t)ctx->n_chrom * 8;
+    p->job_next  = ctx->d_jobnext;
 }
 
 static int max_chrom_len(const cnf2_ctx* ctx)
@@ -731,6 +736,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     p.dosage       = d_d;
     p.flags        = (want_dosage ? 0 : KP_NO_DOSAGE) | ((flags & CNF2_RAW_DOSAGE) ? KP_RAW_DOSAGE : 0) |
               ((flags & CNF2_NO_TIES) ? KP_NO_TIES : 0);
+    if (flags & CNF2_STATIC_JOBS) p.job_next = nullptr;
     if (flags & CNF2_LOG_PATHS) {
         if ((rc = ensure(ctx, &ctx->d_pathlog, &ctx->pathlog_cap, nl))) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_pathlog, 0xff, nl * sizeof(int32_t), ctx->stream));
@@ -739,6 +745,24 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     }
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (n_general > 0) {
+        // the tied windows' kernel on a second stream with its own spill slots (behind the fast kernel's) and its own job
+        // counter: no ordering between the two kernels.  It is launched FIRST: its jobs are the long ones (a backward pass
+        // per tie combination), and blocks of either kernel that find no room wait and take jobs from their launch's counter
+        // once they get on -- the sweep then ends on the short jobs of the untied windows
+        KernelParams pt = p;
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev0, 0));
+        pt.jobs   = ctx->d_jobs + n_fast;
+        pt.n_jobs = (int)n_general;
+        if (pt.job_next) pt.job_next = ctx->d_jobnext + 1;
+        pt.spill  = ctx->d_spill + (size_t)((n_fast > 0 || n_packed > 0) ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
+        // the tile-producer kernel with a pass per tie combination; the general kernel (one lane per table entry, per-marker
+        // producer) with the full spill and where asked for
+        if ((flags & CNF2_FULL_SPILL) || (flags & CNF2_TIES_GENERAL)) launch_fb(pt, grid_gen, false, ctx->stream2);
+        else launch_fb_fast_tied(pt, grid_gen, ctx->stream2);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));
+    }
     if (n_packed > 0) {
         p.pjobs   = ctx->d_pjobs;
         p.n_pjobs = (int)n_packed;
@@ -754,20 +778,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         p.clock_out = nullptr;
         HIP_TRY(ctx, hipGetLastError());
     }
-    if (n_general > 0) {
-        // second stream, own spill slots behind the fast kernel's: no ordering between the two kernels
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev0, 0));
-        p.jobs   = ctx->d_jobs + n_fast;
-        p.n_jobs = (int)n_general;
-        p.spill  = ctx->d_spill + (size_t)((n_fast > 0 || n_packed > 0) ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
-        // tied windows: the tile-producer kernel with a pass per tie combination; the general kernel (one lane per table
-        // entry, per-marker producer) with the full spill and where asked for
-        if ((flags & CNF2_FULL_SPILL) || (flags & CNF2_TIES_GENERAL)) launch_fb(p, grid_gen, false, ctx->stream2);
-        else launch_fb_fast_tied(p, grid_gen, ctx->stream2);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2, 0));
-    }
+    if (n_general > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
 
@@ -1208,6 +1219,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
 
         KernelParams p;
         base_params(ctx, &p);
+        if (flags & CNF2_STATIC_JOBS) p.job_next = nullptr;
         p.windows      = ctx->d_windows + ind_begin;
         p.spill        = ctx->d_spill;
         p.spill_stride = stride;
@@ -1384,6 +1396,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
     KernelParams p;
     base_params(ctx, &p);
+    if (flags & CNF2_STATIC_JOBS) p.job_next = nullptr;
     p.windows      = ctx->d_windows + ind_begin;
     p.spill        = ctx->d_spill;
     p.spill_stride = stride;

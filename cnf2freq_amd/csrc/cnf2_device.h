@@ -78,6 +78,10 @@ struct KernelParams {
     int32_t*       lexp;
     // [4] or NULL: shader-clock and wall-clock ticks of block 0's first wave (launch_fb_fast: the bench's effective clock)
     unsigned long long* clock_out;
+    // fast kernel: the launch's job counter (zeroed before the launch), from which its waves take their jobs one at a
+    // time -- whichever waves are resident share the list evenly, whatever the jobs' lengths and whenever their blocks
+    // got onto the machine; NULL = wave w sweeps jobs w, w + waves, ...
+    int*           job_next;
 };
 #define CNF2_LEXP_IGNORED (-2147483647 - 1)   /* shift mode not analysed: CNF2_IGNORED_D */
 #define CNF2_LEXP_DEAD    (-2147483647)       /* no likelihood left: CNF2_MINFACTOR_F */

@@ -874,6 +874,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
     __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
     __shared__ __attribute__((aligned(16))) double xlds[XPOSE ? CNF2_WAVES_PER_BLOCK : 1][XPOSE ? 64 * XPOSE_RS : 2];
     __shared__ double tsum[TIED ? CNF2_WAVES_PER_BLOCK : 1][TIED ? 24 : 1];     // TIED: class sums of the tile's markers over the combinations
+    // TIED: beta and the two scale mantissas as they stand at the tile's start ([k][lane]: conflict-free), read back for
+    // every further combination -- 20 registers per lane that would otherwise live (in scratch) across the whole tile
+    __shared__ double tsave[TIED ? CNF2_WAVES_PER_BLOCK : 1][TIED ? 11 * 64 : 1];
 
     const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
@@ -889,7 +892,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         t_wall   = wall_clock64();
     }
 
-    for (int job = wave; job < p.n_jobs; job += nwave) {
+    // the next job of this wave: from the launch's counter (one atomic per job, by lane 0) or, without one, by striding
+    auto take_job = [&](int strided) {
+        if (!p.job_next) return strided;
+        int j = 0;
+        if (fresh_lane() == 0) j = atomicAdd(p.job_next, 1);
+        return __builtin_amdgcn_readfirstlane(j);
+    };
+    for (int job = take_job(wave); job < p.n_jobs; job = take_job(job + nwave)) {
         // the lane number read afresh, as a value the compiler cannot see through: what is derived from it is formed per
         // job, where it is used, instead of being held in registers (or spilled) for the whole kernel
         const int lane = fresh_lane();
@@ -913,6 +923,16 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         if (TIED) hom = 0;
         hom = __builtin_amdgcn_readfirstlane(hom);
         const int n_combo = TIED ? __builtin_amdgcn_readfirstlane(1 << w.n_groups) : 1;
+        // TIED: the tie groups of this lane's three slots (part_forces), one byte each, so that the window itself need not
+        // stay live for the combinations' loop
+        int my_ties = 0;
+        if (TIED) {
+            const bool   hi = (c.part >> 2) != 0, fp = (c.part & 1) != 0;
+            const int8_t tp = hi ? w.tie[4] : w.tie[1];
+            const int8_t ta = hi ? w.tie[5] : w.tie[2], tb = hi ? w.tie[6] : w.tie[3];
+            const int8_t tt = fp ? tb : ta, to = fp ? ta : tb;
+            my_ties = (tp & 255) | ((tt & 255) << 8) | ((to & 255) << 16);
+        }
         if (p.path_log && lane == 0) p.path_log[(size_t)jb.ind * p.n_chrom + jb.chrom] = TIED ? PATH_TIED : hom;
         const int s = lane >> 3;
         c.s0 = s & 1;
@@ -1092,8 +1112,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 // forward step (cnF2freq.cpp:2238-2367); marker m-1 is the previous row of this tile
                 double ep[8];
                 emission_from_row(row - TAB_STRIDE, c, ep);
+                if (!TIED) {                       // (TIED: the 16 registers are needed elsewhere; the even marker forms its own)
 #pragma unroll
-                for (int j = 0; j < 8; j++) S.ec[j] = ep[j];
+                    for (int j = 0; j < 8; j++) S.ec[j] = ep[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) wj[j] = S.am[j] * ep[j];
                 // the normaliser inv(m-1) is a per-chain scalar and everything below is linear in wj:
@@ -1277,21 +1299,31 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
         load_raw<-1>(p, c, first + (ntile - 1) * 8, first, last, &raw);
         for (int t = ntile - 1; t >= 0; t--) {
             const int m0 = first + t * 8;
-            // TIED: the state at the tile's start, restored for every further combination
-            BwdState  S0;
-            int       bmask0 = bmask;
+            // TIED: the state at the tile's start, restored for every combination: beta, the mantissas and the exponents from
+            // LDS, the spill row in flight by asking for it again
+            const int bmask0 = bmask;
+            const bool bdead0 = S.bdead;
             if (TIED) {
-                S0 = S;
-                if (lane < 24) tsum[wib][lane] = 0.0;
+                double* sv = tsave[wib] + lane;
+#pragma unroll
+                for (int j = 0; j < 8; j++) sv[j * 64] = S.b[j];
+                sv[8 * 64] = S.bmant;
+                sv[9 * 64] = S.fmant;
+                sv[10 * 64] = __hiloint2double(S.bexpo, S.fexpo);
+                double zero = 0.0;
+                asm volatile("" : "+v"(zero));          // formed here: the compiler would keep (and spill) a 0.0 for the whole kernel
+                if (lane < 24) tsum[wib][lane] = zero;
             }
           for (int combo = 0; combo < n_combo; combo++) {
             if (TIED) {
-                if (combo > 0) {
-                    S     = S0;
-                    bmask = bmask0;
-                }
                 cur_combo = combo;
-                part_forces(w, c.part, combo, &c.pc);
+                // the spill row of the tile's top marker once more (the first combination has it in flight from the tile
+                // above): asked for here, so that the producer's work covers the latency
+                if (combo > 0) load_row(HALF ? ((((m0 + 7 < last) ? m0 + 7 : last) - first) >> 1) : (((m0 + 7 < last) ? m0 + 7 : last) - first));
+                const int tp = (int8_t)(my_ties & 255), tt = (int8_t)((my_ties >> 8) & 255), to = (int8_t)((my_ties >> 16) & 255);
+                c.pc.force_par = tp < 0 ? -1 : ((combo >> tp) & 1);          // = part_forces(w, c.part, combo, &c.pc)
+                c.pc.force_tr  = tt < 0 ? -1 : ((combo >> tt) & 1);
+                c.pc.force_ot  = to < 0 ? -1 : ((combo >> to) & 1);
             }
 #ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
             if (t == ntile - 1)
@@ -1299,6 +1331,19 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             produce_tile<true, TIED>(p, c, tab, m0, last, raw, hom);
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
+            if (TIED) {
+                // (for the first combination too: nothing of the backward state is then live across the producer, whose tie
+                // form needs the registers)
+                const double* sv = tsave[wib] + lane;
+#pragma unroll
+                for (int j = 0; j < 8; j++) S.b[j] = sv[j * 64];
+                S.bmant = sv[8 * 64];
+                S.fmant = sv[9 * 64];
+                S.bexpo = __double2hiint(sv[10 * 64]);
+                S.fexpo = __double2loint(sv[10 * 64]);
+                S.bdead = bdead0;
+                bmask   = bmask0;
+            }
             int       i    = mend - m0;                 // local index; its parity is the parity of m - first
             if (HALF) {
                 if (!(i & 1)) {                         // an even top marker: only the last tile of a chromosome
@@ -1307,7 +1352,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 }
                 for (; i >= 1; i -= 2) {
                     marker(odd_t(), tab + i * TAB_STRIDE, m0 + i);
-                    marker(even_t(), tab + (i - 1) * TAB_STRIDE, m0 + i - 1, true);
+                    marker(even_t(), tab + (i - 1) * TAB_STRIDE, m0 + i - 1, !TIED);
                 }
             } else {
                 for (; i >= 0; i--) marker(even_t(), tab + i * TAB_STRIDE, m0 + i);
@@ -1316,7 +1361,13 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
             // whole marker loop costs more in registers than the extra latency it hides; measured)
 #ifndef CNF2_X_NOPRODUCE
-            if (t > 0 && combo == n_combo - 1) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
+            // (TIED: the tile's own inputs once more for its next combination, rather than 29 registers held across the
+            // marker loop; the tile's start goes through an empty asm so that the eight addresses are formed here, not kept)
+            if (TIED) {
+                int m0x = (combo < n_combo - 1) ? m0 : m0 - 8;
+                asm volatile("" : "+s"(m0x));
+                if (t > 0 || combo < n_combo - 1) load_raw<-1>(p, c, m0x, first, last, &raw);
+            } else if (t > 0) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
 #endif
             // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
             // of the tile's markers, lane sub == 0 normalises and stores the row
@@ -3418,6 +3469,11 @@ void launch_state_rows(const Stage2Params& q, uint32_t flags, double* out, hipSt
     hipLaunchKernelGGL(state_rows_kernel, dim3(q.len), dim3(64), 0, stream, q, flags, out);
 }
 
+static void zero_job_counter(const KernelParams& p, hipStream_t stream)
+{
+    if (p.job_next) (void)hipMemsetAsync(p.job_next, 0, sizeof(int), stream);
+}
+
 void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(fb_packed_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
@@ -3425,21 +3481,25 @@ void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
 
 void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL((fb_fast_kernel<true, 0, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL((fb_fast_kernel<true, 1, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL((fb_fast_kernel<true, 0, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast(const KernelParams& p, int grid, bool half_spill, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     if (half_spill) hipLaunchKernelGGL(fb_fast_kernel<true>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL(fb_fast_kernel<false>, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
@@ -3453,6 +3513,7 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
 
 void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL((fb_fast_kernel<true, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }
@@ -3462,6 +3523,7 @@ void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)
 }
 void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL((fb_fast_kernel<true, 2>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }

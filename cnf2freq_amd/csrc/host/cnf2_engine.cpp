@@ -1,5 +1,6 @@
 // cnf2_engine.cpp -- see cnf2_engine.h.
 #include "cnf2_engine.h"
+#include "cnf2_text.h"
 #include <chrono>
 
 #include <math.h>
@@ -667,6 +668,24 @@ bool Engine::deserialize(const char* path)
     return true;
 }
 
+// Text output by blocks of individuals: `fill(i, buffer)` forms the text of individual i (any thread), the buffers are
+// written in order.
+template <class F>
+static void write_blocks(FILE* out, int n, F&& fill)
+{
+    const int            T = host_threads(), K = std::max(1, T * 4);
+    std::vector<TextBuf> bufs((size_t)std::min(K, std::max(n, 1)));
+    for (int i0 = 0; i0 < n; i0 += K) {
+        const int nk = std::min(K, n - i0);
+#pragma omp parallel for num_threads(T) schedule(dynamic, 1)
+        for (int k = 0; k < nk; k++) {
+            bufs[k].clear();
+            fill(i0 + k, bufs[k]);
+        }
+        for (int k = 0; k < nk; k++) fwrite(bufs[k].s.data(), 1, bufs[k].n, out);
+    }
+}
+
 void Engine::iteration(FILE* out)
 {
     // CNF2_TIMING=1: wall-clock of the steps of an iteration on stderr (tuning aid)
@@ -758,17 +777,14 @@ void Engine::iteration(FILE* out)
             rows_out = fopen(spool_name(part_.rank).c_str(), "w");
             if (!rows_out) throw EngineError(CNF2_ERR_STATE, "cannot write " + spool_name(part_.rank));
         }
-        for (int j = 0; j < nb && opt.print_rows; j++) {            // cnF2freq.cpp:6183-6188
-            fprintf(rows_out, "%s:%d\n", P.inds[T.dous[b0 + j]].name.c_str(), c + 1);
-            const double ll = loglik[(size_t)j * C + c];
-            const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
-            if (!skipped)
-                for (int m = P.chromstarts[c]; m < P.chromstarts[c + 1]; m++) {
-                    const double* d = &dosage[((size_t)j * M + m) * 3];
-                    fprintf(rows_out, "%.5lf\t%.5lf\t%.5lf\n", d[0], d[1], d[2]);
-                }
-            fprintf(rows_out, "\n");
-        }
+        // cnF2freq.cpp:6183-6188: "%s:%d\n", a line "%.5lf\t%.5lf\t%.5lf\n" per marker, an empty line (the text is formed
+        // by the host's threads, an individual each, and written in order: cnf2_format.h)
+        if (opt.print_rows)
+            write_blocks(rows_out, nb, [&](int j, TextBuf& tb) {
+                const double ll = loglik[(size_t)j * C + c];
+                const bool skipped = (ll != ll) || ll < (double)CNF2_MINFACTOR;     // cnF2freq.cpp:5403
+                rows_text(P.inds[T.dous[b0 + j]].name, c + 1, &dosage[(size_t)j * M * 3], P.chromstarts[c], P.chromstarts[c + 1], skipped, tb);
+            });
         if (spool) {
             if (part_.rank > 0) fclose(rows_out);
             exchange(X_BARRIER, nullptr, 0, 0, "the barrier behind the spooled rows");
@@ -844,23 +860,14 @@ void Engine::iteration(FILE* out)
     iteration_no_++;
 }
 
+// The dump of cnF2freq.cpp:8157-8192 (cnf2_text.h dump_text), formed by the host's threads
 void Engine::dump(FILE* out, int limit)
 {
     sync_rows();
-    for (size_t r = 0; r < P.inds.size(); r++) {
-        const Individual& I = P.inds[r];
-        if (I.n > limit) continue;
-        fprintf(out, "%d %s\n", I.n, I.name.c_str());
-        for (int m = 0; m < M; m++) {
-            if (I.has_prior)
-                fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\t%d\t%d\t%lf\t%lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0,
-                        I.sure[m * 2], I.sure[m * 2 + 1], 0.5, I.prior_allele[m * 2], I.prior_allele[m * 2 + 1],
-                        I.prior_sure[m * 2], I.prior_sure[m * 2 + 1]);
-            else
-                fprintf(out, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0, I.sure[m * 2],
-                        I.sure[m * 2 + 1], 0.5);
-        }
-    }
+    std::vector<int> who;
+    for (size_t r = 0; r < P.inds.size(); r++)
+        if (P.inds[r].n <= limit) who.push_back((int)r);
+    write_blocks(out, (int)who.size(), [&](int k, TextBuf& tb) { dump_text(P.inds[who[k]], M, tb); });
 }
 
 }  // namespace cnf2host

@@ -92,6 +92,11 @@ enum {
     CNF2_TURN_VALU    = 1u << 15, /* cnf2_sweep_turn_scan: the 1 024 dot products per (individual, marker) on the vector ALU (one lane
                                     per pair of shift modes, flips as register renaming) instead of the matrix cores
                                     (v_mfma_f64_16x16x4: a 32 x 32 x 64 product per unit); same sums in another order: cross-check, A/B */
+    CNF2_STATIC_JOBS  = 1u << 18, /* cnf2_sweep, cnf2_sweep_accumulate, cnf2_sweep_turn_scan: wavefront w of a launch sweeps jobs w, w + waves, ...
+                                     instead of taking its jobs one at a time from the launch's counter (the default: whichever
+                                     blocks are resident share the job list evenly, whatever the chromosomes' lengths and
+                                     however the kernels of the tied and the untied windows share the machine).  Same results
+                                     to the bit: a job's arithmetic does not depend on the wave that runs it. */
     CNF2_LOG_PATHS    = 1u << 9, /* cnf2_sweep records which kernel / producer specialisation swept every job (cnf2_last_paths) */
     CNF2_XPOSE        = 1u << 8  /* sweep kernel variant: the three lane-held state bits of the transition are brought into
                                     registers by a transpose through LDS instead of being exchanged by DPP moves (same

@@ -30,6 +30,8 @@ static HostPedigree make_ped(int n_rec, const int32_t* par, const uint8_t* empty
 #include "cnf2_variance.h"
 #include "host/cnf2_partition.h"
 #include "host/cnf2_shm_transport.h"
+#include "host/cnf2_format.h"
+#include "host/cnf2_text.h"
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -80,6 +82,90 @@ int shim_partition(int n_rec, const int32_t* par, const uint8_t* empty, const in
 // The shared-memory transport of `cnF2freq --gpus N` (csrc/host/cnf2_shm_transport.h) on HOST buffers: `world` forked ranks run
 // the reduce-scatter, the all-gather, the hit-counter sum and a barrier on seeded data with slots of `slot_bytes` (small slots
 // force the chunked path) and check what they receive; returns the number of ranks that failed.
+// fmt_fixed (csrc/host/cnf2_format.h) against snprintf("%.Nf") on n values: the number of values whose characters differ
+// (first_bad: index of the first one, -1 if none) and, in *fallbacks, how many took the snprintf route inside fmt_fixed.
+int shim_format_check(const double* v, int n, int decimals, int* first_bad, int* fallbacks)
+{
+    int bad = 0, fb = 0;
+    *first_bad = -1;
+    for (int i = 0; i < n; i++) {
+        char a[512], b[512];
+        char* e = cnf2host::fmt_fixed(a, v[i], decimals);
+        *e = 0;
+        snprintf(b, sizeof(b), "%.*f", decimals, v[i]);
+        if (strcmp(a, b) != 0) {
+            if (!bad) *first_bad = i;
+            bad++;
+        }
+        const double x = fabs(v[i]);
+        if (!(x < 1e9)) fb++;
+        else {
+            static const double P10[10] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+            const double s = x * P10[decimals], off = fabs(s - floor(s) - 0.5);
+            if (!(s < 4.0e15 && off > s * 2.3e-16 + 1e-300)) fb++;
+        }
+    }
+    *fallbacks = fb;
+    return bad;
+}
+// rows_text / dump_text (csrc/host/cnf2_text.h) against the reference's fprintf calls (cnF2freq.cpp:6183-6188, 8157-8192) on
+// one made-up individual of M markers: 0 = both texts identical, 1 = rows differ, 2 = dump differs, 3 = both
+int shim_text_check(int M, const double* dosage, const double* hw, const unsigned char* allele, const double* sure,
+                    const unsigned char* prior_allele, const double* prior_sure, int has_prior, int n, const char* name)
+{
+    using namespace cnf2host;
+    Individual I;
+    I.n = n;
+    I.name = name;
+    I.hw.assign(hw, hw + M);
+    I.allele.assign(allele, allele + 2 * M);
+    I.sure.assign(sure, sure + 2 * M);
+    I.has_prior = has_prior != 0;
+    if (has_prior) {
+        I.prior_allele.assign(prior_allele, prior_allele + 2 * M);
+        I.prior_sure.assign(prior_sure, prior_sure + 2 * M);
+    }
+    int     bad = 0;
+    TextBuf tb;
+    char*   mem = nullptr;
+    size_t  len = 0;
+    for (int skipped = 0; skipped < 2; skipped++) {
+        FILE* f = open_memstream(&mem, &len);
+        fprintf(f, "%s:%d\n", name, 7);
+        if (!skipped)
+            for (int m = 1; m < M; m++) fprintf(f, "%.5lf\t%.5lf\t%.5lf\n", dosage[m * 3], dosage[m * 3 + 1], dosage[m * 3 + 2]);
+        fprintf(f, "\n");
+        fclose(f);
+        tb.clear();
+        rows_text(I.name, 7, dosage, 1, M, skipped != 0, tb);
+        if (tb.n != len || memcmp(tb.s.data(), mem, len) != 0) bad |= 1;
+        free(mem);
+    }
+    FILE* f = open_memstream(&mem, &len);
+    fprintf(f, "%d %s\n", I.n, I.name.c_str());
+    for (int m = 0; m < M; m++) {
+        if (I.has_prior)
+            fprintf(f, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\t%d\t%d\t%lf\t%lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0,
+                    I.sure[m * 2], I.sure[m * 2 + 1], 0.5, I.prior_allele[m * 2], I.prior_allele[m * 2 + 1], I.prior_sure[m * 2],
+                    I.prior_sure[m * 2 + 1]);
+        else
+            fprintf(f, "%f\t%d\t%d\t\t%f\t%lf %lf %lf\n", I.hw[m], I.allele[m * 2], I.allele[m * 2 + 1], 0.0, I.sure[m * 2],
+                    I.sure[m * 2 + 1], 0.5);
+    }
+    fclose(f);
+    tb.clear();
+    dump_text(I, M, tb);
+    if (tb.n != len || memcmp(tb.s.data(), mem, len) != 0) bad |= 2;
+    free(mem);
+    return bad;
+}
+int shim_format_int(int v, char* out)
+{
+    char* e = cnf2host::fmt_int(out, v);
+    *e = 0;
+    return (int)(e - out);
+}
+
 int shim_shm_transport_selftest(int world, int seg_doubles, int seg_bytes, int slot_bytes)
 {
     using namespace cnf2host;

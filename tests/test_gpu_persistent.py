@@ -218,3 +218,41 @@ def test_accumulator_invariants_at_full_chromosome_length(capi):
     # the rows that come with it are distributions
     assert np.allclose(got["dosage"].sum(axis=2), 1.0, atol=1e-12)
     ctx.close()
+
+
+def test_jobs_from_the_counter_equal_strided_jobs_on_unequal_chromosomes(capi):
+    """The waves of a sweep launch take their jobs one at a time from the launch's counter (KernelParams::job_next); with
+    CNF2_STATIC_JOBS wave w sweeps jobs w, w + waves, ...  A job's arithmetic does not depend on the wave that runs it: both
+    forms must agree to the bit, on one block (every wave takes many jobs) and on the full grid, for tied and untied
+    windows over chromosomes of very different lengths -- and with the oracle."""
+    ped = synth.make_ail(6, 24, 3, 10, 3, seed=17, chrom_cm=60.0, missing=0.05)
+    # chromosomes of 11, 11, 11 markers -> cut the map into 3 + 7 + 23
+    cs = np.array([0, 3, 10, 33], np.int32)
+    assert ped.n_markers == 33
+    ped.chromstarts = cs
+    pos = np.asarray(ped.pos, float).copy()
+    for c in range(3):
+        pos[cs[c]:cs[c + 1]] = np.arange(cs[c + 1] - cs[c]) * 4.0
+    ped.pos = pos
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    n = len(ped.dous)
+    tied = sum(1 for j in range(n) if (ctx.window_info(j)["tie"] >= 0).any())
+    assert tied >= 5 and n - tied >= 20, (tied, n)
+    runs = {}
+    for reserve in (0, ONE_BLOCK):
+        ctx.set_grid_reserve(reserve)
+        for static in (False, True):
+            runs[reserve, static] = ctx.sweep(static_jobs=static)
+    ctx.set_grid_reserve(0)
+    ref = runs[0, True]
+    for key, r in runs.items():
+        for k in ("factors", "loglik", "dosage"):
+            assert np.array_equal(r[k], ref[k]), (key, k)
+    o = oracle_ped(ped)
+    for c in range(3):
+        first, last = int(cs[c]), int(cs[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(ref["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(ref["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
