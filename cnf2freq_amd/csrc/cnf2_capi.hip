@@ -574,6 +574,19 @@ static int max_chrom_len(const cnf2_ctx* ctx)
     return mx;
 }
 
+// The chromosomes in the order their jobs are listed: longest first (ties in map order).  The waves of a launch take the
+// jobs in list order (KernelParams::job_next), so the long jobs start first and a launch ends on the short ones; the jobs of
+// one chromosome keep the order of the individuals, so nothing that adds up over individuals sees a difference.
+static std::vector<int> chrom_order(const cnf2_ctx* ctx)
+{
+    std::vector<int> o(ctx->n_chrom);
+    for (int c = 0; c < ctx->n_chrom; c++) o[c] = c;
+    std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
+        return ctx->chromstarts[a + 1] - ctx->chromstarts[a] > ctx->chromstarts[b + 1] - ctx->chromstarts[b];
+    });
+    return o;
+}
+
 int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, double* loglik_out, double* dosage_out,
                uint32_t flags)
 {
@@ -621,7 +634,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
             }
             const size_t full = el.size() / 4 * 4;
             for (size_t k = 0; k < full; k++) packed[el[k]] = 1;
-            for (int c = 0; c < ctx->n_chrom; c++)
+            for (int c : chrom_order(ctx))
                 for (size_t k = 0; k < full; k += 4) {
                     PackedJob pj;
                     for (int i = 0; i < 4; i++) pj.ind[i] = el[k + i];
@@ -638,7 +651,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     jobs.reserve(n_jobs);
     size_t n_fast = 0;
     for (int pass = 0; pass < 2; pass++) {
-        for (int c = 0; c < ctx->n_chrom; c++)
+        for (int c : chrom_order(ctx))
             for (int j = 0; j < n; j++) {
                 if (merge && packed[j]) continue;
                 const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
@@ -767,7 +780,9 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         p.pjobs   = ctx->d_pjobs;
         p.n_pjobs = (int)n_packed;
         int gp    = (int)((n_packed + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
-        launch_fb_packed(p, gp < grid_fast ? gp : grid_fast, ctx->stream);
+        KernelParams pp = p;
+        if (pp.job_next) pp.job_next = ctx->d_jobnext + 2;    // (the fast kernel behind it on the stream zeroes its own)
+        launch_fb_packed(pp, gp < grid_fast ? gp : grid_fast, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (n_fast > 0) {
@@ -1147,7 +1162,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         std::vector<Job> jobs;
         size_t           n_fast = 0;
         for (int pass = 0; pass < 2; pass++) {
-            for (int c = 0; c < ctx->n_chrom; c++)
+            for (int c : chrom_order(ctx))
                 for (int j = 0; j < n; j++) {
                     const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
                     if (tied != (pass == 1)) continue;
@@ -1281,6 +1296,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 HIP_TRY(ctx, hipGetLastError());
                 q.kp     = p;
                 q.n_jobs = (int)nb;
+                q.max_len = jobs[b0].last - jobs[b0].first + 1;      // the batch's longest job is its first (chrom_order)
                 q.flags  = (q.flags & ~(uint32_t)KP_ACC_LANES) | ((pass == 1 || (flags & CNF2_ACC_LANES)) ? KP_ACC_LANES : 0);
                 launch_acc_rows(q, ctx->stream);
                 HIP_TRY(ctx, hipGetLastError());
@@ -1356,7 +1372,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     std::vector<Job> jobs;
     size_t           n_fast = 0;
     for (int pass = 0; pass < 2; pass++) {
-        for (int c = 0; c < ctx->n_chrom; c++)
+        for (int c : chrom_order(ctx))
             for (int j = 0; j < n; j++) {
                 const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
                 if (tied != (pass == 1)) continue;
@@ -1429,6 +1445,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
             HIP_TRY(ctx, hipGetLastError());
             q.kp     = p;
             q.n_jobs = (int)nb;
+            q.max_len = jobs[b0].last - jobs[b0].first + 1;          // the batch's longest job is its first (chrom_order)
             q.scaled_transitions = fast;
             launch_turn_rows(q, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());

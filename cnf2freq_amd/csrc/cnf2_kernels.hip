@@ -694,7 +694,10 @@ __device__ __forceinline__ void load_raw(const KernelParams& p, const FastCtx& c
 }
 
 // the table row c.mi of the tile from this lane's raw inputs (valid: the row's marker exists)
-template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, bool TIES = false>
+// STRIDE: doubles per table row; KOFF > 0 (tie combinations, second of a pair): only the restricted tables are stored,
+// KOFF doubles behind the first combination's
+template <bool CLASSES, bool HOMPAR = false, bool HOMLEAF = false, bool NORESTR = false, bool TIES = false, int STRIDE = TAB_STRIDE,
+          int KOFF = 0>
 __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool valid, const RawSlots& raw)
 {
     if (valid) {
@@ -703,7 +706,7 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         const Slot tr   = unpack_slot(raw.ap[2], raw.su[2].x, raw.su[2].y, raw.hw[2]);
         const Slot ot   = unpack_slot(raw.ap[3], raw.su[3].x, raw.su[3].y, raw.hw[3]);
         double  cw[2];
-        double* row = tab + c.mi * TAB_STRIDE;
+        double* row = tab + c.mi * STRIDE;
         // entry e = sp*4 + bit_ot*2 + bit_tr goes to table index base + sp*8 + k: k = 0 / 6 for the two
         // diagonal entries, and the two off-diagonal ones swap places with firstpar (part_entry_index); the
         // two lane-dependent offsets are per-job constants, so no value is ever selected.  Entries are stored
@@ -711,11 +714,13 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
         double* rb = row + c.idx_base;
         emtab_part_to<CLASSES, HOMPAR, HOMLEAF, NORESTR, TIES>(c.pc, root, par, tr, ot,
                                [&](int kind, int e, double v) {
+                                   if (KOFF > 0 && kind == 0) return;
                                    const int b  = e & 3;
                                    const int k  = b == 0 ? 0 : (b == 1 ? c.idx_k01 : (b == 2 ? c.idx_k10 : 6));
-                                   rb[(kind == 0 ? 0 : (kind == 1 ? TAB_R : TAB_2)) + (e >> 2) * 8 + k] = v;
+                                   rb[(kind == 0 ? 0 : (kind == 1 ? TAB_R : TAB_2) + KOFF) + (e >> 2) * 8 + k] = v;
                                },
                                cw);
+        if (KOFF > 0) return;
         if ((c.part & 5) == 0) {                    // P == 0, firstpar == 0: one writer per f
             row[TAB_C + c.pc.f * 2 + 0] = cw[0];
             row[TAB_C + c.pc.f * 2 + 1] = cw[1];
@@ -731,18 +736,18 @@ __device__ __forceinline__ void produce_row(const FastCtx& c, double* tab, bool 
 // 3 = no slot of the window is restricted (flag2ignore == 0: a complete window): the restricted table is a
 // copy of the unrestricted one (NORESTR)
 // TIES: the restricted tables of the tie combination whose forces are in c.pc (general form of the producer)
-template <bool CLASSES, bool TIES = false>
+template <bool CLASSES, bool TIES = false, int STRIDE = TAB_STRIDE, int KOFF = 0>
 __device__ __forceinline__ void produce_tile(const KernelParams& p, const FastCtx& c, double* tab, int m0, int last,
                                              const RawSlots& raw, int hom)
 {
     if (TIES) {
-        produce_row<CLASSES, false, false, false, CLASSES>(c, tab, m0 + c.mi <= last, raw);
+        produce_row<CLASSES, false, false, false, CLASSES, STRIDE, KOFF>(c, tab, m0 + c.mi <= last, raw);
         return;
     }
-    if (hom == 2) produce_row<CLASSES, true, true>(c, tab, m0 + c.mi <= last, raw);
-    else if (hom == 1) produce_row<CLASSES, true, false>(c, tab, m0 + c.mi <= last, raw);
-    else if (hom == 3) produce_row<CLASSES, false, false, true>(c, tab, m0 + c.mi <= last, raw);
-    else produce_row<CLASSES, false, false>(c, tab, m0 + c.mi <= last, raw);
+    if (hom == 2) produce_row<CLASSES, true, true, false, false, STRIDE>(c, tab, m0 + c.mi <= last, raw);
+    else if (hom == 1) produce_row<CLASSES, true, false, false, false, STRIDE>(c, tab, m0 + c.mi <= last, raw);
+    else if (hom == 3) produce_row<CLASSES, false, false, true, false, STRIDE>(c, tab, m0 + c.mi <= last, raw);
+    else produce_row<CLASSES, false, false, false, false, STRIDE>(c, tab, m0 + c.mi <= last, raw);
 }
 
 // Raw inputs of one lane of the tile producer's first phase (ONE window member at one marker), requested a
@@ -857,11 +862,13 @@ struct BwdState {
 // with one forward step from the stored even neighbour (same arithmetic, same bits).  Halves the
 // spill traffic for ~15 % more arithmetic.
 // TIED: windows with tie groups (ignoreflag2's all-or-none rule, cnF2freq.cpp:3484-3486).  The forward pass and the beta
-// recursion do not see the rule; the per-locus rows are sums over the tie combinations of class sums taken with that
-// combination's restricted tables.  So every tile of the backward pass is run once per combination -- tables produced
-// with the combination's forces, beta and the scales restored from the tile's start -- and the tile epilogue adds the
-// combinations up before it writes the rows.  A job with n combinations costs one forward and n backward passes of the
-// tile producer's kind instead of the general kernel's per-marker producer (20 x the latency of a job).
+// recursion do not see the rule; the per-locus rows are sums over the tie combinations (2, 4 or 8 of them) of class sums
+// taken with that combination's restricted tables.  A table row holds the restricted tables of TWO combinations; a marker's
+// posterior weights are contracted with both (everything else at the marker is the same for every combination), so a
+// window with one tie group -- most of them -- is swept in one backward pass, one with two groups in two.  Every further
+// pass over a tile starts from the tile's state (beta, scales: kept in LDS; spill row and tile inputs: asked for again)
+// and the tile epilogue adds the passes up before it writes the rows.  The tables are dynamic LDS (84 KB a block, see the
+// declaration): a block shares a CU with a block of the untied windows' kernel, not with another of its own.
 template <bool HALF, int STOREW = 0, bool XPOSE = false, bool TIED = false>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
@@ -871,7 +878,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
     // per lane and k), then [chain][2] = reciprocal normaliser of the (even) marker and, HALF only, of
     // an odd last marker.
     constexpr int ROW = 528;
-    __shared__ __attribute__((aligned(16))) double lds[CNF2_WAVES_PER_BLOCK][8 * TAB_STRIDE];
+    // TIED: the restricted tables of TWO tie combinations per row (the second pair TIE_KOFF doubles behind the first)
+    constexpr int TIE_KOFF = 128;
+    constexpr int TS = TIED ? TAB_STRIDE + TIE_KOFF : TAB_STRIDE;
+    // (TIED: the tables are dynamic LDS, CNF2_TIED_LDS_BYTES at the launch.  With 105 KB of static LDS the compiler concludes
+    // that only one block fits a CU and hands every wave 400 registers -- which keeps the block from sharing a CU with a
+    // block of the untied windows' kernel; what it cannot see it does not count, and the launch bounds' 256 registers stand)
+    __shared__ __attribute__((aligned(16))) double lds[TIED ? 1 : CNF2_WAVES_PER_BLOCK][TIED ? 2 : 8 * TS];
+    extern __shared__ __attribute__((aligned(16))) double lds_tied[];
     __shared__ __attribute__((aligned(16))) double xlds[XPOSE ? CNF2_WAVES_PER_BLOCK : 1][XPOSE ? 64 * XPOSE_RS : 2];
     __shared__ double tsum[TIED ? CNF2_WAVES_PER_BLOCK : 1][TIED ? 24 : 1];     // TIED: class sums of the tile's markers over the combinations
     // TIED: beta and the two scale mantissas as they stand at the tile's start ([k][lane]: conflict-free), read back for
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
     const int wib   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave  = blockIdx.x * CNF2_WAVES_PER_BLOCK + wib;
     const int nwave = gridDim.x * CNF2_WAVES_PER_BLOCK;
-    double*   tab   = lds[wib];
+    double*   tab   = TIED ? lds_tied + wib * (8 * TS) : lds[TIED ? 0 : wib];
     double*   xb    = xlds[XPOSE ? wib : 0];
     double*   spill = p.spill + (size_t)wave * p.spill_stride;
     // shader-clock and wall-clock ticks of the first wave (the bench's effective clock of this very kernel)
@@ -1013,7 +1027,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (t == 0)
 #endif
             {
-                produce_tile<false>(p, c, tab, m0, last, raw, hom);
+                produce_tile<false, false, TS>(p, c, tab, m0, last, raw, hom);
                 if (t + 1 < ntile) load_raw<0>(p, c, m0 + 8, first, last, &raw);   // next tile's inputs, a tile ahead
             }
             wave_lds_fence();
@@ -1021,11 +1035,11 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (HALF) {
                 const int itop = mend - m0;
                 for (int i = 0; i <= itop; i += 2) {
-                    fwd_step(even_t(), tab + i * TAB_STRIDE, m0 + i);
-                    if (i < itop) fwd_step(odd_t(), tab + (i + 1) * TAB_STRIDE, m0 + i + 1);
+                    fwd_step(even_t(), tab + i * TS, m0 + i);
+                    if (i < itop) fwd_step(odd_t(), tab + (i + 1) * TS, m0 + i + 1);
                 }
             } else {
-                for (int m = m0; m <= mend; m++) fwd_step(even_t(), tab + (m - m0) * TAB_STRIDE, m);
+                for (int m = m0; m <= mend; m++) fwd_step(even_t(), tab + (m - m0) * TS, m);
             }
             wave_lds_fence();
         }
@@ -1111,7 +1125,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 // odd marker: alpha-minus(m) = T( alpha-minus(m-1) * e(m-1) * inv(m-1) ), exactly the
                 // forward step (cnF2freq.cpp:2238-2367); marker m-1 is the previous row of this tile
                 double ep[8];
-                emission_from_row(row - TAB_STRIDE, c, ep);
+                emission_from_row(row - TS, c, ep);
                 if (!TIED) {                       // (TIED: the 16 registers are needed elsewhere; the even marker forms its own)
 #pragma unroll
                     for (int j = 0; j < 8; j++) S.ec[j] = ep[j];
@@ -1158,6 +1172,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #ifdef CNF2_X_FUSEDACC   /* timing ablation only (tools/ablate_fused_acc.sh): results are wrong */
             double x_av[2], x_sb[2], x_t0[2], x_t1[2], x_cf[2];
 #endif
+            // TIED: the sums of the pair of tie combinations whose restricted tables the row holds (everything else at this
+            // marker -- the posterior weights wj, the scale -- is the same for every combination)
+#pragma unroll 1
+            for (int ko = 0; ko < (TIED ? 2 * TIE_KOFF : 1); ko += TIE_KOFF)
 #pragma unroll
             for (int f = 0; f < 2; f++) {
                 // the lane's own line (its low bits index that half of the tables) and the line held in the registers:
@@ -1165,10 +1183,10 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 // which the class sums below do not notice: they use n_a1 + n_b1)
                 constexpr bool T = XPOSE && ODD;
                 const int     ia = ((T ? 1 : 0) << 5) | (f << 4) | ((T ? c.s2 : c.s1) << 3) | c.lo;
-                const double* Br = row + TAB_R + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
-                const double* B1 = row + TAB_2 + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
+                const double* Br = row + ko + TAB_R + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
+                const double* B1 = row + ko + TAB_2 + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
                 const double  cf = row[TAB_C + f * 2 + c.s0];
-                const double  av = cf * row[TAB_R + ia], a1 = cf * row[TAB_2 + ia];
+                const double  av = cf * row[ko + TAB_R + ia], a1 = cf * row[ko + TAB_2 + ia];
                 double        sb = 0.0, sb1 = 0.0;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -1314,21 +1332,31 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 asm volatile("" : "+v"(zero));          // formed here: the compiler would keep (and spill) a 0.0 for the whole kernel
                 if (lane < 24) tsum[wib][lane] = zero;
             }
-          for (int combo = 0; combo < n_combo; combo++) {
+          // TIED: the tie combinations two at a time (there are 2, 4 or 8): one pass over the tile per pair
+          for (int combo = 0; combo < n_combo; combo += (TIED ? 2 : 1)) {
+            const int tp = (int8_t)(my_ties & 255), tt = (int8_t)((my_ties >> 8) & 255), to = (int8_t)((my_ties >> 16) & 255);
+            auto forces = [&](int k) {                                       // = part_forces(w, c.part, k, &c.pc)
+                c.pc.force_par = tp < 0 ? -1 : ((k >> tp) & 1);
+                c.pc.force_tr  = tt < 0 ? -1 : ((k >> tt) & 1);
+                c.pc.force_ot  = to < 0 ? -1 : ((k >> to) & 1);
+            };
             if (TIED) {
                 cur_combo = combo;
-                // the spill row of the tile's top marker once more (the first combination has it in flight from the tile
+                // the spill row of the tile's top marker once more (the first pass has it in flight from the tile
                 // above): asked for here, so that the producer's work covers the latency
                 if (combo > 0) load_row(HALF ? ((((m0 + 7 < last) ? m0 + 7 : last) - first) >> 1) : (((m0 + 7 < last) ? m0 + 7 : last) - first));
-                const int tp = (int8_t)(my_ties & 255), tt = (int8_t)((my_ties >> 8) & 255), to = (int8_t)((my_ties >> 16) & 255);
-                c.pc.force_par = tp < 0 ? -1 : ((combo >> tp) & 1);          // = part_forces(w, c.part, combo, &c.pc)
-                c.pc.force_tr  = tt < 0 ? -1 : ((combo >> tt) & 1);
-                c.pc.force_ot  = to < 0 ? -1 : ((combo >> to) & 1);
+                forces(combo);
             }
 #ifdef CNF2_X_NOPRODUCE  /* timing ablation only: results are wrong */
             if (t == ntile - 1)
 #endif
-            produce_tile<true, TIED>(p, c, tab, m0, last, raw, hom);
+            {
+                produce_tile<true, TIED, TS>(p, c, tab, m0, last, raw, hom);
+                if (TIED) {
+                    forces(combo + 1);
+                    produce_tile<true, TIED, TS, TIE_KOFF>(p, c, tab, m0, last, raw, hom);
+                }
+            }
             wave_lds_fence();
             const int mend = (m0 + 7 < last) ? m0 + 7 : last;
             if (TIED) {
@@ -1347,15 +1375,15 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             int       i    = mend - m0;                 // local index; its parity is the parity of m - first
             if (HALF) {
                 if (!(i & 1)) {                         // an even top marker: only the last tile of a chromosome
-                    marker(even_t(), tab + i * TAB_STRIDE, m0 + i);
+                    marker(even_t(), tab + i * TS, m0 + i);
                     i--;
                 }
                 for (; i >= 1; i -= 2) {
-                    marker(odd_t(), tab + i * TAB_STRIDE, m0 + i);
-                    marker(even_t(), tab + (i - 1) * TAB_STRIDE, m0 + i - 1, !TIED);
+                    marker(odd_t(), tab + i * TS, m0 + i);
+                    marker(even_t(), tab + (i - 1) * TS, m0 + i - 1, !TIED);
                 }
             } else {
-                for (; i >= 0; i--) marker(even_t(), tab + i * TAB_STRIDE, m0 + i);
+                for (; i >= 0; i--) marker(even_t(), tab + i * TS, m0 + i);
             }
             wave_lds_fence();
             // next tile's inputs: requested here, before the epilogue's LDS work (holding them across the
@@ -1364,16 +1392,16 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             // (TIED: the tile's own inputs once more for its next combination, rather than 29 registers held across the
             // marker loop; the tile's start goes through an empty asm so that the eight addresses are formed here, not kept)
             if (TIED) {
-                int m0x = (combo < n_combo - 1) ? m0 : m0 - 8;
+                int m0x = (combo + 2 < n_combo) ? m0 : m0 - 8;
                 asm volatile("" : "+s"(m0x));
-                if (t > 0 || combo < n_combo - 1) load_raw<-1>(p, c, m0x, first, last, &raw);
+                if (t > 0 || combo + 2 < n_combo) load_raw<-1>(p, c, m0x, first, last, &raw);
             } else if (t > 0) load_raw<-1>(p, c, m0 - 8, first, last, &raw);
 #endif
             // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
             // of the tile's markers, lane sub == 0 normalises and stores the row
             {
                 const int     mi2 = lane >> 3, sub = lane & 7;
-                const double* red = tab + mi2 * TAB_STRIDE + sub * 8;
+                const double* red = tab + mi2 * TS + sub * 8;
                 double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
                 for (int i2 = 0; i2 < 8; i2++) {
@@ -1400,7 +1428,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 d0 = fmax(d0, 0.0);
                 d1 = fmax(d1, 0.0);
                 d2 = fmax(d2, 0.0);
-                if (sub == 0 && m0 + mi2 <= last && combo == n_combo - 1) {
+                if (sub == 0 && m0 + mi2 <= last && combo + (TIED ? 2 : 1) >= n_combo) {
                     if (!(p.flags & KP_RAW_DOSAGE)) {
                         const double tsum = d0 + d1 + d2;
                         const double inv  = tsum > 0.0 ? 1.0 / tsum : 0.0;
@@ -1475,7 +1503,14 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_packed_kernel(KernelParams p
     double*   tab   = lds[wib];
     double*   spill = p.spill + (size_t)wave * p.spill_stride;
 
-    for (int job = wave; job < p.n_pjobs; job += nwave) {
+    // (jobs from the launch's counter, as in fb_fast_kernel)
+    auto take_job = [&](int strided) {
+        if (!p.job_next) return strided;
+        int j = 0;
+        if (lane == 0) j = atomicAdd(p.job_next, 1);
+        return __builtin_amdgcn_readfirstlane(j);
+    };
+    for (int job = take_job(wave); job < p.n_pjobs; job = take_job(job + nwave)) {
         const PackedJob pj = p.pjobs[job];
         // producer role: part x (marker in tile, job)
         FastCtx c;
@@ -3476,19 +3511,33 @@ static void zero_job_counter(const KernelParams& p, hipStream_t stream)
 
 void launch_fb_packed(const KernelParams& p, int grid, hipStream_t stream)
 {
+    zero_job_counter(p, stream);
     hipLaunchKernelGGL(fb_packed_kernel, dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
 }
 
+// dynamic LDS of the tied instantiations: 8 table rows per wave, each with the restricted tables of two tie combinations
+#define CNF2_TIED_LDS_BYTES (CNF2_WAVES_PER_BLOCK * 8 * (TAB_STRIDE + 128) * (int)sizeof(double))
+template <class K>
+static void allow_tied_lds(K kernel)
+{
+    static bool done = false;        // (per instantiation; more than 64 KB of dynamic LDS has to be asked for once)
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CNF2_TIED_LDS_BYTES);
+        done = true;
+    }
+}
 void launch_fb_fast_tied(const KernelParams& p, int grid, hipStream_t stream)
 {
     zero_job_counter(p, stream);
-    hipLaunchKernelGGL((fb_fast_kernel<true, 0, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    allow_tied_lds(fb_fast_kernel<true, 0, false, true>);
+    hipLaunchKernelGGL((fb_fast_kernel<true, 0, false, true>), dim3(grid), dim3(CNF2_BLOCK), CNF2_TIED_LDS_BYTES, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_tied_w(const KernelParams& p, int grid, hipStream_t stream)
 {
     zero_job_counter(p, stream);
-    hipLaunchKernelGGL((fb_fast_kernel<true, 1, false, true>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    allow_tied_lds(fb_fast_kernel<true, 1, false, true>);
+    hipLaunchKernelGGL((fb_fast_kernel<true, 1, false, true>), dim3(grid), dim3(CNF2_BLOCK), CNF2_TIED_LDS_BYTES, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_fast_xpose(const KernelParams& p, int grid, hipStream_t stream)

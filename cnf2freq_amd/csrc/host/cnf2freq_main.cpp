@@ -164,7 +164,13 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
         }
         fflush(stdout);
         fflush(out);
-        if (opt.dump_all || it == opt.count - 1) E.dump(out, opt.limit);        // (gathers the ranks' rows: every rank calls it)
+        if (opt.dump_all || it == opt.count - 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            E.dump(out, opt.limit);                                              // (gathers the ranks' rows: every rank calls it)
+            if (getenv("CNF2_TIMING") && rank == 0)
+                fprintf(stderr, "  [write] dump of round %-3d                  %.3f s\n", it,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
         fflush(stdout);
         fflush(out);
     }

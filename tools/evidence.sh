@@ -6,6 +6,7 @@
 #   bench    bench lines of every workload (the default line with its iteration probe; ail; outbred), the iteration bench on one
 #            rank and as a 2-rank gloo rehearsal on this one GPU, bench.py --gpus 2 without a launcher
 #   iter     rocprofv3 kernel stats of the iteration probe; CNF2_TIMING laps of config 5's setup and first iterations
+#   cli      the executable on PlantImpute files of 5 000 individuals x 10 004 markers with CNF2_TIMING laps (tools/cli_scale.py)
 #   config5  config 5 end to end, 100 iterations (tools/run_config5.py): ~3 minutes
 #   c4       one of config 4's 8 shards on this GPU: 12 500 individuals x 200 080 markers (80 chromosomes x 2 501), 2 steps
 # Everything lands in gpurun_out/ev_<tag>/; copy what is to be judged into profiles/.
@@ -45,6 +46,10 @@ PY
     cd $R
     CNF2_TIMING=1 timeout -k 10 400 python tools/run_config5.py 2500 2500 4 6 > $o/${tag}_config5_setup_and_6_iterations_timing.log 2>&1; echo "timing exit $?"
     grep "postmarkerdata\|upload\|^iteration" $o/${tag}_config5_setup_and_6_iterations_timing.log | head -20 ;;
+cli)
+    cd $R
+    timeout -k 10 500 python tools/cli_scale.py 500 4 2500 4 4 > $o/${tag}_cli_5000_individuals_x_10004_markers.log 2>&1; echo "cli exit $?"
+    cat $o/${tag}_cli_5000_individuals_x_10004_markers.log | cut -c1-200 ;;
 c4)
     cd $R
     timeout -k 10 600 python bench.py --inds 12500 --chroms 80 --steps 2 --warmup 1 --cpu-seconds 0 --no-iteration-probe --no-merge-probe > $o/${tag}_bench_c4_shard_12500x200080.json.log 2> $o/bench_c4.err; echo "c4 exit $?"; summ $o/${tag}_bench_c4_shard_12500x200080.json.log ;;
