@@ -637,7 +637,7 @@ bool Engine::deserialize(const char* path)
             if (!getline(line)) break;
             double hw, negshift, s1, s2;
             int    a, b;
-            if (sscanf(line.c_str(), "%lf %d %d %lf %lf %lf", &hw, &a, &b, &negshift, &s1, &s2) != 6) {
+            if (parse_dump_line(line.c_str(), &hw, &a, &b, &negshift, &s1, &s2) != 6) {       // = sscanf "%lf %d %d %lf %lf %lf"
                 fprintf(stderr, "Reading haplotype for marker %d for individual %s failed: %s\n", i, I.name.c_str(), line.c_str());
                 continue;
             }

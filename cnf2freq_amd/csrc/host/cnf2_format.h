@@ -70,6 +70,79 @@ inline char* fmt_fixed(char* p, double d, int decimals)
     return p + snprintf(p, 400, "%.*f", decimals, d);       // (a double below 1e9 or not finite: well under 400 characters)
 }
 
+// ---- reading the dump back (Engine::deserialize): a marker's line is read by sscanf(line, "%lf %d %d %lf %lf %lf") in the
+// reference (cnF2freq.cpp:7994-8062), 0.6 us a line.  The numbers a dump holds are plain decimals of a few digits: such a
+// number is (integer of its digits) / 10^(digits behind the point), both exact in a double when the integer is below 2^53
+// and the power at most 10^22, and one IEEE division rounds correctly -- which is what strtod returns.  Anything else in
+// a line (exponents, "nan", hexadecimal floats, more than 18 digits, a field that does not end at a blank) sends the whole
+// line to sscanf.
+inline bool scan_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+inline bool fast_decimal(const char*& p, double* out)
+{
+    static const double P10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    while (scan_space(*p)) p++;
+    bool neg = false;
+    if (*p == '-') {
+        neg = true;
+        p++;
+    } else if (*p == '+') p++;
+    uint64_t v = 0;
+    int      nd = 0, nf = 0;
+    while (*p >= '0' && *p <= '9') {
+        v = v * 10 + (uint64_t)(*p++ - '0');
+        if (++nd > 18) return false;
+    }
+    if (*p == '.') {
+        p++;
+        while (*p >= '0' && *p <= '9') {
+            v = v * 10 + (uint64_t)(*p++ - '0');
+            nf++;
+            if (++nd > 18) return false;
+        }
+    }
+    if (nd == 0 || (*p && !scan_space(*p)) || v >= (1ull << 53)) return false;
+    const double r = nf ? (double)v / P10[nf] : (double)v;
+    *out = neg ? -r : r;
+    return true;
+}
+inline bool fast_int(const char*& p, int* out)
+{
+    while (scan_space(*p)) p++;
+    bool neg = false;
+    if (*p == '-') {
+        neg = true;
+        p++;
+    } else if (*p == '+') p++;
+    int64_t v = 0;
+    int     nd = 0;
+    while (*p >= '0' && *p <= '9') {
+        v = v * 10 + (*p++ - '0');
+        if (++nd > 9) return false;
+    }
+    if (nd == 0 || (*p && !scan_space(*p))) return false;
+    *out = (int)(neg ? -v : v);
+    return true;
+}
+// the fields of a dump line; returns what sscanf(line, "%lf %d %d %lf %lf %lf", ...) returns
+inline int parse_dump_line(const char* line, double* hw, int* a, int* b, double* negshift, double* s1, double* s2)
+{
+    const char* p = line;
+    double      f[4];
+    int         i[2];
+    if (fast_decimal(p, &f[0]) && fast_int(p, &i[0]) && fast_int(p, &i[1]) && fast_decimal(p, &f[1]) && fast_decimal(p, &f[2]) &&
+        fast_decimal(p, &f[3])) {
+        *hw = f[0];
+        *a = i[0];
+        *b = i[1];
+        *negshift = f[1];
+        *s1 = f[2];
+        *s2 = f[3];
+        return 6;
+    }
+    return sscanf(line, "%lf %d %d %lf %lf %lf", hw, a, b, negshift, s1, s2);
+}
+
 // a growing character buffer with room guaranteed before every number
 struct TextBuf {
     std::string s;

@@ -159,6 +159,31 @@ int shim_text_check(int M, const double* dosage, const double* hw, const unsigne
     free(mem);
     return bad;
 }
+// parse_dump_line (csrc/host/cnf2_format.h) against sscanf(line, "%lf %d %d %lf %lf %lf") on `n` NUL-separated lines: the
+// number of lines on which the return value or any converted field differs (bitwise for the doubles)
+int shim_parse_check(const char* lines, int n, int* first_bad, int* fast)
+{
+    int bad = 0;
+    *first_bad = -1;
+    *fast = 0;
+    const char* p = lines;
+    for (int k = 0; k < n; k++) {
+        double fa[4] = {-7, -7, -7, -7}, fb[4] = {-7, -7, -7, -7};
+        int    ia[2] = {-7, -7}, ib[2] = {-7, -7};
+        const int ra = cnf2host::parse_dump_line(p, &fa[0], &ia[0], &ia[1], &fa[1], &fa[2], &fa[3]);
+        const int rb = sscanf(p, "%lf %d %d %lf %lf %lf", &fb[0], &ib[0], &ib[1], &fb[1], &fb[2], &fb[3]);
+        bool same = ra == rb && memcmp(fa, fb, sizeof(fa)) == 0 && memcmp(ia, ib, sizeof(ia)) == 0;
+        if (!same) {
+            if (!bad) *first_bad = k;
+            bad++;
+        }
+        const char* q = p;
+        double      d;
+        if (cnf2host::fast_decimal(q, &d)) (*fast)++;
+        p += strlen(p) + 1;
+    }
+    return bad;
+}
 int shim_format_int(int v, char* out)
 {
     char* e = cnf2host::fmt_int(out, v);

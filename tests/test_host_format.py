@@ -99,3 +99,37 @@ def test_rows_and_dump_text_equal_the_fprintf_rendering(shim, has_prior):
     arrs = [np.ascontiguousarray(a) for a in (dos, hw, allele, sure, pa, ps)]
     rc = shim.shim_text_check(M, *[a.ctypes.data for a in arrs], has_prior, 12345, b"ind_12345_aux_realf")
     assert rc == 0, {1: "rows differ", 2: "dump differs", 3: "rows and dump differ"}[rc]
+
+
+def test_dump_lines_parse_like_sscanf(shim):
+    """Engine::deserialize reads a marker's line of a dump with parse_dump_line (cnf2_format.h) where the reference uses
+    sscanf("%lf %d %d %lf %lf %lf") (cnF2freq.cpp:7994-8062): same return value, same bits in every field -- for what a dump
+    holds ("%f" text), for other spellings of numbers, and for lines that are not a marker's line at all."""
+    shim.shim_parse_check.restype = C.c_int
+    shim.shim_parse_check.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(11)
+    lines = []
+    for _ in range(200000):
+        hw, s1, s2 = rng.random(3)
+        a, b = rng.choice([0, 1, 2, 9], 2)
+        lines.append("%f\t%d\t%d\t\t%f\t%f %f %f\t%d\t%d\t%f\t%f" % (hw, a, b, 0.0, s1, s2, 0.5, 1, 2, 0.02, 0.02))   # a dump's line
+    n_plain = len(lines)
+    def num():
+        k = rng.integers(0, 12)
+        x = rng.random() * 10.0 ** rng.integers(-8, 8)
+        return ["%.17g" % x, "%e" % x, "%.3f" % x, "%d" % int(x), "-%f" % x, "+%.2f" % x, ".5", "5.", "nan", "inf", "0x1p-3",
+                "%.25f" % x][k]
+    for _ in range(100000):
+        sep = [" ", "\t", "  ", " \t"][rng.integers(0, 4)]
+        f = [num(), str(rng.integers(-3, 12)), str(rng.integers(0, 3)), num(), num(), num()]
+        if rng.random() < 0.1:
+            f[rng.integers(0, 6)] = ["x", "1.5.2", "", "12abc", "3e", "99999999999", "1234567890123456789012"][rng.integers(0, 7)]
+        if rng.random() < 0.1:
+            f = f[:rng.integers(0, 6)]
+        lines.append(sep.join(f))
+    lines += ["", " ", "12 G0_1", "abc", "0.5 1 2 0.0 0.02 0.02", "9007199254740993 1 1 0.1 0.2 0.3", "0.000000\t1\t2\t\t0.000000\t0.020000 0.020000 0.500000"]
+    blob = b"\0".join(l.encode() for l in lines) + b"\0"
+    first, fast = C.c_int(), C.c_int()
+    bad = shim.shim_parse_check(blob, len(lines), C.byref(first), C.byref(fast))
+    assert bad == 0, "%d lines differ from sscanf, first: %r" % (bad, lines[first.value])
+    assert fast.value >= n_plain                      # every line of a real dump takes the short cut
