@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files: per-kernel sums (and per-unit values
-when --units is given).  Usage: pmc_summarize.py <dir>... [--units N] [--kernel substr]"""
+"""Summarise rocprofv3 --pmc counter_collection.csv files: per-kernel sums over the dispatches seen (and per-unit values
+when --units, the units of ONE dispatch, is given: sum / dispatches / units).
+Usage: pmc_summarize.py <dir>... [--units N] [--kernel substr]"""
 import collections
 import csv
 import glob
@@ -29,5 +30,5 @@ for d in dirs:
         for k in sorted(agg):
             line = "%-28s %.6g (dispatch rows %d)" % (k, agg[k], n[k])
             if units:
-                line += "   per unit %.4g" % (agg[k] / units)
+                line += "   per unit %.4g" % (agg[k] / n[k] / units)
             print(line)
