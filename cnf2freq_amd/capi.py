@@ -362,7 +362,7 @@ class Context:
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False, table_form=False, lane_form=False,
-                         ties_general=False, deterministic=False):
+                         ties_general=False, deterministic=False, static_jobs=False):
         """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
@@ -379,7 +379,7 @@ class Context:
                                                (0 if ties else NO_TIES) | (RAW_DOSAGE if raw else 0)
                                                | (ACC_TABLE if table_form else 0) | (ACC_LANES if lane_form else 0)
                                                | (TIES_GENERAL if ties_general else 0)
-                                               | (DETERMINISTIC if deterministic else 0)),
+                                               | (DETERMINISTIC if deterministic else 0) | (STATIC_JOBS if static_jobs else 0)),
                   "cnf2_sweep_accumulate")
         return dict(factors=factors, loglik=loglik, dosage=dos, infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
@@ -392,7 +392,8 @@ class Context:
                                                C.c_void_p(d_hb), C.c_void_p(d_hc), C.c_void_p(d_hz),
                                                flags | OUT_DEVICE | ACC_DEVICE), "cnf2_sweep_accumulate")
 
-    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True, ties_general=False, valu=False):
+    def sweep_turn_scan(self, ind_begin=0, ind_end=None, full=True, lse=True, ties=True, ties_general=False, valu=False,
+                        static_jobs=False):
         """Batched turn scan: rawervals [n][M][128][8] and / or their log-sum-exp over the admissible modes [n][M][128]."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
@@ -400,7 +401,7 @@ class Context:
         ls = np.zeros((n, self.n_markers, 128)) if lse else None
         self._chk(self.L.cnf2_sweep_turn_scan(self.h, ind_begin, ind_end, _p(raw) if full else None, _p(ls) if lse else None,
                                               (0 if ties else NO_TIES) | (TIES_GENERAL if ties_general else 0)
-                                              | (TURN_VALU if valu else 0)),
+                                              | (TURN_VALU if valu else 0) | (STATIC_JOBS if static_jobs else 0)),
                   "cnf2_sweep_turn_scan")
         return raw, ls
 

@@ -256,3 +256,31 @@ def test_jobs_from_the_counter_equal_strided_jobs_on_unequal_chromosomes(capi):
         np.testing.assert_allclose(ref["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(ref["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
+
+
+def test_accumulate_and_turn_scan_jobs_from_the_counter_equal_strided_jobs(capi):
+    """The same for the two batched consumers (their sweeps are the accumulate and the turn-scan instantiation of the kernel):
+    CNF2_DETERMINISTIC accumulators (fixed order of addition) and the turn scan's values must not depend on which wave swept
+    which job -- one block, batches of 5 jobs, chromosomes of unequal length, tied and untied windows."""
+    ped = synth.make_ail(6, 24, 3, 10, 3, seed=19, chrom_cm=60.0, missing=0.05)
+    cs = np.array([0, 5, 12, 33], np.int32)
+    ped.chromstarts = cs
+    pos = np.asarray(ped.pos, float).copy()
+    for c in range(3):
+        pos[cs[c]:cs[c + 1]] = np.arange(cs[c + 1] - cs[c]) * 3.0
+    ped.pos = pos
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    desc = ctx.descendants()
+    ctx.set_batch_jobs(5)
+    ctx.set_grid_reserve(ONE_BLOCK)
+    acc = {s: ctx.sweep_accumulate(desc, deterministic=True, static_jobs=s) for s in (False, True)}
+    turn = {s: ctx.sweep_turn_scan(full=False, lse=True, static_jobs=s)[1] for s in (False, True)}
+    ctx.set_grid_reserve(0)
+    ctx.set_batch_jobs(0)
+    for k in ("factors", "loglik", "dosage", "infprobs", "haplobase", "haplocount", "homozyg"):
+        assert np.array_equal(acc[False][k], acc[True][k], equal_nan=True), k
+    assert np.array_equal(turn[False], turn[True], equal_nan=True)
+    o = oracle_ped(ped)
+    _check_accumulators(acc[False], ped, o, desc)
+    ctx.close()
