@@ -574,6 +574,15 @@ static int max_chrom_len(const cnf2_ctx* ctx)
     return mx;
 }
 
+// A batch of the batched consumers is swept by the resident waves in rounds (a wave takes the next job when it has finished
+// one): 6.1 rounds take the time of 7.  When the jobs do not fit one batch, a batch is a whole number of rounds.
+static size_t whole_rounds(size_t batch, size_t n_jobs, int grid_cap)
+{
+    const size_t waves = (size_t)grid_cap * CNF2_WAVES_PER_BLOCK;
+    if (batch >= n_jobs || batch < waves) return batch;
+    return batch / waves * waves;
+}
+
 // The chromosomes in the order their jobs are listed: longest first (ties in map order).  The waves of a launch take the
 // jobs in list order (KernelParams::job_next), so the long jobs start first and a launch ends on the short ones; the jobs of
 // one chromosome keep the order of the individuals, so nothing that adds up over individuals sees a difference.
@@ -1212,6 +1221,7 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the weights of one job (%zu MB)", per_job >> 17);
         if (batch > jobs.size()) batch = jobs.size();
         if (batch > 1000000) batch = 1000000;
+        batch = whole_rounds(batch, jobs.size(), grid_cap);
         if (ctx->batch_jobs > 0 && batch > (size_t)ctx->batch_jobs) batch = (size_t)ctx->batch_jobs;
         {
             // CNF2_TIMING: the first call of a run allocates the batch buffer (up to half the free memory) -- seconds
@@ -1408,6 +1418,7 @@ int cnf2_sweep_turn_scan(cnf2_ctx* ctx, int ind_begin, int ind_end, double* rawe
     if (batch < 1) return fail(ctx, CNF2_ERR_NOMEM, "not enough memory for the alpha/beta rows of one job");
     if (batch > jobs.size()) batch = jobs.size();
     if (batch > 1000000) batch = 1000000;
+    batch = whole_rounds(batch, jobs.size(), grid_cap);
     if (ctx->batch_jobs > 0 && batch > (size_t)ctx->batch_jobs) batch = (size_t)ctx->batch_jobs;
     if ((rc = ensure(ctx, &ctx->d_wbuf, &ctx->wbuf_cap, batch * per_job))) return rc;
     KernelParams p;
