@@ -284,3 +284,33 @@ def test_accumulate_and_turn_scan_jobs_from_the_counter_equal_strided_jobs(capi)
     o = oracle_ped(ped)
     _check_accumulators(acc[False], ped, o, desc)
     ctx.close()
+
+
+def test_tied_windows_on_chromosomes_of_one_two_eight_and_nine_markers(capi):
+    """The tied instantiation runs a tile once per PAIR of tie combinations and restores its state per pass: chromosomes of
+    1, 2, 8, 9 and 13 markers put the tile boundary, the even top marker and the one-marker job under it -- sweep rows and
+    likelihoods and the accumulators of tied and untied windows against the oracle."""
+    ped = synth.make_ail(6, 24, 3, 10, 3, seed=23, chrom_cm=60.0, missing=0.05)
+    cs = np.array([0, 1, 3, 11, 20, 33], np.int32)
+    ped.chromstarts = cs
+    pos = np.asarray(ped.pos, float).copy()
+    for c in range(5):
+        pos[cs[c]:cs[c + 1]] = np.arange(cs[c + 1] - cs[c]) * 5.0
+    ped.pos = pos
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    n = len(ped.dous)
+    groups = [int((ctx.window_info(j)["tie"].max()) + 1) for j in range(n)]
+    assert sum(1 for g in groups if g == 1) >= 3 and sum(1 for g in groups if g >= 2) >= 3, groups   # one pass and several
+    got = ctx.sweep()
+    o = oracle_ped(ped)
+    for c in range(5):
+        first, last = int(cs[c]), int(cs[c + 1]) - 1
+        want = o.sweep_batch(ped.dous, ped.gen[ped.dous], first=first, last=last, mode=2)
+        np.testing.assert_allclose(got["factors"][:, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(got["dosage"][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    desc = ctx.descendants()
+    acc = ctx.sweep_accumulate(desc, deterministic=True)
+    assert np.array_equal(acc["dosage"], got["dosage"]) and np.array_equal(acc["factors"], got["factors"])
+    _check_accumulators(acc, ped, o, desc)
+    ctx.close()
