@@ -2319,23 +2319,37 @@ __global__ __launch_bounds__(256) void addvariance_kernel(KernelParams p, int fi
 
 // fixparents' admissibility test (cnF2freq.cpp:1411-1431) for window y of p.windows at every marker: is there a state i
 // and a path flag2 of parity b with a non-zero emission under shift mode 0, CORRECTIONINFERENCE set?  out[y][m][b].
-// One thread per (marker, parity); the loop ends at the first non-zero value, as the reference's does.
+// One thread per (marker, parity) tries the first paths of state 0, where nearly every admissible genotype is found at
+// once; an item that found nothing there may need all 64 x 64 (state, path) pairs -- as a thread of its own it kept the
+// other 63 lanes of its wavefront waiting for 4 096 evaluations (160 ms of a 5 000-individual set-up) -- so the wavefront
+// takes such items one at a time, lane = state, and stops at the first path for which any state is non-zero.
 __global__ __launch_bounds__(256) void okvals_kernel(KernelParams p, uint8_t* out)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.n_markers * 2) return;
-    const int    m = t >> 1, b = t & 1;
+    const int    t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int    lane = threadIdx.x & 63;
+    const bool   live = t < p.n_markers * 2;
+    const int    m = live ? t >> 1 : 0, b = t & 1;
     const Window w = p.windows[blockIdx.y];
-    uint8_t      ok = 0;
-    for (int i = 0; i < 64 && !ok; i++)
-        for (int flag2 = b; flag2 < 128; flag2 += 2) {
-            const double v = tp_path<4, false, true>(p, w, m, 0, 0, 0.0, (unsigned)(i * 2), flag2, 0, 0, 0.0, nullptr);
-            if (v != 0.0) {
-                ok = 1;
+    bool         ok = false;
+    if (live)
+        for (int flag2 = b; flag2 < 16 && !ok; flag2 += 2)
+            ok = tp_path<4, false, true>(p, w, m, 0, 0, 0.0, 0u, flag2, 0, 0, 0.0, nullptr) != 0.0;
+    unsigned long long pend = __ballot(live && !ok);
+    while (pend) {
+        const int L = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const int mL = __shfl(m, L), bL = __shfl(b, L);
+        bool      found = false;
+        for (int flag2 = bL; flag2 < 128; flag2 += 2) {
+            const double v = tp_path<4, false, true>(p, w, mL, 0, 0, 0.0, (unsigned)(lane * 2), flag2, 0, 0, 0.0, nullptr);
+            if (__ballot(v != 0.0)) {
+                found = true;
                 break;
             }
         }
-    out[((size_t)blockIdx.y * p.n_markers + m) * 2 + b] = ok;
+        if (lane == L) ok = found;
+    }
+    if (live) out[((size_t)blockIdx.y * p.n_markers + m) * 2 + b] = ok ? 1 : 0;
 }
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream)
 {

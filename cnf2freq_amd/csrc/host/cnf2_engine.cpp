@@ -1,5 +1,7 @@
 // cnf2_engine.cpp -- see cnf2_engine.h.
 #include "cnf2_engine.h"
+
+#include <memory>
 #include "cnf2_text.h"
 #include <chrono>
 
@@ -457,7 +459,17 @@ void Engine::postmarkerdata_local(int indcount)
         // what fixparents does to the individual itself: no admissible interpretation at all clears the genotype
         std::vector<size_t> qof(R, (size_t)-1);               // record -> position in recs
         for (size_t q = 0; q < recs.size(); q++) qof[recs[q]] = q;
+        // (rare: the records that have such a marker are found by all threads, then handled in order, messages and all)
+        std::vector<uint8_t> clears(recs.size(), 0);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (size_t q = 0; q < recs.size(); q++) {
+            const uint8_t* o = &ok[q * M * 2];
+            uint8_t        hit = 0;
+            for (int g = 0; g < M && !hit; g++) hit = !o[g * 2] && !o[g * 2 + 1];
+            clears[q] = hit;
+        }
+        for (size_t q = 0; q < recs.size(); q++) {
+            if (!clears[q]) continue;
             Individual& I = P.inds[recs[q]];
             for (int g = 0; g < M; g++)
                 if (!ok[(q * M + g) * 2] && !ok[(q * M + g) * 2 + 1]) {
@@ -502,7 +514,6 @@ void Engine::postmarkerdata_local(int indcount)
         any = 0;
         anyrem = 0;
         struct Fix { int r, g; uint8_t a0, a1; double s0, s1; };
-        std::vector<Fix> fixes;
         // every (record, marker) reads the frozen state only: records in parallel, each thread's corrections appended in
         // record order afterwards (the messages of a run that is not quiet keep their order by running it on one thread)
         std::vector<std::vector<Fix>> fixes_of(recs.size());
@@ -547,19 +558,18 @@ void Engine::postmarkerdata_local(int indcount)
             }
         }
         any = any_sum;
-        for (auto& v : fixes_of) {
-            fixes.insert(fixes.end(), v.begin(), v.end());
-            std::vector<Fix>().swap(v);
-        }
-        for (const Fix& fx : fixes) {
-            Individual& I = P.inds[fx.r];
-            I.allele[fx.g * 2] = fx.a0;
-            I.allele[fx.g * 2 + 1] = fx.a1;
-            I.sure[fx.g * 2] = fx.s0;
-            I.sure[fx.g * 2 + 1] = fx.s1;
-        }
-        for (int r : recs) {
-            Individual& I = P.inds[r];
+        // a record's corrections touch that record only, and every gather above is done: applied record by record, by all
+        // threads (config 5: 57 million of them)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(host_threads())
+        for (size_t q = 0; q < recs.size(); q++) {
+            Individual& I = P.inds[recs[q]];
+            for (const Fix& fx : fixes_of[q]) {
+                I.allele[fx.g * 2] = fx.a0;
+                I.allele[fx.g * 2 + 1] = fx.a1;
+                I.sure[fx.g * 2] = fx.s0;
+                I.sure[fx.g * 2 + 1] = fx.s1;
+            }
+            std::vector<Fix>().swap(fixes_of[q]);
             for (int g = 0; g < M; g++)
                 if (I.allele[g * 2] == SEXMARKER) std::swap(I.allele[g * 2], I.allele[g * 2 + 1]);
         }
@@ -570,8 +580,10 @@ void Engine::postmarkerdata_local(int indcount)
     // variances with the record's own window, founder flags as fixtrees has assigned them so far (cnF2freq.cpp:3373-3389)
     push_rows();
     if (!recs.empty()) {
-        std::vector<double> var(recs.size() * (size_t)M);
-        check(cnf2_variances(ctx, recs.data(), (int)recs.size(), 1, var.data()), "cnf2_variances");
+        // (2 GB at config 5's size: not value-initialised, every element is written by the call)
+        std::unique_ptr<double[]> var(new double[recs.size() * (size_t)M]);
+        check(cnf2_variances(ctx, recs.data(), (int)recs.size(), 1, var.get()), "cnf2_variances");
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (size_t q = 0; q < recs.size(); q++)
             for (int g = 0; g < M; g++) {
                 const double v = var[q * M + g];
@@ -580,7 +592,10 @@ void Engine::postmarkerdata_local(int indcount)
     }
     lap("variances (GPU)");
     // lockhaplos (cnF2freq.cpp:3045-3081): per chromosome, lock the phase at the marker of largest variance
-    for (int r : recs) {
+    // (records are independent; the messages of a run that is not quiet keep their order by running it on one thread)
+#pragma omp parallel for schedule(static) num_threads(host_threads()) if (opt.quiet)
+    for (size_t q = 0; q < recs.size(); q++) {
+        const int   r = recs[q];
         Individual& I = P.inds[r];
         for (int c = 0; c < C; c++) {
             int& ls = lockstart_[(size_t)r * C + c];
