@@ -314,3 +314,24 @@ def test_tied_windows_on_chromosomes_of_one_two_eight_and_nine_markers(capi):
     assert np.array_equal(acc["dosage"], got["dosage"]) and np.array_equal(acc["factors"], got["factors"])
     _check_accumulators(acc, ped, o, desc)
     ctx.close()
+
+
+def test_more_jobs_than_resident_waves_on_the_full_grid(capi):
+    """4 800 jobs on the full grid (2 048 resident waves: every wave takes a second and a third job while others are still
+    on their first): jobs from the counter and strided jobs agree to the bit, a sample of individuals equals the oracle."""
+    ped = synth.make_f2(600, 40, 8, seed=77, chrom_cm=50.0)
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    a = ctx.sweep()
+    b = ctx.sweep(static_jobs=True)
+    for k in ("factors", "loglik", "dosage"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["loglik"]).all() and (np.abs(a["dosage"].sum(axis=2) - 1.0) < 1e-9).all()
+    o = oracle_ped(ped)
+    pick = np.arange(0, 600, 37)
+    for c in (0, 7):
+        first, last = int(ped.chromstarts[c]), int(ped.chromstarts[c + 1]) - 1
+        want = o.sweep_batch(ped.dous[pick], ped.gen[ped.dous[pick]], first=first, last=last, mode=2)
+        np.testing.assert_allclose(a["factors"][pick, c], want["factors"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(a["dosage"][pick][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
+    ctx.close()
