@@ -821,6 +821,10 @@ def main():
                          "effective_clock_mhz": clock_mhz, "sweep_kernel_clock_mhz": sweep_clock_mhz,
                          "fma_probe_clock_mhz": probe_mhz,
                          "valu_per_unit": valu_per_unit, "valu_issue_frac": valu_issue_frac,
+                         # what binds: the vector ALU's issue slots.  `frac` prices SURVEY 8(d)'s textbook bytes (alpha stored
+                         # and reloaded at every marker); the kernel spills every second marker and rebuilds the others, so
+                         # it moves about half of them (frac_physical) and `frac` can pass 1 without HBM being the limit
+                         "binding": "valu_issue",
                          # achieved / frac above are rank 0's launch; every rank's own launch beside it
                          "per_rank": [{"rank": r, "kernel_ms": km, "achieved": float(n) * M * B_UNIT / (km * 1e-3) / 1e9,
                                        "frac": float(n) * M * B_UNIT / (km * 1e-3) / HBM_PEAK,
