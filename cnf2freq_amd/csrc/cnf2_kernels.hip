@@ -1174,8 +1174,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #endif
             // TIED: the sums of the pair of tie combinations whose restricted tables the row holds (everything else at this
             // marker -- the posterior weights wj, the scale -- is the same for every combination)
+            // (turn-scan mode: no rows are asked for -- no class sums, no restricted tables, no epilogue)
 #pragma unroll 1
-            for (int ko = 0; ko < (TIED ? 2 * TIE_KOFF : 1); ko += TIE_KOFF)
+            for (int ko = 0; ko < (STOREW == 2 ? 0 : (TIED ? 2 * TIE_KOFF : 1)); ko += TIE_KOFF)
 #pragma unroll
             for (int f = 0; f < 2; f++) {
                 // the lane's own line (its low bits index that half of the tables) and the line held in the registers:
@@ -1298,10 +1299,12 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             }
             // every lane parks its three class partials in this marker's row (all of it is dead by now:
             // tables, root weights and gap factors have been read); the tile epilogue sums them
-            wave_lds_fence();
-            row[lane]       = q0;
-            row[64 + lane]  = q1;
-            row[128 + lane] = q2;
+            if (STOREW != 2) {
+                wave_lds_fence();
+                row[lane]       = q0;
+                row[64 + lane]  = q1;
+                row[128 + lane] = q2;
+            }
             // beta(m-1) = T( beta(m) * e(m) ); at the first marker the result is never used
 #pragma unroll
             for (int j = 0; j < 8; j++) S.b[j] *= e[j];
@@ -1351,7 +1354,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (t == ntile - 1)
 #endif
             {
-                produce_tile<true, TIED, TS>(p, c, tab, m0, last, raw, hom);
+                produce_tile<STOREW != 2, TIED, TS>(p, c, tab, m0, last, raw, hom);
                 if (TIED) {
                     forces(combo + 1);
                     produce_tile<true, TIED, TS, TIE_KOFF>(p, c, tab, m0, last, raw, hom);
@@ -1399,7 +1402,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #endif
             // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
             // of the tile's markers, lane sub == 0 normalises and stores the row
-            {
+            if (STOREW != 2) {
                 const int     mi2 = lane >> 3, sub = lane & 7;
                 const double* red = tab + mi2 * TS + sub * 8;
                 double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
