@@ -362,8 +362,9 @@ class Context:
         return dict(infprobs=inf, haplobase=hb, haplocount=hc, homozyg=hz)
 
     def sweep_accumulate(self, desc, ind_begin=0, ind_end=None, ties=True, raw=False, table_form=False, lane_form=False,
-                         ties_general=False, deterministic=False, static_jobs=False):
-        """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device."""
+                         ties_general=False, deterministic=False, static_jobs=False, rows=True):
+        """One haplotyping sweep: the outputs of sweep() and the per-record accumulators, batched on the device.
+        rows=False: no dosage pointer is passed (what an iteration that prints no rows does): "dosage" comes back as zeros."""
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         desc = np.ascontiguousarray(desc, np.int32)
@@ -374,7 +375,7 @@ class Context:
         hb = np.zeros((self.n_rec, self.n_markers))
         hc = np.zeros((self.n_rec, self.n_markers))
         hz = np.zeros((n, self.n_markers, 2))
-        self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(factors), _p(loglik), _p(dos),
+        self._chk(self.L.cnf2_sweep_accumulate(self.h, ind_begin, ind_end, _p(desc), _p(factors), _p(loglik), _p(dos) if rows else None,
                                                _p(inf), _p(hb), _p(hc), _p(hz),
                                                (0 if ties else NO_TIES) | (RAW_DOSAGE if raw else 0)
                                                | (ACC_TABLE if table_form else 0) | (ACC_LANES if lane_form else 0)

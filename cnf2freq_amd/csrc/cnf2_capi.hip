@@ -1166,6 +1166,11 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         d_l = ctx->d_loglik;
         d_d = ctx->d_dosage;
     }
+    // A caller that passes no dosage pointer gets no per-locus rows (an iteration that prints none: all but the last of a
+    // run): the sweep then runs in the instantiation that forms none -- no class sums, no restricted tables, no tile
+    // epilogue -- and, since the posterior weights do not see the tie rule, the sweep of the windows with tie groups takes it
+    // as well (their accumulators do see the rule: they stay a pass of their own).
+    const bool want_rows = dosage_out != nullptr;
     if (n > 0) {
         // job list: untied windows (fast kernel) first, tied ones (general kernel) after
         std::vector<Job> jobs;
@@ -1300,8 +1305,9 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
                 p.n_jobs = (int)nb;
                 int grid = (int)((nb + CNF2_WAVES_PER_BLOCK - 1) / CNF2_WAVES_PER_BLOCK);
                 if (grid > grid_cap) grid = grid_cap;
-                if (pass == 0) launch_fb_fast_w(p, grid, ctx->stream);
+                if (pass == 0) launch_fb_fast_w(p, grid, ctx->stream, want_rows);
                 else if (flags & CNF2_TIES_GENERAL) launch_fb_w(p, grid, ctx->stream);
+                else if (!want_rows) launch_fb_fast_w(p, grid, ctx->stream, false);
                 else launch_fb_fast_tied_w(p, grid, ctx->stream);
                 HIP_TRY(ctx, hipGetLastError());
                 q.kp     = p;

@@ -154,7 +154,9 @@ void launch_copy_rows_u8(const uint8_t* src, size_t src_stride, const int32_t* s
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
-void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream);
+// rows = false: the instantiation that forms no per-locus rows (p.dosage is not written; windows with tie groups can take
+// it too: the posterior weights do not see the tie rule)
+void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream, bool rows = true);
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_fast_ab(const KernelParams& p, int grid, hipStream_t stream);
 void launch_fb_ab(const KernelParams& p, int grid, hipStream_t stream);

@@ -873,7 +873,11 @@ template <bool HALF, int STOREW = 0, bool XPOSE = false, bool TIED = false>
 __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 {
     static_assert(!XPOSE || (HALF && STOREW == 0), "the transposing variant exists for the plain half-spill sweep");
-    static_assert(!TIED || (!XPOSE && STOREW != 2), "tie combinations: plain sweep and accumulate mode");
+    // STOREW: 0 plain sweep; 1 accumulate mode (also stores the posterior weights wg); 2 turn-scan mode (stores alpha e, beta
+    // and their scales; no rows); 3 accumulate mode of a call that did not ask for the per-locus rows (wg only)
+    constexpr bool ROWS = STOREW == 0 || STOREW == 1;      // class sums, restricted tables, tile epilogue, p.dosage
+    constexpr bool WG   = STOREW == 1 || STOREW == 3;
+    static_assert(!TIED || (!XPOSE && ROWS), "tie combinations only matter to the rows");
     // Spill row (528 doubles): [k = 0..3][lane][2] = registers 2k, 2k+1 of every lane (one 16-byte access
     // per lane and k), then [chain][2] = reciprocal normaliser of the (even) marker and, HALF only, of
     // an odd last marker.
@@ -1174,9 +1178,9 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #endif
             // TIED: the sums of the pair of tie combinations whose restricted tables the row holds (everything else at this
             // marker -- the posterior weights wj, the scale -- is the same for every combination)
-            // (turn-scan mode: no rows are asked for -- no class sums, no restricted tables, no epilogue)
+            // (no rows asked for: no class sums, no restricted tables, no epilogue)
 #pragma unroll 1
-            for (int ko = 0; ko < (STOREW == 2 ? 0 : (TIED ? 2 * TIE_KOFF : 1)); ko += TIE_KOFF)
+            for (int ko = 0; ko < (!ROWS ? 0 : (TIED ? 2 * TIE_KOFF : 1)); ko += TIE_KOFF)
 #pragma unroll
             for (int f = 0; f < 2; f++) {
                 // the lane's own line (its low bits index that half of the tables) and the line held in the registers:
@@ -1199,7 +1203,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 n_b1 += av * sb1;
                 n_2 += a1 * sb1;
 #ifdef CNF2_X_FUSEDACC
-                if (STOREW == 1) {
+                if (WG) {
                     // the two HOMOZYGOUS probe contractions of phase B: stand-in tables of the same shape in the same row
                     const double* H0 = row + (((T ? 0 : 1) << 5) | (f << 4) | ((T ? c.s1 : c.s2) << 3));
                     double        t0 = 0.0, t1 = 0.0;
@@ -1222,7 +1226,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             double q1 = scale * (n_a1 + n_b1 - 2.0 * n_2);
             double q0 = scale * (n_tot - n_a1 - n_b1 + n_2);
 #ifdef CNF2_X_FUSEDACC
-            if (STOREW == 1 && (!TIED || cur_combo == 0)) {
+            if (WG && (!TIED || cur_combo == 0)) {
                 // phase B of acc_tile_kernel formed here: v (sum over s2), z (over s0 and s2), u (over the 32 lanes of a half)
                 double*   wp = p.wbuf + ((size_t)job * p.wstride + ml) * 160;
                 const int e0 = (c.s1 << 3) | c.lo;
@@ -1261,7 +1265,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
                 if ((lane & 16) == 0) wp[64 + ((lane >> 3) & 1) * 16 + (c.s2 << 3) + (lane & 7)] = h1v;
             }
 #else
-            if (STOREW == 1 && (!TIED || cur_combo == 0)) {
+            if (WG && (!TIED || cur_combo == 0)) {
                 // accumulate mode: wg(s, g) = exp(scales - factor) alphaminus beta for the batched HOT LOOP 2 kernel
                 // (the same in every tie combination)
                 double* wp = p.wbuf + ((size_t)job * p.wstride + ml) * 512;
@@ -1299,7 +1303,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             }
             // every lane parks its three class partials in this marker's row (all of it is dead by now:
             // tables, root weights and gap factors have been read); the tile epilogue sums them
-            if (STOREW != 2) {
+            if (ROWS) {
                 wave_lds_fence();
                 row[lane]       = q0;
                 row[64 + lane]  = q1;
@@ -1354,7 +1358,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
             if (t == ntile - 1)
 #endif
             {
-                produce_tile<STOREW != 2, TIED, TS>(p, c, tab, m0, last, raw, hom);
+                produce_tile<ROWS, TIED, TS>(p, c, tab, m0, last, raw, hom);
                 if (TIED) {
                     forces(combo + 1);
                     produce_tile<true, TIED, TS, TIE_KOFF>(p, c, tab, m0, last, raw, hom);
@@ -1402,7 +1406,7 @@ __global__ __launch_bounds__(CNF2_BLOCK, 2) void fb_fast_kernel(KernelParams p)
 #endif
             // tile epilogue: lanes (marker mi = lane >> 3, eighth sub = lane & 7) add up the 3 x 64 partials
             // of the tile's markers, lane sub == 0 normalises and stores the row
-            if (STOREW != 2) {
+            if (ROWS) {
                 const int     mi2 = lane >> 3, sub = lane & 7;
                 const double* red = tab + mi2 * TS + sub * 8;
                 double        d0 = 0.0, d1 = 0.0, d2 = 0.0;
@@ -3577,10 +3581,11 @@ void launch_row_flags(const uint8_t* allele8, const double2* sure, int n_rows, i
     hipLaunchKernelGGL(row_flags_kernel, dim3(n_rows), dim3(256), 0, stream, allele8, sure, n_markers, flags);
 }
 
-void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream)
+void launch_fb_fast_w(const KernelParams& p, int grid, hipStream_t stream, bool rows)
 {
     zero_job_counter(p, stream);
-    hipLaunchKernelGGL((fb_fast_kernel<true, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    if (rows) hipLaunchKernelGGL((fb_fast_kernel<true, 1>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL((fb_fast_kernel<true, 3>), dim3(grid), dim3(CNF2_BLOCK), 0, stream, p);
     launch_likelihood_logs(p, stream);
 }
 void launch_fb_w(const KernelParams& p, int grid, hipStream_t stream)

@@ -335,3 +335,47 @@ def test_more_jobs_than_resident_waves_on_the_full_grid(capi):
         np.testing.assert_allclose(a["factors"][pick, c], want["factors"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(a["dosage"][pick][:, first:last + 1], want["dosage"], rtol=1e-7, atol=1e-11)
     ctx.close()
+
+
+def test_accumulate_without_rows_gives_the_same_accumulators(capi):
+    """A call that passes no dosage pointer (an iteration that prints no rows) sweeps in the instantiation that forms none,
+    windows with tie groups included (their posterior weights do not see the tie rule; their accumulators, which do, keep
+    their own pass).  Likelihoods equal the with-rows call to the bit; so do the CNF2_DETERMINISTIC accumulators wherever
+    the same sweep kernel is behind them (all windows with the tie rule off, the untied windows with it on); the tied
+    windows' weights come from another instantiation of the kernel (its multiply-adds are fused differently) and agree to
+    rounding.  One block and the full grid, chromosomes of unequal length; the with-rows call against the oracle."""
+    ped = synth.make_ail(6, 24, 3, 10, 3, seed=29, chrom_cm=60.0, missing=0.05)
+    cs = np.array([0, 4, 13, 33], np.int32)
+    ped.chromstarts = cs
+    pos = np.asarray(ped.pos, float).copy()
+    for c in range(3):
+        pos[cs[c]:cs[c + 1]] = np.arange(cs[c + 1] - cs[c]) * 3.0
+    ped.pos = pos
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    n = len(ped.dous)
+    tied = np.array([(ctx.window_info(j)["tie"] >= 0).any() for j in range(n)])
+    assert tied.sum() >= 5 and (~tied).sum() >= 20, (tied.sum(), n)
+    desc = ctx.descendants()
+    keys = ("infprobs", "haplobase", "haplocount", "homozyg")
+    for ties in (False, True):
+        with_rows = ctx.sweep_accumulate(desc, deterministic=True, ties=ties)
+        for reserve in (0, ONE_BLOCK):
+            ctx.set_grid_reserve(reserve)
+            got = ctx.sweep_accumulate(desc, deterministic=True, ties=ties, rows=False)
+            ctx.set_grid_reserve(0)
+            assert not got["dosage"].any()
+            for k in ("factors", "loglik"):
+                assert np.array_equal(got[k], with_rows[k]), (ties, reserve, k)
+            assert np.array_equal(got["homozyg"][~tied], with_rows["homozyg"][~tied], equal_nan=True), (ties, reserve)
+            for k in keys:
+                if not ties:
+                    assert np.array_equal(got[k], with_rows[k], equal_nan=True), (reserve, k)
+                else:
+                    np.testing.assert_allclose(got[k], with_rows[k], rtol=1e-13, atol=1e-300, equal_nan=True, err_msg=k)
+        if ties:
+            _check_accumulators(with_rows, ped, oracle_ped(ped), desc)
+            atomic = ctx.sweep_accumulate(desc, rows=False)             # the default (atomic) accumulators: equal to rounding
+            for k in keys:
+                np.testing.assert_allclose(atomic[k], with_rows[k], rtol=1e-12, atol=1e-14, equal_nan=True, err_msg=k)
+    ctx.close()
