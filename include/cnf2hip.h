@@ -228,7 +228,11 @@ int cnf2_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *de
  * locus through per-line tables (cnf2_acctab.h) and applies homozyg's scale, moveinfprobs and movehaplos with f64
  * atomics.  CNF2_ACC_DEVICE: infprobs / haplobase / haplocount / homozyg are caller-owned device buffers
  * ([n_rec][M][2][2], [n_rec][M], [n_rec][M], [ind_end - ind_begin][M][2]); several GPUs that share ancestors sum
- * the first three with one all-reduce (the reference's reduce calls, cnF2freq.cpp:6245-6254). */
+ * the first three with one all-reduce (the reference's reduce calls, cnF2freq.cpp:6245-6254).
+ * dosage_out == NULL: the per-locus rows are not formed at all (an iteration that prints none, cnF2freq.cpp:6183: all but
+ * the last of a run): the sweep runs in an instantiation without class sums, restricted tables and row epilogue;
+ * likelihoods and accumulators are those of a call with rows (to the bit for windows without tie groups, to rounding
+ * for the others, whose posterior weights then come from another instantiation of the kernel). */
 int cnf2_sweep_accumulate(cnf2_ctx *ctx, int ind_begin, int ind_end, const int32_t *descendants, double *factors_out,
                           double *loglik_out, double *dosage_out, double *infprobs, double *haplobase,
                           double *haplocount, double *homozyg, uint32_t flags);
