@@ -265,7 +265,7 @@ def generate_outbred_on_gpu(n_fam, kids, snps_per_chrom, n_chrom, seed, missing,
     return ped
 
 
-def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warmup=2, timed=3):
+def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warmup=2, timed=3, update_flags=None):
     """BASELINE config 5's unit of work at a fifth of its size, beside the headline (outside every timed region): haplotyping
     iterations (sweep + HOT LOOP 2 accumulators, update passes, step-size control) of a 3-generation outbred pedigree with 20 %
     missing genotypes -- `fams` families x 4 analysed children x `chroms` x `snps_per_chrom` markers -- through libcnf2host.so,
@@ -281,6 +281,8 @@ def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warm
     os.dup2(2, 1)
     try:
         run = host.Run(ped, device=local)
+        if update_flags is not None:
+            run.set_update_flags(update_flags)
         L = capi.load()
         ctx = run.context()
         L.cnf2_set_batch_jobs(ctx, max(1, n * chroms // 4))

@@ -21,6 +21,7 @@ TIES_GENERAL = 4096
 UPDATE_PLAIN = 8192
 UPDATE_BOTH_FLOWS = 1 << 16       # both allele values' certainty flows (the bit-exact form of the fast update kernels)
 UPDATE_ONE_SCOUT = 1 << 17        # the certainties' scout in one pass (A/B)
+UPDATE_LITERAL_FINISH = 1 << 19   # the set-aside flows one literal bisection step per round instead of the guided bisection (A/B)
 DETERMINISTIC = 16384
 TURN_VALU = 32768
 STATIC_JOBS = 1 << 18             # wave w sweeps jobs w, w + waves, ... instead of taking jobs from the launch's counter (A/B)

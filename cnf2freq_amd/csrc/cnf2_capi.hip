@@ -1647,6 +1647,7 @@ static int update_pass_impl(cnf2_ctx* ctx, int chrom, const int32_t* recs, int n
         u.todo_cap = ctx->todo_cap / 3;
         u.scout_passes = (flags & CNF2_UPDATE_ONE_SCOUT) ? 1 : 2;
         u.mirror = (flags & CNF2_UPDATE_BOTH_FLOWS) ? 0 : 1;
+        u.literal_finish = (flags & CNF2_UPDATE_LITERAL_FINISH) ? 1 : 0;
     }
     if (u.n_rec > 0) launch_update_pass(u, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());

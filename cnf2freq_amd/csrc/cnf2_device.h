@@ -143,6 +143,7 @@ struct UpdateParams {
     size_t         todo_cap;      // flows per chunk of a scout = entries of todo
     int            mirror;        // certainties: run one flow per side where both values have evidence, the other is its mirror image
     int            scout_passes;  // certainties: 2 = a short first scout pass and a second for the flows still going; 1 = one pass (A/B)
+    int            literal_finish; // the flows set aside take one literal bisection step per round (rounds 3 / 4) instead of the guided bisection (A/B, cross-check)
     double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };
 void launch_update_pass(const UpdateParams& u, hipStream_t stream);

@@ -513,20 +513,32 @@ CNF2_UHD IntervalFacts flow_interval(const SlopeTerms& s, double xa, double xb, 
     const double qa = s.ev.b * (1.0 - xa) + s.ev.a * xa, qb = s.ev.b * (1.0 - xb) + s.ev.a * xb;
     const double qlo = qa < qb ? qa : qb, qhi = qa < qb ? qb : qa;
     if (!(ulo > 0.0) || !(qlo > 0.0) || !(s.e >= 0.0) || !(s.d >= 0.0)) return F;
-    const double edge = xa < 1.0 - xb ? xa : 1.0 - xb;
-    // |logit(x)| <= -log(min(x, 1 - x)) <= 1 / min(x, 1 - x); and -log(m 2^k) <= -k log 2 for a mantissa m in [1, 2)
-    double lmax;
-    if (fine) {
-        int k;
-        (void)frexp(edge, &k);                               // edge = m' 2^k with m' in [1/2, 1): edge >= 2^(k - 1)
-        lmax = (double)(1 - k) * 0.69314718055994530942;
-    } else {
-        lmax = upd_div(1.0, edge);
-    }
+    // |logit(x)| = log(max(x, 1 - x) / m), m = min(x, 1 - x), is at most |1 - 2 x| / m (log(1 + z) <= z) and at most -log m
+    // <= -k log 2 for m = m' 2^k, m' in [1/2, 1) (fine: one frexp per end; the callers that ask per step do without);
+    // it grows away from 1/2, so its bound on the interval is the larger of the ends'
+    auto logit_bound = [&](double x) CNF2_LI {
+        const double m = x < 1.0 - x ? x : 1.0 - x;
+        double       l = upd_div(fabs(1.0 - 2.0 * x), m);
+        if (fine) {
+            int k;
+            (void)frexp(m, &k);
+            const double l2 = (double)(1 - k) * 0.69314718055994530942;
+            l = l2 < l ? l2 : l;
+        }
+        return l;
+    };
+    const double la = logit_bound(xa), lb = logit_bound(xb);
+    const double lmax = la > lb ? la : lb;
+    // the term 2 a b (a - b) L / Q^3 of -G' counts only where it is negative: (a - b) > 0 and L < 0 (possible left of 1/2:
+    // L >= logit(xa)), or (a - b) < 0 and L > 0 (right of 1/2: L <= logit(xb))
+    const double lneg = s.ev.amb > 0 ? (xa < 0.5 ? la : 0.0) : (xb > 0.5 ? lb : 0.0);
     const double amb = s.ev.amb < 0 ? -s.ev.amb : s.ev.amb;
     const double r_uhi = upd_div(1.0, uhi), r_ulo = upd_div(1.0, ulo), r_qlo = upd_div(1.0, qlo), r_qhi = upd_div(1.0, qhi);
-    // -G' >= e / uhi - (a b / ulo + 2 a b |a - b| lmax / qlo) / qlo^2 + (a - b)^2 / qhi^2 + d num / uhi^2
-    double s1 = s.e * r_uhi - s.ev.ab * (r_ulo + 2.0 * amb * r_qlo * lmax) * (r_qlo * r_qlo) + (s.ev.amb * r_qhi) * (s.ev.amb * r_qhi);
+    // -G' >= (e - a b / qlo^2) / u - 2 a b |a - b| lneg / qlo^3 + (a - b)^2 / qhi^2 + d num / uhi^2: the two terms in 1 / u are
+    // kept together (their coefficient taken at its lowest, then u where that is worst) -- bounded one by one, e / uhi less
+    // a b / (ulo qlo^2), the bound fails for every value next to 0 or 1 whose evidence weighs about what the entropy does
+    const double cu = s.e - s.ev.ab * (r_qlo * r_qlo);
+    double s1 = (cu >= 0.0 ? cu * r_uhi : cu * r_ulo) - s.ev.ab * (2.0 * amb * r_qlo * lneg) * (r_qlo * r_qlo) + (s.ev.amb * r_qhi) * (s.ev.amb * r_qhi);
     double mag = (s.ev.ab * lmax + amb * qhi) * (r_qlo * r_qlo) + s.e * lmax + fabs(s.c0);
     if (s.d != 0.0) {
         const double dist = s.pr < xa ? xa - s.pr : (s.pr > xb ? s.pr - xb : 0.0);
@@ -576,6 +588,56 @@ CNF2_UHD double flow_time_bound(const SlopeTerms& s, double xa, double xb, doubl
         else lo = mid;
     }
     return hi;
+}
+
+// An enclosure of the gradient itself on an interval inside the clamp: G = L (a b / Q^2 - e) + (a - b) / Q + c0 + d W with
+// L = logit in [L(xa), L(xb)], Q between its values at the ends, u = x (1 - x) as above, every term taken at the corner of
+// its box that is worst (the terms are treated as independent: wider than the truth, never narrower).  glo <= G <= ghi on
+// [xa, xb]; lg_a, lg_b: logit at the ends as computed (widened here by their error).  Used where the flow is known to
+// run into its cap: if |G| >= gmin > 0 on the whole bracket, the rule over [start, m] cannot report more than
+// |m - start| / gmin, whatever the gradient does in between.
+struct GradientRange {
+    double glo, ghi;
+};
+CNF2_UHD GradientRange flow_gradient_range(const SlopeTerms& s, double xa, double xb, double lg_a, double lg_b)
+{
+    GradientRange R;
+    R.glo = -HUGE_VAL;
+    R.ghi = HUGE_VAL;
+    const double ua = xa * (1.0 - xa), ub = xb * (1.0 - xb);
+    const double ulo = ua < ub ? ua : ub;
+    const double uhi = (xa <= 0.5 && 0.5 <= xb) ? 0.25 : (ua < ub ? ub : ua);
+    const double qa = s.ev.b * (1.0 - xa) + s.ev.a * xa, qb = s.ev.b * (1.0 - xb) + s.ev.a * xb;
+    const double qlo = qa < qb ? qa : qb, qhi = qa < qb ? qb : qa;
+    if (!(ulo > 0.0) || !(qlo > 0.0) || !(xa < xb) || !isfinite(lg_a) || !isfinite(lg_b)) return R;
+    const double wl = 1e-12 * (1.0 + fabs(lg_a)), wh = 1e-12 * (1.0 + fabs(lg_b));
+    const double llo = lg_a - wl, lhi = lg_b + wh;
+    const double r_qlo = upd_div(1.0, qlo), r_qhi = upd_div(1.0, qhi);
+    const double klo = s.ev.ab * (r_qhi * r_qhi) - s.e, khi = s.ev.ab * (r_qlo * r_qlo) - s.e;
+    const double p1 = llo * klo, p2 = llo * khi, p3 = lhi * klo, p4 = lhi * khi;
+    double plo = p1 < p2 ? p1 : p2, phi = p1 < p2 ? p2 : p1;
+    plo = p3 < plo ? p3 : plo;
+    plo = p4 < plo ? p4 : plo;
+    phi = p3 > phi ? p3 : phi;
+    phi = p4 > phi ? p4 : phi;
+    const double m1 = s.ev.amb * r_qlo, m2 = s.ev.amb * r_qhi;
+    double lo = plo + (m1 < m2 ? m1 : m2) + s.c0, hi = phi + (m1 < m2 ? m2 : m1) + s.c0;
+    if (s.d != 0.0) {
+        const double r_ulo = upd_div(1.0, ulo), r_uhi = upd_div(1.0, uhi);
+        const double na = s.pr - xb, nb = s.pr - xa;              // pr - x in [na, nb]
+        const double w1 = na * r_ulo, w2 = na * r_uhi, w3 = nb * r_ulo, w4 = nb * r_uhi;
+        double wlo = w1 < w2 ? w1 : w2, whi = w1 < w2 ? w2 : w1;
+        wlo = w3 < wlo ? w3 : wlo;
+        wlo = w4 < wlo ? w4 : wlo;
+        whi = w3 > whi ? w3 : whi;
+        whi = w4 > whi ? w4 : whi;
+        lo += s.d * wlo;
+        hi += s.d * whi;
+    }
+    const double mag = fabs(plo) + fabs(phi) + fabs(m1) + fabs(m2) + fabs(s.c0) + fabs(lo) + fabs(hi);
+    R.glo = lo - 1e-12 * mag;
+    R.ghi = hi + 1e-12 * mag;
+    return R;
 }
 
 // ------------------------------------------------------------------ the scout: steps without quadratures, cheaply
@@ -736,6 +798,406 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         f->spared++;
         flow_decide(f, 0.0, scalefactor);
     }
+}
+
+// ------------------------------------------------------------------ the guided bisection: the literal decisions from three quadratures
+// A flow that reaches its step size runs ~10 quadratures in cappedgd: the bisection walks towards the point x* at which the
+// rule reports the step size, and every midpoint on the way costs 16 gradient evaluations to learn "not there yet" or "too
+// far".  Where the gradient is strictly monotone on the bracket (flow_interval: s1 > 0; the flow runs towards an attractor,
+// |G| falls along its way) those verdicts are ordered.  Write f = 1 / |G| (positive and increasing along the way) and
+// R(m) = rule[f] over [start, m]; the rule has positive weights w_i at relative positions 0 < c_i < 1, so
+//     dR/dm = sum_i w_i d/dx[(x - start) f(x)] at the nodes > 0:      R is increasing in m.
+// Hence ONE literal evaluation at a point p is a fact about every midpoint on one side of it:
+//   * the rule reports less than the band [sf (1 - 1e-3), sf (1 + 1e-3)] at p  =>  it does at every midpoint before p
+//     (and the gradient there has the start's sign: it lies between the start's and p's);
+//   * the rule reports more than the band at p, or the gradient has turned round at p  =>  every midpoint beyond p is
+//     "too far" (its gradient has turned round, or the rule reports at least what it reported at p: nodes beyond p see a
+//     smaller |G| than p does; they still see the start's sign when the last node, 0.6 % of the interval before its end,
+//     is clear of the root -- the same condition the time bound above asks for).
+// Rounding: a computed gradient is the true one up to `noise` (flow_interval), so a computed 1 / G at a node is good to
+// noise / |G| <= noise / |G(p)| relatively, and a fact only counts ("solid") when it stands clear of the band by that.
+// The literal bisection is then run as before -- same midpoints, same order, same tests -- but a midpoint that a solid
+// fact covers costs nothing, and the points that ARE evaluated are chosen where they decide most: an estimate of x*
+// (Newton on the rule's own value: dR/dm = 1 / |G(m)| to leading order) is turned into the path the bisection will take,
+// and the path's last three points are evaluated -- the midpoint predicted to land in the band and the two ends of the
+// bracket it halves.  If they come out as predicted every other midpoint of the path is covered: 3 - 4 quadratures instead
+// of ~10.  If they do not, nothing is lost but the evaluation: every result is a fact or (in the band, not solid) a memo of
+// the point itself, the estimate is refined with it, and the bisection goes on; what is never done is take a decision that
+// was not either evaluated literally or implied by such an evaluation.  Flows whose gradient is not (yet) known to be
+// monotone take literal steps, and the test is repeated as their bracket shrinks.
+enum { PT_NONE = 0, PT_NEAR = 1, PT_FAR = 2, PT_BAND = 3, PT_TINY = 4 };
+struct FlowPoint {
+    int    kind;         // what a step of cappedgd with this midpoint does: PT_NEAR "not there yet", PT_FAR "too far", PT_BAND tolerance met, PT_TINY interval under 1e-10
+    bool   by_rule;      // t is the (finite) value the rule reported; false: the gradient's sign, a non-finite value or the 1e-10 test decided
+    double t, pace;      // pace = 1 / gradient at the point, as computed
+};
+// one step's evaluation at the point p, in the order and with the arithmetic of flow_try / flow_quadrature
+template <class G>
+CNF2_UHD FlowPoint flow_point(const FlowState& f, G&& rgradient, double p, double scalefactor)
+{
+    FlowPoint r;
+    r.by_rule = false;
+    r.t = 0.0;
+    const double gm = flow_pace(rgradient, p, f.epsilon);
+    r.pace = gm;
+    if (((gm < 0) != f.falling) || !isfinite(gm)) {
+        r.kind = PT_FAR;
+        return r;
+    }
+    double a = f.orig, b = p;
+    if (a > b) {
+        const double s = a;
+        a = b;
+        b = s;
+    }
+    if (b - a < 1e-10) {
+        r.kind = PT_TINY;
+        return r;
+    }
+    const double eps = f.epsilon;
+    double       t = gauss15([&](double v) CNF2_LI { return flow_pace(rgradient, v, eps); }, a, b);
+    if (b != p) t = -t;
+    if (!isfinite(t)) t = (scalefactor + 0.1) * 1.1;
+    else r.by_rule = true;
+    r.t = t;
+    r.kind = (fabs(t - scalefactor) < scalefactor * 1e-3) ? PT_BAND : (t < scalefactor ? PT_NEAR : PT_FAR);
+    return r;
+}
+
+#define CNF2_GUIDE_MEMO 3
+struct FlowGuide {
+    double s1, noise;          // flow_interval over the bracket and the start when the gradient is known to be monotone there
+    bool   mono;
+    bool   capped;             // the whole bracket is known to be "not there yet" (flow_guide_seed)
+    double near_d, far_d;      // solid facts, as distances from the start along the flow: every midpoint up to near_d is "not there yet", every one from far_d on "too far"
+    // "too far" by the rule's value at a point holds for the midpoints beyond it whose nodes all see the start's sign: farc_d
+    // is such a fact (the rule reported farc_t there) that could not show this from the slope; it counts up to clear_d, the
+    // farthest point at which the gradient has been seen to keep that sign solidly (clear_f = |G| there).  want_clear: ask for
+    // the gradient at the bracket's far end (one evaluation) to set clear_d
+    double farc_d, farc_t, clear_d, clear_f;
+    bool   want_clear;
+    double memo_x[CNF2_GUIDE_MEMO];   // literal results that hold for the point itself only (in the band, under 1e-10, not solid)
+    int    memo_kind[CNF2_GUIDE_MEMO];
+    // the estimate of the distance at which the rule reports the step size: the anchor (a point whose rule value is known:
+    // the start, where it is 0, or the evaluation that came closest to the step size) and a linear model of the gradient
+    // along the way, |G|(d) = anchor_f - slope (d - anchor_d), under which the rule's value has a closed form
+    double anchor_d, anchor_f, anchor_t, slope;
+    double last_d, last_f;     // the evaluation before, for the slope (signed: negative once the gradient has turned round)
+    double best_dt;            // |step size - rule| at the anchor
+    bool   mono_tried;         // ... at the bracket the flow was taken up with
+    int    spec_left;          // evaluations away from the bisection's own midpoint that the flow may still ask for
+    int    evals, points;      // gradient evaluations, literal points (diagnostics)
+};
+#define CNF2_GUIDE_SPECULATIVE 8
+CNF2_UHD void flow_guide_begin(FlowGuide* g)
+{
+    g->s1 = 0.0;
+    g->noise = HUGE_VAL;
+    g->mono = false;
+    g->mono_tried = false;
+    g->capped = false;
+    g->near_d = 0.0;
+    g->far_d = HUGE_VAL;
+    g->farc_d = HUGE_VAL;
+    g->farc_t = 0.0;
+    g->clear_d = g->clear_f = 0.0;
+    g->want_clear = false;
+    for (int i = 0; i < CNF2_GUIDE_MEMO; i++) {
+        g->memo_x[i] = -1.0;
+        g->memo_kind[i] = PT_NONE;
+    }
+    g->anchor_d = g->anchor_f = g->anchor_t = g->slope = 0.0;
+    g->last_d = g->last_f = 0.0;
+    g->best_dt = HUGE_VAL;
+    g->spec_left = CNF2_GUIDE_SPECULATIVE;
+    g->evals = g->points = 0;
+}
+// is the gradient monotone on the bracket (and from the start to it)?  Tried when the flow is taken up and at fixed step
+// numbers while the bracket shrinks
+CNF2_UHD bool flow_guide_mono_due(int it) { return it == 0 || it == 1 || it == 2 || it == 4 || it == 7 || it == 11 || it == 16 || it == 22 || it == 29 || it == 37; }
+CNF2_UHD void flow_guide_try_mono(const FlowState& f, FlowGuide* g, const SlopeTerms& st)
+{
+    const double eps = f.epsilon, top = 1.0 - f.epsilon;
+    if (g->mono || !(f.lo >= eps && f.hi <= top) || !isfinite(f.g0) || f.g0 == 0.0) return;
+    const double        xa = f.lo < f.orig ? f.lo : f.orig, xb = f.hi > f.orig ? f.hi : f.orig;
+    const IntervalFacts B = flow_interval(st, xa, xb, true);
+    if (B.s1 > 0.0 && B.noise < HUGE_VAL) {
+        g->mono = true;
+        g->s1 = B.s1;
+        g->noise = B.noise;
+    }
+}
+CNF2_UHD double flow_distance(const FlowState& f, double x) { return f.falling ? f.orig - x : x - f.orig; }
+// what is known about a midpoint without evaluating it
+CNF2_UHD int flow_guide_known(const FlowState& f, const FlowGuide& g, double mid)
+{
+    const double d = flow_distance(f, mid);
+    if (g.mono && d > 0.0) {
+        if (d >= g.far_d || (d >= g.farc_d && d <= g.clear_d)) return PT_FAR;
+        if (d <= g.near_d) return d < 1e-10 ? PT_TINY : PT_NEAR;       // the 1e-10 test on sorted ends: b - a = |mid - start|
+    }
+    int kind = PT_NONE;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = CNF2_GUIDE_MEMO - 1; i >= 0; i--)
+        if (g.memo_kind[i] != PT_NONE && g.memo_x[i] == mid) kind = g.memo_kind[i];
+    return kind;
+}
+// the result of a literal evaluation at p: a fact, a memo, a better estimate
+CNF2_UHD void flow_guide_feed(const FlowState& f, FlowGuide* g, double p, const FlowPoint& r, double scalefactor)
+{
+    const double d = flow_distance(f, p);
+    g->points++;
+    g->evals += r.by_rule ? 16 : 1;
+    bool solid = false;
+    const bool usable = isfinite(r.pace) && r.pace != 0.0;
+    const double gp = usable ? 1.0 / fabs(r.pace) : 0.0;             // |G(p)| as computed
+    if (g->mono && d > 0.0 && usable) {
+        const double slack = 4.0 * g->noise / gp + 1e-12;
+        if (r.kind == PT_NEAR && r.by_rule && gp > 4.0 * g->noise && r.t * (1.0 + slack) < scalefactor * (1.0 - 1e-3)) {
+            solid = true;
+            if (d > g->near_d) g->near_d = d;
+        } else if (r.kind == PT_FAR && !r.by_rule && ((r.pace < 0) != f.falling) && gp > 2.0 * g->noise) {
+            solid = true;                                            // the gradient has turned round, by more than its noise
+            if (d < g->far_d) g->far_d = d;
+        } else if (r.kind == PT_FAR && r.by_rule && gp > 4.0 * g->noise && r.t * (1.0 - slack) > scalefactor * (1.0 + 1e-3)) {
+            if (0.006 * d * g->s1 > 8.0 * g->noise) {
+                solid = true;
+                if (d < g->far_d) g->far_d = d;
+            } else if (d < g->farc_d) {
+                g->farc_d = d;
+                g->farc_t = r.t;
+                if (g->clear_d > d && !(r.t * (1.0 - 4.0 * g->noise / g->clear_f - 1e-12) > scalefactor * (1.0 + 1e-3))) g->farc_d = HUGE_VAL;
+                else if (!(g->clear_d > d)) g->want_clear = true;
+                solid = g->farc_d == d && g->clear_d > d;
+            }
+        }
+        // a gradient that solidly keeps the start's sign: no root up to here
+        if (((r.pace < 0) == f.falling) && gp > 4.0 * g->noise && d > g->clear_d) {
+            g->clear_d = d;
+            g->clear_f = gp;
+        }
+    }
+    // an evaluation that leaves neither a solid fact nor the band's point (inside the gradient's noise next to a root, or the
+    // rule's value next to the band): from here on the flow takes the bisection's own steps, each of which is progress
+    if (!solid && r.kind != PT_BAND) g->spec_left = 0;
+    if (!solid) {                                                    // newest first (constant indices: the memo stays in registers)
+        g->memo_x[2] = g->memo_x[1];
+        g->memo_kind[2] = g->memo_kind[1];
+        g->memo_x[1] = g->memo_x[0];
+        g->memo_kind[1] = g->memo_kind[0];
+        g->memo_x[0] = p;
+        g->memo_kind[0] = r.kind;
+    }
+    if (usable && d > 0.0 && d != g->last_d) {
+        const double fs = ((r.pace < 0) != f.falling) ? -gp : gp;     // along the flow: negative beyond the root
+        g->slope = (g->last_f - fs) / (d - g->last_d);
+        g->last_d = d;
+        g->last_f = fs;
+        if (r.by_rule) {
+            const double dt = fabs(scalefactor - r.t);
+            if (dt < g->best_dt) {
+                g->best_dt = dt;
+                g->anchor_d = d;
+                g->anchor_f = gp;
+                g->anchor_t = r.t;
+            }
+        }
+    }
+}
+// the gradient at the bracket's far end (asked for by want_clear), 1 / G as computed
+CNF2_UHD void flow_guide_feed_clear(const FlowState& f, FlowGuide* g, double p, double pace)
+{
+    const double d = flow_distance(f, p);
+    g->want_clear = false;
+    g->evals++;
+    if (!g->mono || !isfinite(pace) || pace == 0.0 || !(d > 0.0)) {
+        g->farc_d = HUGE_VAL;
+        return;
+    }
+    const double gp = 1.0 / fabs(pace);
+    if (((pace < 0) != f.falling)) {
+        if (gp > 2.0 * g->noise && d < g->far_d) g->far_d = d;        // turned round, solidly: a fact of its own
+        g->farc_d = HUGE_VAL;
+        return;
+    }
+    if (gp > 4.0 * g->noise && d > g->clear_d) {
+        g->clear_d = d;
+        g->clear_f = gp;
+    }
+    if (!(g->clear_d >= d) || !(g->farc_t * (1.0 - 4.0 * g->noise / g->clear_f - 1e-12) > 0.0)) g->farc_d = HUGE_VAL;
+}
+// the model's answer: where the rule reports the step size (*ds) and |G| there (*fs).  With |G| linear from the anchor the
+// time from it to d is -log(1 - slope (d - anchor_d) / anchor_f) / slope.
+CNF2_UHD void flow_guide_estimate(const FlowGuide& g, double scalefactor, double* ds, double* fs)
+{
+    const double rem = scalefactor - g.anchor_t, z = g.slope * rem;
+    double       step;
+    if (fabs(z) < 1e-4) step = rem * g.anchor_f * (1.0 - 0.5 * z);
+    else step = (g.anchor_f / g.slope) * (1.0 - exp(-z));
+    if (!isfinite(step)) step = rem * g.anchor_f;
+    *ds = g.anchor_d + step;
+    const double fl = g.anchor_f - g.slope * step;
+    *fs = fl > 0.0 ? fl : g.anchor_f;
+}
+// the start and one gradient evaluation at the distance an Euler step would reach seed the model (slope from the two)
+template <class G>
+CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, const SlopeTerms& st, double scalefactor)
+{
+    const double f0 = 1.0 / fabs(f.g0);
+    g->anchor_d = 0.0;
+    g->anchor_f = f0;
+    g->anchor_t = 0.0;
+    g->last_d = 0.0;
+    g->last_f = f0;
+    g->slope = 0.0;
+    const double far_end = flow_distance(f, f.falling ? f.lo : f.hi);
+    double       de = scalefactor * f0;
+    if (!(de < far_end)) de = far_end;
+    const double x = f.falling ? f.orig - de : f.orig + de;
+    const double d = flow_distance(f, x);
+    if (!(d > 0.0)) return;
+    const double pe = flow_pace(rgradient, x, f.epsilon);
+    g->evals++;
+    if (!isfinite(pe) || pe == 0.0) return;
+    const double fe = ((pe < 0) != f.falling) ? -1.0 / fabs(pe) : 1.0 / fabs(pe);
+    g->slope = (f0 - fe) / d;
+    g->last_d = d;
+    g->last_f = fe;
+    // The flow runs into its cap (an Euler step from the start overshoots the bracket, so the evaluation above sits at the
+    // bracket's far end)?  If |G| >= gmin > 0 on the whole bracket the rule reports at most |m - start| / gmin at any
+    // midpoint m: with that under the band every step is "not there yet" and nothing is left to evaluate.  gmin: where the
+    // gradient is known to be monotone, its value at the far end; else an enclosure of the gradient on the bracket.
+    if (de == far_end && x >= f.epsilon && x <= 1.0 - f.epsilon && f.orig >= f.epsilon && f.orig <= 1.0 - f.epsilon) {
+        double gmin = 0.0;
+        if (g->mono) {
+            if (fe > 4.0 * g->noise) gmin = fe * (1.0 - 4.0 * g->noise / fe - 1e-12);
+        } else {
+            const double        xa = x < f.orig ? x : f.orig, xb = x < f.orig ? f.orig : x;
+            const GradientRange R = flow_gradient_range(st, xa, xb, logit(xa), logit(xb));
+            gmin = f.falling ? -R.ghi : R.glo;
+        }
+        if (gmin > 0.0 && d * (1.0 + 1e-12) < scalefactor * (1.0 - 1e-3) * gmin) {
+            g->mono = true;                  // what the facts need of it holds: the sign is the start's on the whole bracket
+            if (!(g->noise < HUGE_VAL)) g->noise = 0.0;
+            g->capped = true;
+            g->near_d = d;
+        }
+    }
+}
+// the path the bisection takes from the flow's present bracket if the rule reports the band exactly between the distances
+// band_lo and band_hi: its last midpoint (0: the bisection ends without one, on its step count or its bounds) and the two
+// ends of the bracket at that time where they are midpoints of the path
+struct FlowPlan {
+    double term_x, near_x, far_x;
+    bool   has_term, has_near, has_far;
+};
+CNF2_UHD void flow_guide_plan(const FlowState& f, double band_lo, double band_hi, FlowPlan* P)
+{
+    double lo = f.lo, hi = f.hi;
+    int    it = f.it;
+    P->has_term = P->has_near = P->has_far = false;
+    P->term_x = P->near_x = P->far_x = 0.0;
+    for (;;) {
+        if (it >= 51 || lo > f.hilim || hi < f.lolim) return;
+        it++;
+        const double mid = (lo + hi) / 2;
+        const double d = flow_distance(f, mid);
+        if (d >= band_hi) {
+            P->far_x = mid;
+            P->has_far = true;
+            if (f.falling) lo = mid;
+            else hi = mid;
+        } else if (d < 1e-10 || d > band_lo) {
+            P->term_x = mid;
+            P->has_term = true;
+            return;
+        } else {
+            P->near_x = mid;
+            P->has_near = true;
+            if (f.falling) hi = mid;
+            else lo = mid;
+        }
+    }
+}
+// The next thing to do: 0 = the flow has ended; 2 = evaluate *p literally (flow_point) and hand the result to flow_guide_feed;
+// 3 = evaluate the gradient alone at *p (flow_pace) and hand 1 / G to flow_guide_feed_clear.
+// Midpoints that facts cover are decided here, in the literal order, with flow_decide.
+CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, double scalefactor, double* p)
+{
+    for (;;) {
+        if (!f->live) return 0;
+        if (f->it >= 51 || f->lo > f->hilim || f->hi < f->lolim) {
+            f->why = 3;
+            f->live = false;
+            return 0;
+        }
+        if (!g->mono && (!g->mono_tried || flow_guide_mono_due(f->it))) flow_guide_try_mono(*f, g, st);
+        g->mono_tried = true;
+        const double mid = (f->lo + f->hi) / 2;
+        if (g->want_clear) {
+            *p = f->falling ? f->lo : f->hi;
+            return 3;
+        }
+        const int    kind = flow_guide_known(*f, *g, mid);
+        if (kind == PT_NONE) {
+            *p = mid;
+            if (!g->mono || g->spec_left <= 0) return 2;              // literal steps until the gradient is known to be monotone
+            g->spec_left--;
+            const double far_end = flow_distance(*f, f->falling ? f->lo : f->hi);
+            double       ds, fs;
+            flow_guide_estimate(*g, scalefactor, &ds, &fs);
+            // facts contradict the estimate: halve what is open.  (An estimate beyond the bracket's far end is no contradiction:
+            // the flow runs into its cap, every midpoint is "not there yet", and the last of them is the one to evaluate.)
+            if (!(ds > g->near_d && ds < g->far_d)) ds = 0.5 * (g->near_d + (g->far_d < far_end ? g->far_d : far_end));
+            const double half = 1e-3 * scalefactor * fs;
+            FlowPlan     P;
+            flow_guide_plan(*f, ds - half, ds + half, &P);
+            if (P.has_term && flow_guide_known(*f, *g, P.term_x) == PT_NONE) *p = P.term_x;
+            else if (P.has_near && flow_guide_known(*f, *g, P.near_x) == PT_NONE) *p = P.near_x;
+            else if (P.has_far && flow_guide_known(*f, *g, P.far_x) == PT_NONE) *p = P.far_x;
+            return 2;
+        }
+        f->it++;
+        f->mid = mid;
+        if (kind == PT_BAND) {
+            f->why = 1;
+            f->live = false;
+            return 0;
+        }
+        if (kind == PT_TINY) {
+            f->why = 2;
+            f->live = false;
+            return 0;
+        }
+        flow_decide(f, kind == PT_NEAR ? 0.0 : (scalefactor + 0.1) * 1.1, scalefactor);
+    }
+}
+// a whole flow, the guided way (host tests; the device kernels run flow_guide_next / flow_point / flow_guide_feed per round)
+template <class G>
+CNF2_UHD double flow_step_guided(G&& rgradient, const SlopeTerms& st, double orig, double epsilon, double scalefactor, int* hits,
+                                 bool breakathalf, FlowGuide* guide = nullptr, FlowState* state = nullptr)
+{
+    FlowState f;
+    FlowGuide g;
+    flow_begin(&f, rgradient, orig, epsilon, scalefactor, breakathalf);
+    flow_guide_begin(&g);
+    if (f.pinned) {
+        while (flow_advance(&f, rgradient, scalefactor)) {}
+    } else {
+        double p;
+        flow_guide_try_mono(f, &g, st);
+        g.mono_tried = true;
+        flow_guide_seed(f, &g, rgradient, st, scalefactor);
+        for (int rc; (rc = flow_guide_next(&f, &g, st, scalefactor, &p)) != 0;) {
+            if (rc == 3) flow_guide_feed_clear(f, &g, p, flow_pace(rgradient, p, f.epsilon));
+            else flow_guide_feed(f, &g, p, flow_point(f, rgradient, p, scalefactor), scalefactor);
+        }
+    }
+    if (guide) *guide = g;
+    if (state) *state = f;
+    return flow_end(f, scalefactor, hits, breakathalf);
 }
 
 // ------------------------------------------------------------------ genotype certainties (processinfprobs)

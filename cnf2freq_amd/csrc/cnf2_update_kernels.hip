@@ -223,6 +223,9 @@ struct HaploTodo {
     double             similarity;   // what haplo_rewrite returned in the scout (the rewrite is not repeated)
 };
 
+__device__ __forceinline__ double haplo_similarity_of(const FlowTodo&) { return 0.0; }
+__device__ __forceinline__ double haplo_similarity_of(const HaploTodo& e) { return e.similarity; }
+
 // diagnostics: stats[0..3] += a, b, c, d summed over the wavefront
 __device__ __forceinline__ void flow_stats(unsigned long long* stats, unsigned a_, unsigned b_, unsigned c_, unsigned d_)
 {
@@ -726,6 +729,92 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(
     flow_stats(u.stats ? u.stats + 12 : nullptr, n_steps, n_rounds, n_quads, n_why1);
 }
 
+// ---- the guided finish: the flows the scouts set aside, with the literal decisions from three or four quadratures each ----
+// (cnf2_update.h, "the guided bisection").  Persistent like the finish kernels above -- a wavefront is 64 independent workers
+// over a queue of its own -- but a round is not "the next bisection step": a lane asks for the literal evaluation of ONE
+// point (flow_guide_next: the bisection's midpoints that facts cover are decided on the way, the point asked for is the one
+// that settles most), all lanes evaluate theirs together (flow_point: the midpoint's gradient and the 15 nodes, the same
+// arithmetic as a step of cappedgd), and the result goes back as a fact (flow_guide_feed).  The decisions, and with them the
+// results, are those of the literal kernels to the bit (tests/test_host_update.py on the host; the GPU suite compares the
+// passes); what changes is that a flow which reaches its step size takes 3 - 4 rounds instead of ~10.
+// KIND 0: genotype certainties (FlowTodo), 1: haplotype weights (HaploTodo).
+template <int KIND, class Entry>
+__global__ CNF2_FINISH_OCC __launch_bounds__(64) void guided_finish_kernel(UpdateParams u, unsigned long long* next, const Entry* todo,
+                                                                           unsigned long long n_items, double* flow_out)
+{
+    const StepControl  sc = {u.scalefactor, u.entropyfactor};
+    __shared__ Entry   queue[FLOW_QUEUE];
+    FlowSupply<Entry>  q = {0ull, 0ull, 0, true};
+    if (KIND == 0 && u.mirror == 2 && u.flow_next[26] == 0ull) return;
+    bool               have = false;
+    int                both = PARTNER_NONE;
+    unsigned long long item = 0;
+    size_t             row_i = 0;
+    CertaintyFlow      c;
+    HaploFlow          h;
+    FlowState          f;
+    FlowGuide          g;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_points = 0, n_rounds = 0, n_evals = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return KIND == 0 ? certainty_rgradient(c, x) : haplo_rgradient(h, x); };
+    for (;;) {
+        const int busy = __popcll(__ballot(have));
+        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            Entry e;
+            if (flow_pop(&q, queue, !have, &e)) {
+                double start;
+                if (KIND == 0) {
+                    item = e.item_steps >> 6;
+                    certainty_item(u, item, sc, &c, &both);
+                    st = certainty_slope(c);
+                    start = c.curprob;
+                    f.epsilon = c.epsilon;
+                } else {
+                    size_t k;
+                    int    r;
+                    haplo_item(u, e.item_steps >> 6, &row_i, &k, &r);
+                    start = u.hw[row_i];
+                    haplo_flow_terms(start, u.acc_hb[k], u.acc_hc[k], haplo_similarity_of(e), u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+                    st = haplo_slope(h);
+                    f.epsilon = h.epsilon;
+                }
+                flow_begin(&f, grad, start, f.epsilon, sc.scalefactor, false);
+                flow_replay(&f, e.path, (int)(e.item_steps & 63));
+                flow_guide_begin(&g);
+                flow_guide_try_mono(f, &g, st);
+                g.mono_tried = true;
+                flow_guide_seed(f, &g, grad, st, sc.scalefactor);
+                have = true;
+            }
+            continue;
+        }
+        if (busy == 0) break;               // nothing running and nothing left
+        n_rounds++;
+        int    rc = 0;
+        double p = 0.0;
+        if (have) {
+            rc = flow_guide_next(&f, &g, st, sc.scalefactor, &p);
+            if (rc == 0) {
+                int          hh = 0;
+                const double res = flow_end(f, sc.scalefactor, &hh, false);
+                hits += hh;
+                if (KIND == 0) certainty_store(u, flow_out, item, both, res, &hits, hh);
+                else u.hw[row_i] = res;
+                have = false;
+                n_points += g.points;
+                n_evals += g.evals;
+                n_why1 += f.why == 1;
+            }
+        }
+        if (rc == 2) flow_guide_feed(f, &g, p, flow_point(f, grad, p, sc.scalefactor), sc.scalefactor);
+        else if (rc == 3) flow_guide_feed_clear(f, &g, p, flow_pace(grad, p, f.epsilon));
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + (KIND == 0 ? 8 : 12) : nullptr, n_points, n_rounds, n_evals, n_why1);
+}
+
 void launch_update_pass(const UpdateParams& u, hipStream_t stream)
 {
     const int    len = u.last - u.first + 1;
@@ -763,8 +852,12 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
             hipLaunchKernelGGL(certainty_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
                                (FlowTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n, u.flow_out);
         }
-        hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
-                           (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+        if (u.literal_finish)
+            hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                               (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+        else
+            hipLaunchKernelGGL((guided_finish_kernel<0, FlowTodo>), dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u,
+                               u.flow_next, (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
     }
     }
     hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
@@ -776,8 +869,12 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, (HaploTodo*)u.todo);
         const size_t w = (n + 63) / 64;
-        hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
-                           (const HaploTodo*)u.todo, (unsigned long long)n);
+        if (u.literal_finish)
+            hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
+                               (const HaploTodo*)u.todo, (unsigned long long)n);
+        else
+            hipLaunchKernelGGL((guided_finish_kernel<1, HaploTodo>), dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u,
+                               u.flow_next, (const HaploTodo*)u.todo, (unsigned long long)n, (double*)nullptr);
     }
 }
 

@@ -84,6 +84,10 @@ enum {
                                     (DESIGN.md section 3.11).  The bit-exact form: equal to CNF2_UPDATE_PLAIN to the bit */
     CNF2_UPDATE_ONE_SCOUT = 1u << 17, /* cnf2_update_pass, fast form: the certainties' scout in one pass instead of two (same
                                     results to the bit; A/B switch, tools/ab_scout.py) */
+    CNF2_UPDATE_LITERAL_FINISH = 1u << 19, /* cnf2_update_pass, fast form: the flows the scouts set aside take one literal bisection
+                                    step (midpoint, bound, quadrature) per round, as in rounds 3 / 4, instead of the guided
+                                    bisection (cnf2_update.h: the same decisions from 3 - 4 quadratures per flow).  Same
+                                    results to the bit; A/B switch and cross-check */
     CNF2_DETERMINISTIC = 1u << 14, /* cnf2_sweep_accumulate: every analysed individual writes what its window members receive at a
                                     locus into a row of its own (336 B per individual x marker, allocated for the whole
                                     range) and one more kernel adds the rows of every record in ascending order of the

@@ -712,6 +712,29 @@ void shim_flow(int kind, double y, double g, double h, double e, double c0, doub
             g2.spared += spared;
             f = g2;
         }
+    } else if ((screened == 4 || screened == 5) && !f.pinned) {
+        // the guided bisection (4: from the start; 5: after the scout, as the device runs it): out[5] = gradient evaluations, out[6] = literal points
+        int evals = 0, rc = 2;
+        if (screened == 5) rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals);
+        cnf2::FlowGuide g;
+        cnf2::flow_guide_begin(&g);
+        if (rc != 0) {
+            const unsigned long long path = f.path;
+            const int                steps = f.it, spared = f.spared;
+            cnf2::flow_begin(&f, grad, y, epsilon, scalefactor, false);
+            cnf2::flow_replay(&f, path, steps);
+            f.spared = spared;
+            cnf2::flow_guide_try_mono(f, &g, st);
+            g.mono_tried = true;
+            cnf2::flow_guide_seed(f, &g, grad, st, scalefactor);
+            double p;
+            for (int rcn; (rcn = cnf2::flow_guide_next(&f, &g, st, scalefactor, &p)) != 0;) {
+                if (rcn == 3) cnf2::flow_guide_feed_clear(f, &g, p, cnf2::flow_pace(grad, p, f.epsilon));
+                else cnf2::flow_guide_feed(f, &g, p, cnf2::flow_point(f, grad, p, scalefactor), scalefactor);
+            }
+        }
+        out[5] = evals + g.evals;
+        out[6] = g.points;
     } else if (screened == 2 && !f.pinned) {
         // the one-evaluation-at-a-time machine the kernels run
         cnf2::FlowRun r;
@@ -769,6 +792,75 @@ void shim_time_bound(int kind, double y, double g, double h, double e, double c0
     out[3] = sign_const ? 1.0 : 0.0;
     out[4] = ((1.0 / rg(xa) < 0) == (1.0 / rg(xb) < 0)) ? 1.0 : 0.0;     // the caller's precondition: same sign at both ends
     out[5] = 1.0 / rg(mid_is_b ? xa : xb);                                 // gradient at the flow's start (its sign is the direction)
+}
+// Many certainty flows three ways (tuning aid and the CPU parity test of the guided bisection): per flow inputs as in
+// shim_certainty_flow_trace; out[n][8] = literal result, literal hits, literal gradient evaluations (steps + 15 per quadrature),
+// guided result, guided hits, gradient evaluations of the scout, of the guided part, literal points of the guided part;
+// scout_first: what the device does (the scout, then the guided bisection from where the scout stopped); else guided from the start.
+// Absent values (no evidence) get NaN results.
+void shim_certainty_flows_guided(int n, const double* inf, const int32_t* v, const int32_t* allele, const double* sure,
+                                 const int32_t* prior_allele, const double* prior_sure, const int32_t* children, double scalefactor,
+                                 int scout_first, double* out)
+{
+    cnf2::StepControl sc = {scalefactor, 1.0};
+    for (int i = 0; i < n; i++) {
+        double* o = out + (size_t)i * 8;
+        for (int k = 0; k < 8; k++) o[k] = 0;
+        cnf2::SideState s = {allele[i], sure[i], prior_allele[i], prior_sure[i]};
+        cnf2::CertaintyFlow c;
+        if (!cnf2::certainty_flow_setup(inf + (size_t)i * 2, v[i], s, children[i], sc, &c)) {
+            o[0] = o[3] = NAN;
+            continue;
+        }
+        auto grad = [&](double x) { return cnf2::certainty_rgradient(c, x); };
+        const cnf2::SlopeTerms st = cnf2::certainty_slope(c);
+        {
+            cnf2::FlowState f;
+            cnf2::flow_begin(&f, grad, c.curprob, c.epsilon, scalefactor, false);
+            while (cnf2::flow_advance(&f, grad, scalefactor)) {}
+            int hits = 0;
+            o[0] = cnf2::flow_end(f, scalefactor, &hits, false);
+            o[1] = hits;
+            o[2] = f.pinned ? 1 : f.it + 15 * f.quads;
+        }
+        cnf2::FlowState f;
+        cnf2::FlowGuide g;
+        cnf2::flow_begin(&f, grad, c.curprob, c.epsilon, scalefactor, false);
+        cnf2::flow_guide_begin(&g);
+        int evals = 0;
+        if (f.pinned) {
+            while (cnf2::flow_advance(&f, grad, scalefactor)) {}
+        } else {
+            int rc = 2;
+            if (scout_first) rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals);
+            if (rc != 0) {
+                double p;
+                cnf2::flow_guide_try_mono(f, &g, st);
+                g.mono_tried = true;
+                cnf2::flow_guide_seed(f, &g, grad, st, scalefactor);
+                const bool trace = (getenv("SHIM_TRACE") && i < atoi(getenv("SHIM_TRACE"))) || (getenv("SHIM_TRACE_ONE") && i == atoi(getenv("SHIM_TRACE_ONE")));
+                if (trace) printf("flow %d orig %.9g eps %.3g lo %.9g hi %.9g falling %d G0 %.4g\n", i, f.orig, f.epsilon, f.lo, f.hi, (int)f.falling, 1 / f.g0);
+                for (int rcn; g.points < 320 && (rcn = cnf2::flow_guide_next(&f, &g, st, scalefactor, &p)) != 0;) {
+                    if (rcn == 3) {
+                        cnf2::flow_guide_feed_clear(f, &g, p, cnf2::flow_pace(grad, p, f.epsilon));
+                        continue;
+                    }
+                    const cnf2::FlowPoint r = cnf2::flow_point(f, grad, p, scalefactor);
+                    cnf2::flow_guide_feed(f, &g, p, r, scalefactor);
+                    if (g.points == 300) printf("RUNAWAY flow %d\n", i);
+                    if (trace || (g.points > 300 && g.points < 310)) printf("   it %2d mono %d point d %.9g (mid d %.9g) kind %d t/sf %.6f G %.4g  near %.9g far %.9g dstar %.9g\n", f.it, (int)g.mono,
+                                      cnf2::flow_distance(f, p), cnf2::flow_distance(f, (f.lo + f.hi) / 2), r.kind, r.t / scalefactor, 1 / r.pace, g.near_d, g.far_d, g.anchor_d);
+                }
+                if (trace) printf("   ended it %d why %d\n", f.it, f.why);
+            }
+        }
+        int hits = 0;
+        o[3] = cnf2::flow_end(f, scalefactor, &hits, false);
+        o[4] = hits;
+        o[5] = evals;
+        o[6] = g.evals;
+        o[7] = g.points;
+    }
 }
 double shim_adapt_scalefactor(double scalefactor, int hits, int* old, int n_analysed)
 {

@@ -252,7 +252,7 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
     nine = rs.rand(*ped.allele[1:].shape) < 0.01
     ped.allele[1:][nine & (ped.allele[1:] != 0)] = 9
     ctxs = {}
-    for name in ("mirror", "flow", "flow1", "plain"):
+    for name in ("mirror", "flow", "flow1", "flowL", "plain"):
         ctx = capi.Context(0)
         ctx.upload(ped)
         ctx.snapshot_priors((1 - ped.empty).astype(np.uint8))
@@ -270,13 +270,15 @@ def test_flow_kernels_equal_one_thread_per_element(libs):
         # flow: both values' flows as the reference runs them (CNF2_UPDATE_BOTH_FLOWS), the certainties' scout in two passes;
         # flow1: that scout in one pass (CNF2_UPDATE_ONE_SCOUT).  The forms are flags of the call: nothing reads the environment
         for name, flags in (("mirror", 0), ("flow", capi.UPDATE_BOTH_FLOWS),
-                            ("flow1", capi.UPDATE_BOTH_FLOWS | capi.UPDATE_ONE_SCOUT), ("plain", capi.UPDATE_PLAIN)):
+                            ("flow1", capi.UPDATE_BOTH_FLOWS | capi.UPDATE_ONE_SCOUT),
+                            ("flowL", capi.UPDATE_BOTH_FLOWS | capi.UPDATE_LITERAL_FINISH), ("plain", capi.UPDATE_PLAIN)):
             ctx = ctxs[name]
             acc = ctx.sweep_accumulate(desc, deterministic=True)
             hits = [ctx.update_pass(c, children, desc, 0.19, 1.0, acc, flags=flags) for c in range(2)]
             out[name] = (hits, ctx.download_rows(1, ped.n_rec), {k: acc[k].copy() for k in ("infprobs", "haplobase", "haplocount")})
         total_hits += sum(out["flow"][0])
-        for name in ("flow", "flow1"):
+        # flowL: the set-aside flows one literal step per round (rounds 3 / 4) instead of the guided bisection (the default)
+        for name in ("flow", "flow1", "flowL"):
             assert out[name][0] == out["plain"][0], (rnd, name)
             for x, y in zip(out[name][1], out["plain"][1]):
                 assert np.array_equal(x, y), (rnd, name)

@@ -278,6 +278,7 @@ def test_flows_with_the_bound_equal_flows_without(shim):
     rs = np.random.RandomState(12)
     a, b, m = np.zeros(8), np.zeros(8), np.zeros(8)
     spared = quads = scout_evals = scout_done = literal_evals = 0
+    guided_evals = {4: 0, 5: 0}
     for _ in range(20000):
         kind, y, g, h, e, c0, d, pr = _random_flow(rs)
         eps = 5e-6 / rs.randint(1, 4)
@@ -298,5 +299,12 @@ def test_flows_with_the_bound_equal_flows_without(shim):
         literal_evals += b[4] + 15 * b[1]
         spared += a[2]
         quads += b[1]
+        # the guided bisection (facts from literal evaluations, ordered by the monotone gradient): from the start, and after the scout
+        for form in (4, 5):
+            shim.shim_flow(kind, y, g, h, e, c0, d, pr, eps, sf, form, _p(m))
+            assert m[0] == b[0] and m[3] == b[3] and m[4] == b[4], (form, kind, y, g, h, e, c0, d, pr, eps, sf, b, m)
+            guided_evals[form] += m[5]
     assert spared > 0.2 * quads
     assert scout_done > 4000, scout_done
+    # ... and it is what it is for: under half the gradient evaluations of the literal bisection
+    assert guided_evals[5] < 0.5 * literal_evals, (guided_evals, literal_evals)
