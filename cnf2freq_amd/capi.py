@@ -35,7 +35,7 @@ SYMBOLS = [
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
     "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
-    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
+    "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_update_stats_guided", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
     "cnf2_set_grid_reserve", "cnf2_set_batch_jobs", "cnf2_window_table", "cnf2_update_pass_records", "cnf2_exchange_buffer", "cnf2_exchange_download", "cnf2_exchange_upload", "cnf2_exchange_read", "cnf2_exchange_write",
     "cnf2_packed_accumulator_doubles", "cnf2_packed_row_bytes", "cnf2_pack_accumulators", "cnf2_unpack_accumulators",
@@ -119,6 +119,7 @@ def load():
         L.cnf2_upload_accumulators.argtypes = [vp, vp, vp, vp]
         L.cnf2_accumulator_ptrs.argtypes = [vp, vp, vp, vp]
         L.cnf2_update_stats.argtypes = [vp, vp]
+        L.cnf2_update_stats_guided.argtypes = [vp, vp]
         L.cnf2_emission.argtypes = [vp, i32, i32, vp]
         L.cnf2_emission_paths.argtypes = [vp, i32, i32, vp]
         L.cnf2_selftest_lane_xor.argtypes = [vp, vp]

@@ -1088,15 +1088,18 @@ int cnf2_descendants(cnf2_ctx* ctx, int32_t* desc_out)
     return CNF2_OK;
 }
 
-// Entries of the list the update scouts set flows aside on: a chunk of the pass's flows, at most 2^27 (3.2 GB)
+// Entries of the list the update scouts set flows aside on: a chunk of the pass's flows, at most 2^26
 static size_t todo_chunk(size_t n_rec, size_t chrom_len, size_t markers_upto)
 {
     const size_t n1 = n_rec * chrom_len * 4, n3 = n_rec * markers_upto;
     size_t       want = n1 > n3 ? n1 : n3;
     if (want < 4096) want = 4096;
-    const size_t cap = (size_t)1 << 27;
+    const size_t cap = (size_t)1 << 26;        // x 72 B for the three lists: 4.8 GB
     return want < cap ? want : cap;
 }
+
+// ... in doubles: three lists of 24-byte entries (the scouts' and the two packed ones of the guided kernels) and the packing's counts
+static size_t todo_doubles(size_t chunk) { return chunk * 9 + chunk / 256 + 8; }
 
 enum : uint32_t { ACC_RESERVE_ONLY = 1u << 31 };     // internal flag of cnf2_sweep_accumulate (not in the header)
 
@@ -1240,9 +1243,9 @@ int cnf2_sweep_accumulate(cnf2_ctx* ctx, int ind_begin, int ind_end, const int32
         }
         if (reserve_only) {
             // ... and the buffers of the update passes (cnf2_update_pass): results of a chromosome's flows, the scouts' list
-            if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
+            if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 32 * sizeof(unsigned long long)));
             if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, R * (size_t)mlen * 4))) return rc;
-            if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, todo_chunk(R, (size_t)mlen, M) * 3))) return rc;
+            if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, todo_doubles(todo_chunk(R, (size_t)mlen, M))))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return CNF2_OK;
         }
@@ -1633,18 +1636,21 @@ static int update_pass_impl(cnf2_ctx* ctx, int chrom, const int32_t* recs, int n
     u.entropyfactor = entropyfactor;
     u.hits = ctx->d_hits;
     if (!(flags & CNF2_UPDATE_PLAIN)) {
-        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 28 * sizeof(unsigned long long)));
+        if (!ctx->d_flow_next) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flow_next, 32 * sizeof(unsigned long long)));
         if ((rc = ensure(ctx, &ctx->d_flow_out, &ctx->flow_out_cap, (RU ? RU : 1) * (size_t)(u.last - u.first + 1) * 4))) return rc;
         // the scouts work through their flows in chunks; a chunk's worth of set-aside entries (24 bytes each), no more
         // than the pass has flows (certainties: 4 per record and marker of the chromosome; weights: 1 per record and marker
         // of the chromosomes so far)
         const size_t chunk = todo_chunk(RU, (size_t)(u.last - u.first + 1), (size_t)u.chromstarts_host_upto);
-        if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, chunk * 3))) return rc;
+        if ((rc = ensure(ctx, &ctx->d_todo, &ctx->todo_cap, todo_doubles(chunk)))) return rc;
         u.flow_next = ctx->d_flow_next;
         u.flow_out = ctx->d_flow_out;
         u.stats = getenv("CNF2_UPDATE_STATS") ? ctx->d_flow_next + 2 : nullptr;     // diagnostics only (no effect on results): a few atomics per wavefront
         u.todo = ctx->d_todo;
-        u.todo_cap = ctx->todo_cap / 3;
+        u.todo_cap = chunk;
+        u.todo2 = ctx->d_todo + chunk * 3;
+        u.todo3 = ctx->d_todo + chunk * 6;
+        u.todo_counts = (unsigned long long*)(ctx->d_todo + chunk * 9);
         u.scout_passes = (flags & CNF2_UPDATE_ONE_SCOUT) ? 1 : 2;
         u.mirror = (flags & CNF2_UPDATE_BOTH_FLOWS) ? 0 : 1;
         u.literal_finish = (flags & CNF2_UPDATE_LITERAL_FINISH) ? 1 : 0;
@@ -1871,6 +1877,16 @@ int cnf2_update_stats(cnf2_ctx* ctx, uint64_t* out16)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out16, ctx->d_flow_next + 2, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CNF2_OK;
+}
+
+int cnf2_update_stats_guided(cnf2_ctx* ctx, uint64_t* out8)
+{
+    if (!ctx || !out8) return fail(ctx, CNF2_ERR_ARG, "bad arguments");
+    if (!ctx->d_flow_next) return fail(ctx, CNF2_ERR_STATE, "no update pass has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out8, ctx->d_flow_next + 18, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CNF2_OK;
 }
 

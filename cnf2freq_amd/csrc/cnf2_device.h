@@ -137,9 +137,11 @@ struct UpdateParams {
     double         relhaplo;      // 0.5 on this path (cnF2freq.cpp:2496)
     double         scalefactor, entropyfactor;
     int*           hits;          // device counter
-    unsigned long long* flow_next;   // [2] item counters of the persistent flow kernels; null = one thread per element
+    unsigned long long* flow_next;   // [32]: [0..1] item counters of the persistent flow kernels; null = one thread per element
     unsigned long long* stats;       // [24] diagnostics of the flow kernels (cnf2_update_stats), may be null
     void*          todo;          // flows the scouts set aside for the finish kernels (24 bytes each)
+    void*          todo2, *todo3; // two more lists of the same size (the packed lists of the guided kernels)
+    unsigned long long* todo_counts;  // [todo_cap / 256 + 2] scratch of the packing
     size_t         todo_cap;      // flows per chunk of a scout = entries of todo
     int            mirror;        // certainties: run one flow per side where both values have evidence, the other is its mirror image
     int            scout_passes;  // certainties: 2 = a short first scout pass and a second for the flows still going; 1 = one pass (A/B)

@@ -496,6 +496,9 @@ struct SlopeTerms {
     double   c0;       // constant term: entropyfactor x prior (certainties)
 };
 #define CNF2_GL15_C 6.636457986458086      /* sum of w_i / (1 - z_i) over the 15 nodes */
+#ifndef CNF2_SCOUT_KEEP
+#define CNF2_SCOUT_KEEP 0.3                /* flow_scout, hand_over: slope x step size from which a flow stays with the scout */
+#endif
 struct IntervalFacts {
     double s1;         // lower bound of -G' on the interval; <= 0 or NaN: none
     double noise;      // bound of the rounding error of a computed G on the interval
@@ -653,7 +656,8 @@ CNF2_UHD GradientRange flow_gradient_range(const SlopeTerms& s, double xa, doubl
 // signs are noise and only the evaluation itself says what the literal algorithm sees.  The step sequence, and with it
 // the result, is the literal one; what changes is how much of it is computed.
 // flow_scout runs a begun flow until it ends (returns 0) or a step needs a quadrature (returns 2: the steps completed
-// and their decisions are in f->it and f->path; flow_replay + flow_advance take it from there).
+// and their decisions are in f->it and f->path; flow_replay + flow_advance take it from there; 5: likewise, and the gradient is
+// not known to be monotone on the bracket; 4: set aside at once for the guided bisection, see hand_over).
 // Written for wavefronts that run 64 scouts in lock step (all start at step 0): what costs instructions -- the attempt
 // to show the gradient monotone, the closing in on the root -- happens at fixed step numbers, the same for every lane,
 // and a same-sign step that the constant bound C15 / s1 does not settle ends the scout (the finish pass has the finer
@@ -661,8 +665,13 @@ CNF2_UHD GradientRange flow_gradient_range(const SlopeTerms& s, double xa, doubl
 // max_steps: give up after that many steps of this call (returns 3: the flow is neither ended nor at a quadrature; its
 // completed steps are in f->it and f->path like for 2) -- the first of two scout passes runs a few steps of every flow,
 // the second the rest of the few that are still going, with wavefronts full of them.
+// hand_over: the flows set aside go to the guided bisection (below), which needs 3 - 4 quadratures wherever the gradient is
+// monotone, however far the scout has come: a flow whose gradient is monotone but whose steps the constant bound does not
+// settle is set aside at once (what the scout would spend on it -- the closing in on the root, a dozen evaluations --
+// buys the guided bisection nothing).
 template <class G>
-CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations, int max_steps = 1 << 30)
+CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations, int max_steps = 1 << 30,
+                        bool hand_over = false)
 {
     const double eps = f->epsilon, top = 1.0 - f->epsilon;
     const double limit = scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9);
@@ -686,6 +695,15 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         near_d = new_near ? d : near_d;
         near_g = new_near ? g : near_g;
     };
+    // A flow that cannot move (no finite gradient at its start, or a step size of zero: flow_begin has shut the bracket on the
+    // start) takes its 51 steps at the start itself, every one "too far" by the same non-finite value: nothing to evaluate
+    if (f->live && f->lo == f->hi && f->lo == f->orig && !(f->lo > f->hilim || f->hi < f->lolim)) {
+        f->it = 51;
+        f->why = 3;
+        f->live = false;
+        *evaluations = 0;
+        return 0;
+    }
     for (int step = 0;; step++) {
         *evaluations = evals;
         if (!f->live) return 0;
@@ -707,6 +725,33 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
                     zmax = (ls < 700.0 ? exp(ls) : 1e300) - 1.0;
                     const double g_start = 1.0 / f->g0;
                     if (fabs(g_start) > 2.0 * B.noise) near_g = g_start;       // the start itself (distance 0) is a solid point
+                    if (hand_over && !settles) {
+                        // Which kind of flow is it?  With |G| falling off linearly at the rate k the rule's value saturates at
+                        // C15 / k next to the root: for k x step size well under C15 the flow reaches its step size a fair way
+                        // before the root -- the guided bisection's case, set aside at once -- else it closes in on the root and
+                        // the steps are settled here, by signs and bounds.  k from the start and one evaluation at the distance
+                        // an Euler step would reach (a fact about the root like any other).
+                        const double f0 = fabs(1.0 / f->g0);
+                        const double far_end = f->falling ? f->orig - f->lo : f->hi - f->orig;
+                        double       de = scalefactor * f0;
+                        de = de < far_end ? de : far_end;
+                        const double xe = f->orig + dir * de, dd = (xe - f->orig) * dir;
+                        bool         regular = true;
+                        if (!(dd > far_end * (1.0 / 1048576.0))) regular = false;       // next to a root from the start: twenty steps or more to the band
+                        else if (xe >= eps && xe <= top) {
+                            const double ge = flow_pace(rgradient, xe, eps);
+                            evals++;
+                            if (isfinite(ge) && ge != 0.0) {
+                                const double fe = too_far(ge) ? -fabs(1.0 / ge) : fabs(1.0 / ge);
+                                regular = !((f0 - fe) * scalefactor > CNF2_SCOUT_KEEP * dd);
+                                note(dd, ge);
+                            }
+                        }
+                        if (regular) {
+                            *evaluations = evals;
+                            return 4;
+                        }
+                    }
                 }
             }
         }
@@ -793,7 +838,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         if (!spared) {
             f->it--;                   // this step is for the finish pass: hand the flow over as it stood before it
             *evaluations = evals;
-            return 2;
+            return mono ? 2 : 5;
         }
         f->spared++;
         flow_decide(f, 0.0, scalefactor);
@@ -885,6 +930,10 @@ struct FlowGuide {
     double last_d, last_f;     // the evaluation before, for the slope (signed: negative once the gradient has turned round)
     double best_dt;            // |step size - rule| at the anchor
     bool   mono_tried;         // ... at the bracket the flow was taken up with
+    // the plan in force (flow_guide_plan under the estimate of the time it was made): the points to evaluate, and whether
+    // the evaluations so far came out as it expects (else it is made again, from the better estimate they left)
+    double plan_term, plan_near, plan_far;
+    bool   plan_has_term, plan_has_near, plan_has_far, plan_valid;
     int    spec_left;          // evaluations away from the bisection's own midpoint that the flow may still ask for
     int    evals, points;      // gradient evaluations, literal points (diagnostics)
 };
@@ -895,6 +944,8 @@ CNF2_UHD void flow_guide_begin(FlowGuide* g)
     g->noise = HUGE_VAL;
     g->mono = false;
     g->mono_tried = false;
+    g->plan_term = g->plan_near = g->plan_far = 0.0;
+    g->plan_has_term = g->plan_has_near = g->plan_has_far = g->plan_valid = false;
     g->capped = false;
     g->near_d = 0.0;
     g->far_d = HUGE_VAL;
@@ -979,9 +1030,12 @@ CNF2_UHD void flow_guide_feed(const FlowState& f, FlowGuide* g, double p, const 
             g->clear_f = gp;
         }
     }
+    if (g->plan_valid && ((g->plan_has_term && p == g->plan_term && r.kind != PT_BAND) || (g->plan_has_near && p == g->plan_near && r.kind != PT_NEAR) ||
+                          (g->plan_has_far && p == g->plan_far && r.kind != PT_FAR)))
+        g->plan_valid = false;
     // an evaluation that leaves neither a solid fact nor the band's point (inside the gradient's noise next to a root, or the
     // rule's value next to the band): from here on the flow takes the bisection's own steps, each of which is progress
-    if (!solid && r.kind != PT_BAND) g->spec_left = 0;
+    if (!solid && r.kind != PT_BAND && g->mono) g->spec_left = 0;
     if (!solid) {                                                    // newest first (constant indices: the memo stays in registers)
         g->memo_x[2] = g->memo_x[1];
         g->memo_kind[2] = g->memo_kind[1];
@@ -1065,6 +1119,38 @@ CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, c
     g->slope = (f0 - fe) / d;
     g->last_d = d;
     g->last_f = fe;
+    // Sharpen the estimate before anything is evaluated literally: the time to the model's answer by a 5-point rule (the
+    // integrand is smooth this far from a root, and nothing depends on this value but where the first points are put),
+    // the gradient there, and the model anchored on the two.  Six evaluations instead of the sixteen of a literal point.
+    if (g->mono && de < far_end) {
+        double ds, fs;
+        flow_guide_estimate(*g, scalefactor, &ds, &fs);
+        if (ds > 0.0 && ds < far_end) {
+            const double xs = f.falling ? f.orig - ds : f.orig + ds;
+            const double z5[2] = {0.5384693101056831, 0.9061798459386640}, w5[3] = {0.5688888888888889, 0.4786286704993665, 0.2369268850561891};
+            const double mc = 0.5 * (f.orig + xs), hl = 0.5 * ds;
+            bool         ok = true;
+            auto pace_at = [&](double xx) CNF2_LI {
+                const double pv = flow_pace(rgradient, xx, f.epsilon);
+                g->evals++;
+                ok = ok && isfinite(pv) && pv != 0.0 && ((pv < 0) == f.falling);
+                return fabs(pv);
+            };
+            double acc = w5[0] * pace_at(mc);
+            for (int i = 0; i < 2; i++) acc += w5[i + 1] * (pace_at(mc + hl * z5[i]) + pace_at(mc - hl * z5[i]));
+            const double ps = pace_at(xs);
+            if (ok) {
+                const double t5 = hl * acc, fsx = 1.0 / ps, dx = flow_distance(f, xs);
+                if (dx > g->last_d || dx < g->last_d) g->slope = (g->last_f - fsx) / (dx - g->last_d);
+                g->last_d = dx;
+                g->last_f = fsx;
+                g->anchor_d = dx;
+                g->anchor_f = fsx;
+                g->anchor_t = t5;
+                g->best_dt = fabs(scalefactor - t5) + 1e-3 * scalefactor;      // any literal value near the band takes its place
+            }
+        }
+    }
     // The flow runs into its cap (an Euler step from the start overshoots the bracket, so the evaluation above sits at the
     // bracket's far end)?  If |G| >= gmin > 0 on the whole bracket the rule reports at most |m - start| / gmin at any
     // midpoint m: with that under the band every step is "not there yet" and nothing is left to evaluate.  gmin: where the
@@ -1089,6 +1175,9 @@ CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, c
 // the path the bisection takes from the flow's present bracket if the rule reports the band exactly between the distances
 // band_lo and band_hi: its last midpoint (0: the bisection ends without one, on its step count or its bounds) and the two
 // ends of the bracket at that time where they are midpoints of the path
+#ifndef CNF2_PLAN_DEPTH
+#define CNF2_PLAN_DEPTH 24
+#endif
 struct FlowPlan {
     double term_x, near_x, far_x;
     bool   has_term, has_near, has_far;
@@ -1096,12 +1185,15 @@ struct FlowPlan {
 CNF2_UHD void flow_guide_plan(const FlowState& f, double band_lo, double band_hi, FlowPlan* P)
 {
     double lo = f.lo, hi = f.hi;
-    int    it = f.it;
     P->has_term = P->has_near = P->has_far = false;
     P->term_x = P->near_x = P->far_x = 0.0;
-    for (;;) {
-        if (it >= 51 || lo > f.hilim || hi < f.lolim) return;
-        it++;
+    // at most CNF2_PLAN_DEPTH steps ahead (a wavefront's lanes plan together and wait for the longest; a flow whose band lies
+    // deeper gets the ends its bracket has by then, evaluates them and plans again from the bracket they leave).  The
+    // bisection's own stops (its bounds, cnF2freq.cpp:4131) are left to the bisection: a planned point beyond them is a
+    // fact about the midpoints before it all the same.
+    int steps = 51 - f.it;
+    steps = steps > CNF2_PLAN_DEPTH ? CNF2_PLAN_DEPTH : steps;
+    for (int k = 0; k < steps; k++) {
         const double mid = (lo + hi) / 2;
         const double d = flow_distance(f, mid);
         if (d >= band_hi) {
@@ -1146,18 +1238,54 @@ CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, d
             if (!g->mono || g->spec_left <= 0) return 2;              // literal steps until the gradient is known to be monotone
             g->spec_left--;
             const double far_end = flow_distance(*f, f->falling ? f->lo : f->hi);
-            double       ds, fs;
-            flow_guide_estimate(*g, scalefactor, &ds, &fs);
-            // facts contradict the estimate: halve what is open.  (An estimate beyond the bracket's far end is no contradiction:
-            // the flow runs into its cap, every midpoint is "not there yet", and the last of them is the one to evaluate.)
-            if (!(ds > g->near_d && ds < g->far_d)) ds = 0.5 * (g->near_d + (g->far_d < far_end ? g->far_d : far_end));
-            const double half = 1e-3 * scalefactor * fs;
-            FlowPlan     P;
-            flow_guide_plan(*f, ds - half, ds + half, &P);
-            if (P.has_term && flow_guide_known(*f, *g, P.term_x) == PT_NONE) *p = P.term_x;
-            else if (P.has_near && flow_guide_known(*f, *g, P.near_x) == PT_NONE) *p = P.near_x;
-            else if (P.has_far && flow_guide_known(*f, *g, P.far_x) == PT_NONE) *p = P.far_x;
-            return 2;
+            const double open_hi = g->far_d < far_end ? g->far_d : far_end;
+            // the estimate; if facts contradict it: halve what is open.  (An estimate beyond the bracket's far end is no
+            // contradiction: the flow runs into its cap, every midpoint is "not there yet", the far end is the point to evaluate.)
+            auto estimate = [&](double* ds, double* fs) CNF2_LI {
+                flow_guide_estimate(*g, scalefactor, ds, fs);
+                if (!(*ds > g->near_d && *ds < g->far_d)) *ds = 0.5 * (g->near_d + open_hi);
+            };
+            if (!(g->best_dt < HUGE_VAL)) {
+                // no value of the rule yet: the estimate comes from two gradients (flow_guide_seed) and is good to a few per
+                // cent; evaluate the rule right there (any point is a fact) and let its value make the estimate one to plan with
+                double ds, fs;
+                estimate(&ds, &fs);
+                const double de = ds < far_end ? ds : far_end;
+                *p = f->falling ? f->orig - de : f->orig + de;
+                if (flow_guide_known(*f, *g, *p) != PT_NONE || !(flow_distance(*f, *p) > 0.0)) *p = mid;
+                return 2;
+            }
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if (!g->plan_valid) {
+                    double ds, fs;
+                    estimate(&ds, &fs);
+                    const double half = 1e-3 * scalefactor * fs;
+                    FlowPlan     P;
+                    flow_guide_plan(*f, ds - half, ds + half, &P);
+                    g->plan_term = P.term_x;
+                    g->plan_near = P.near_x;
+                    g->plan_far = P.far_x;
+                    g->plan_has_term = P.has_term;
+                    g->plan_has_near = P.has_near;
+                    g->plan_has_far = P.has_far;
+                    g->plan_valid = true;
+                    attempt = 1;
+                }
+                if (g->plan_has_term && flow_guide_known(*f, *g, g->plan_term) == PT_NONE) {
+                    *p = g->plan_term;
+                    return 2;
+                }
+                if (g->plan_has_near && flow_guide_known(*f, *g, g->plan_near) == PT_NONE) {
+                    *p = g->plan_near;
+                    return 2;
+                }
+                if (g->plan_has_far && flow_guide_known(*f, *g, g->plan_far) == PT_NONE) {
+                    *p = g->plan_far;
+                    return 2;
+                }
+                g->plan_valid = false;            // all its points are known and the midpoint still is not: the plan is out of date
+            }
+            return 2;                             // (*p == mid)
         }
         f->it++;
         f->mid = mid;

@@ -21,6 +21,13 @@
 #else
 #define CNF2_FINISH_OCC
 #endif
+// The guided kernels hold a flow and what is known about it (~100 registers of state) around an evaluation that needs ~60:
+// left alone the compiler takes 200 - 212 registers (2 waves per SIMD); at 3 waves (<= 168, two dozen spilled outside the
+// quadrature loop) the lock-step kernel is 18 % faster, at 4 (<= 128, 95 spilled) 9 % (profiles/r05_d_ab_guided_occupancy.log)
+#ifndef CNF2_GUIDED_WAVES
+#define CNF2_GUIDED_WAVES 3
+#endif
+#define CNF2_GUIDED_OCC __attribute__((amdgpu_waves_per_eu(CNF2_GUIDED_WAVES, CNF2_GUIDED_WAVES)))
 
 namespace cnf2 {
 
@@ -268,31 +275,41 @@ struct FlowSupply {
     bool               more;          // the list has slots the wave has not read
 };
 // tops the queue up to at least `wanted` entries (or until the list is exhausted)
-// An entry's item_steps: ~0 = nothing in this slot; bit 63 set = the flow is still scouting (the second scout pass takes it,
-// `scouting` = true); else it waits for its quadratures (the finish pass).
+// An entry's item_steps: ~0 = nothing in this slot; bit 63 set = the flow is still scouting (the second scout pass takes it);
+// bit 62 = it waits for the step-per-round kernels; neither = for the guided bisection.  want_flags: the kind a kernel takes.
 #define FLOW_SCOUTING (1ull << 63)
+// bit 62 set = set aside for the step-per-round kernels (the gradient is not known to be monotone, or the flow closes in on a
+// root: cheap steps, many of them); neither bit = for the guided bisection
+#define FLOW_LITERAL (1ull << 62)
+#define FLOW_FLAGS (FLOW_SCOUTING | FLOW_LITERAL)
+#define FLOW_ITEM(e) (((e).item_steps & ~FLOW_FLAGS) >> 6)
 template <class Entry>
 __device__ __forceinline__ void flow_supply(FlowSupply<Entry>* q, Entry* queue, unsigned long long* next, const Entry* todo,
-                                            unsigned long long n_items, int wanted, bool scouting = false)
+                                            unsigned long long n_items, int wanted, unsigned long long want_flags = FLOW_LITERAL)
 {
     const int lane = threadIdx.x & 63;
     while (q->more && q->count < wanted) {
         if (q->pos >= q->end) {                              // reservation used up: a new one
+            // slots per reservation: FLOW_CHUNK on the scouts' long, sparse lists; on a short list (the packed lists of the guided
+            // kernels: every slot a flow) as many as leave every wavefront of the launch two reservations -- with 4 096 slots
+            // apiece a list of 10^6 flows would keep 250 of the 4 096 resident wavefronts busy and the rest idle
+            unsigned long long chunk = (n_items / ((unsigned long long)gridDim.x * 2ull) + 63ull) & ~63ull;
+            chunk = chunk < 64ull ? 64ull : (chunk > FLOW_CHUNK ? FLOW_CHUNK : chunk);
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(next, FLOW_CHUNK);
+            if (lane == 0) base = atomicAdd(next, chunk);
             base = __shfl(base, 0);
             if (base >= n_items) {
                 q->more = false;
                 break;
             }
             q->pos = base;
-            q->end = base + FLOW_CHUNK < n_items ? base + FLOW_CHUNK : n_items;
+            q->end = base + chunk < n_items ? base + chunk : n_items;
         }
         const unsigned long long slot = q->pos + lane;
         Entry e;
         e.item_steps = ~0ull;
         if (slot < q->end) e = todo[slot];
-        const bool               holds = e.item_steps != ~0ull && ((e.item_steps & FLOW_SCOUTING) != 0) == scouting;
+        const bool               holds = e.item_steps != ~0ull && (e.item_steps & FLOW_FLAGS) == want_flags;
         const unsigned long long mask = __ballot(holds);
         if (holds) queue[q->count + __popcll(mask & ((1ull << lane) - 1ull))] = e;
         q->count += __popcll(mask);
@@ -450,7 +467,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(Upd
                 n_pinned = 1;
             } else {
                 const SlopeTerms st = certainty_slope(c);
-                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30);
+                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30, !u.literal_finish);
                 if (r == 0) {
                     int          h = 0;
                     const double out = flow_end(f, sc.scalefactor, &h, false);
@@ -459,7 +476,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(Upd
                     n_done = 1;
                 } else {
                     aside = true;
-                    e.item_steps = (item << 6) | (unsigned long long)f.it | (r == 3 ? FLOW_SCOUTING : 0ull);
+                    e.item_steps = (item << 6) | (unsigned long long)f.it | (r == 3 ? FLOW_SCOUTING : (u.literal_finish ? FLOW_LITERAL : 0ull));
                     e.path = f.path;
                 }
             }
@@ -487,12 +504,12 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
     unsigned n_done = 0;
     if (u.mirror == 2 && u.flow_next[27] == 0ull) return;
     for (;;) {
-        flow_supply(&q, queue, next, (const FlowTodo*)todo, n_items, 64, true);
+        flow_supply(&q, queue, next, (const FlowTodo*)todo, n_items, 64, FLOW_SCOUTING);
         if (q.count == 0) break;
         FlowTodo e;
         const bool got = flow_pop(&q, queue, true, &e);
         if (got) {
-            const unsigned long long item = (e.item_steps & ~FLOW_SCOUTING) >> 6;
+            const unsigned long long item = FLOW_ITEM(e);
             CertaintyFlow c;
             int both = PARTNER_NONE;
             certainty_item(u, item, sc, &c, &both);
@@ -503,7 +520,8 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
             const SlopeTerms st = certainty_slope(c);
             int evals = 0;
             FlowTodo out;
-            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, 1 << 30, !u.literal_finish);
+            if (rs == 0) {
                 int          h = 0;
                 const double res = flow_end(f, sc.scalefactor, &h, false);
                 hits += h;
@@ -512,7 +530,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
                 out.path = 0;
                 n_done++;
             } else {
-                out.item_steps = (item << 6) | (unsigned long long)f.it;
+                out.item_steps = (item << 6) | (unsigned long long)f.it | (u.literal_finish ? FLOW_LITERAL : 0ull);
                 out.path = f.path;
                 if (u.mirror == 2) u.flow_next[26] = 1ull;
             }
@@ -525,9 +543,11 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
 }
 
 __global__ CNF2_FINISH_OCC __launch_bounds__(64) void certainty_finish_kernel(UpdateParams u, unsigned long long* next, const FlowTodo* todo,
-                                                              unsigned long long n_items, double* flow_out)
+                                                              unsigned long long n_max, double* flow_out, const unsigned long long* n_in,
+                                                              unsigned long long want_flags)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    const unsigned long long n_items = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;      // n_in: the list's length where only the device knows it
     __shared__ FlowTodo  queue[FLOW_QUEUE];
     FlowSupply<FlowTodo> q = {0ull, 0ull, 0, true};
     if (u.mirror == 2 && u.flow_next[26] == 0ull) return;
@@ -544,10 +564,10 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void certainty_finish_kernel(Up
     for (;;) {
         const int busy = __popcll(__ballot(have));
         if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
-            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy, want_flags);
             FlowTodo e;
             if (flow_pop(&q, queue, !have, &e)) {
-                item = e.item_steps >> 6;
+                item = FLOW_ITEM(e);
                 certainty_item(u, item, sc, &c, &both);
                 flow_begin(&f, grad, c.curprob, c.epsilon, sc.scalefactor, false);
                 flow_replay(&f, e.path, (int)(e.item_steps & 63));
@@ -661,12 +681,13 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
             const SlopeTerms st = haplo_slope(h);
             // (one pass: most weight flows scout for dozens of steps, so a second pass takes nearly all of them up again -- measured
             // 1.2 % slower over 40 iterations, tools/ab_scout.py)
-            if (flow_scout(&f, grad, st, sc.scalefactor, &evals) == 0) {
+            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, 1 << 30, !u.literal_finish);
+            if (rs == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
             } else {
                 aside = true;
-                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it;
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (u.literal_finish ? FLOW_LITERAL : 0ull);
                 e.path = f.path;
                 e.similarity = similarity;
             }
@@ -681,9 +702,10 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
 }
 
 __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
-                                                                unsigned long long n_items)
+                                                                unsigned long long n_max, const unsigned long long* n_in, unsigned long long want_flags)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    const unsigned long long n_items = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
     __shared__ HaploTodo  queue[FLOW_QUEUE];
     FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
     bool               have = false;
@@ -698,12 +720,12 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(
     for (;;) {
         const int busy = __popcll(__ballot(have));
         if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
-            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy, want_flags);
             HaploTodo e;
             if (flow_pop(&q, queue, !have, &e)) {
                 size_t k;
                 int    r;
-                haplo_item(u, e.item_steps >> 6, &row_i, &k, &r);
+                haplo_item(u, FLOW_ITEM(e), &row_i, &k, &r);
                 const double hw = u.hw[row_i];
                 haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
                 flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
@@ -738,11 +760,19 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(
 // results, are those of the literal kernels to the bit (tests/test_host_update.py on the host; the GPU suite compares the
 // passes); what changes is that a flow which reaches its step size takes 3 - 4 rounds instead of ~10.
 // KIND 0: genotype certainties (FlowTodo), 1: haplotype weights (HaploTodo).
+// A flow lives 3 - 5 rounds here and taking one up (loads, the prior's logarithms, the gradient at the start, the replay, the
+// slope bound, the seed) is executed by the whole wavefront for the lanes that are free: flows are taken up in batches --
+// when at most 64 - GUIDED_REFILL lanes are still busy -- so that the set-up runs nearly full and a batch's lanes go
+// through their rounds together.
+#ifndef GUIDED_REFILL
+#define GUIDED_REFILL 48
+#endif
 template <int KIND, class Entry>
-__global__ CNF2_FINISH_OCC __launch_bounds__(64) void guided_finish_kernel(UpdateParams u, unsigned long long* next, const Entry* todo,
-                                                                           unsigned long long n_items, double* flow_out)
+__global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_finish_kernel(UpdateParams u, unsigned long long* next, const Entry* todo,
+                                                                           const unsigned long long* n_in, unsigned long long n_max, double* flow_out)
 {
     const StepControl  sc = {u.scalefactor, u.entropyfactor};
+    const unsigned long long n_items = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
     __shared__ Entry   queue[FLOW_QUEUE];
     FlowSupply<Entry>  q = {0ull, 0ull, 0, true};
     if (KIND == 0 && u.mirror == 2 && u.flow_next[26] == 0ull) return;
@@ -760,13 +790,13 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void guided_finish_kernel(Updat
     auto grad = [&](double x) CNF2_LI { return KIND == 0 ? certainty_rgradient(c, x) : haplo_rgradient(h, x); };
     for (;;) {
         const int busy = __popcll(__ballot(have));
-        if ((q.more || q.count > 0) && busy <= 64 - FLOW_REFILL) {
-            flow_supply(&q, queue, next, todo, n_items, 64 - busy);
+        if ((q.more || q.count > 0) && busy <= 64 - GUIDED_REFILL) {
+            flow_supply(&q, queue, next, todo, n_items, 64 - busy, 0ull);
             Entry e;
             if (flow_pop(&q, queue, !have, &e)) {
                 double start;
                 if (KIND == 0) {
-                    item = e.item_steps >> 6;
+                    item = FLOW_ITEM(e);
                     certainty_item(u, item, sc, &c, &both);
                     st = certainty_slope(c);
                     start = c.curprob;
@@ -774,7 +804,7 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void guided_finish_kernel(Updat
                 } else {
                     size_t k;
                     int    r;
-                    haplo_item(u, e.item_steps >> 6, &row_i, &k, &r);
+                    haplo_item(u, FLOW_ITEM(e), &row_i, &k, &r);
                     start = u.hw[row_i];
                     haplo_flow_terms(start, u.acc_hb[k], u.acc_hc[k], haplo_similarity_of(e), u.ratio[k], u.children[r], u.descendants[r], sc, &h);
                     st = haplo_slope(h);
@@ -813,6 +843,229 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void guided_finish_kernel(Updat
     }
     if (hits) atomicAdd(u.hits, hits);
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 8 : 12) : nullptr, n_points, n_rounds, n_evals, n_why1);
+}
+
+// The scouts' list has a slot per flow they looked at, and most slots are empty (a certainty flow exists only where a
+// record has evidence at the marker: a quarter of the slots of a pass; the flows that ended in the scout are gone too).
+// Three small kernels pack the entries that hold a flow into a second list, in no particular order (a flow's result does
+// not depend on who runs it or when): entries per wavefront-sized stretch of 256 slots, an exclusive scan of those counts
+// by one block, the scatter.  What they move is 16 - 24 bytes per slot: a fraction of a millisecond per pass.
+template <class Entry>
+__device__ __forceinline__ bool todo_holds(const Entry& e) { return e.item_steps != ~0ull && !(e.item_steps & FLOW_FLAGS); }
+#define TODO_STRETCH 256ull
+template <class Entry>
+__global__ __launch_bounds__(256) void todo_count_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
+                                                         unsigned long long* counts)
+{
+    const unsigned long long n = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int                lane = threadIdx.x & 63;
+    if (wave * TODO_STRETCH >= n_max) return;
+    unsigned c = 0;
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long slot = wave * TODO_STRETCH + (unsigned long long)k * 64 + lane;
+        bool holds = false;
+        if (slot < n) holds = todo_holds(todo[slot]);
+        c += __popcll(__ballot(holds));
+    }
+    if (lane == 0) counts[wave] = c;
+}
+// exclusive scan of counts[0 .. n_waves) in place by ONE block; total[0] = their sum
+__global__ __launch_bounds__(1024) void todo_scan_kernel(unsigned long long* counts, unsigned long long n_waves, unsigned long long* total)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (unsigned long long base = 0; base < n_waves; base += 1024) {
+        const unsigned long long i = base + threadIdx.x;
+        const unsigned long long v = i < n_waves ? counts[i] : 0ull;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                       // Hillis-Steele inclusive scan
+            const unsigned long long a = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n_waves) counts[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+template <class Entry>
+__global__ __launch_bounds__(256) void todo_scatter_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
+                                                           const unsigned long long* offsets, Entry* dense)
+{
+    const unsigned long long n = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int                lane = threadIdx.x & 63;
+    if (wave * TODO_STRETCH >= n) return;
+    unsigned long long at = offsets[wave];
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long slot = wave * TODO_STRETCH + (unsigned long long)k * 64 + lane;
+        Entry e;
+        e.item_steps = ~0ull;
+        if (slot < n) e = todo[slot];
+        const bool               holds = todo_holds(e);
+        const unsigned long long mask = __ballot(holds);
+        if (holds) dense[at + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+        at += __popcll(mask);
+    }
+}
+// src[0 .. *n_in or n_max) -> dst packed, *total = entries.  counts: scratch of ceil(n_max / 256) + 1 values.
+template <class Entry>
+static void launch_todo_pack(const Entry* src, const unsigned long long* n_in, size_t n_max, Entry* dst, unsigned long long* counts,
+                             unsigned long long* total, hipStream_t stream)
+{
+    const size_t waves = (n_max + TODO_STRETCH - 1) / TODO_STRETCH, blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(todo_count_kernel<Entry>, dim3((unsigned)blocks), dim3(256), 0, stream, src, n_in, (unsigned long long)n_max, counts);
+    hipLaunchKernelGGL(todo_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (unsigned long long)waves, total);
+    hipLaunchKernelGGL(todo_scatter_kernel<Entry>, dim3((unsigned)blocks), dim3(256), 0, stream, src, n_in, (unsigned long long)n_max,
+                       (const unsigned long long*)counts, dst);
+}
+
+// The first rounds of the guided bisection in lock step: one thread per slot of the scout's list.  A flow that was set aside
+// lives 3 - 5 rounds in the guided form, so in the persistent kernel above a wavefront takes flows up nearly every round --
+// set-up code (loads, the prior's logarithms, the gradient at the start, the replay, the slope bound) that runs for the 16
+// or so lanes that are free while the others wait.  Here every lane sets its flow up at once, all lanes ask for their
+// first, second, ... point together, and a flow that has not ended after GUIDED_ROUNDS points goes back on the list (its
+// steps and decisions so far) for the persistent kernel, which then has little left to do.
+#ifndef GUIDED_ROUNDS
+#define GUIDED_ROUNDS 4
+#endif
+template <int KIND, class Entry>
+__global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_rounds_kernel(UpdateParams u, Entry* todo, const unsigned long long* n_in,
+                                                                           unsigned long long n_max, double* flow_out)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long n_items = *n_in < n_max ? *n_in : n_max;
+    if ((t & ~63ull) >= n_items) return;
+    Entry e;
+    e.item_steps = ~0ull;
+    if (t < n_items) e = todo[t];
+    bool               have = todo_holds(e);
+    const bool         had = have;
+    int                both = PARTNER_NONE;
+    unsigned long long item = 0;
+    size_t             row_i = 0;
+    CertaintyFlow      c;
+    HaploFlow          h;
+    FlowState          f;
+    FlowGuide          g;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_points = 0, n_rounds = 0, n_evals = 0, n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return KIND == 0 ? certainty_rgradient(c, x) : haplo_rgradient(h, x); };
+    if (have) {
+        double start;
+        item = FLOW_ITEM(e);
+        if (KIND == 0) {
+            certainty_item(u, item, sc, &c, &both);
+            st = certainty_slope(c);
+            start = c.curprob;
+            f.epsilon = c.epsilon;
+        } else {
+            size_t k;
+            int    r;
+            haplo_item(u, item, &row_i, &k, &r);
+            start = u.hw[row_i];
+            haplo_flow_terms(start, u.acc_hb[k], u.acc_hc[k], haplo_similarity_of(e), u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+            st = haplo_slope(h);
+            f.epsilon = h.epsilon;
+        }
+        flow_begin(&f, grad, start, f.epsilon, sc.scalefactor, false);
+        flow_replay(&f, e.path, (int)(e.item_steps & 63));
+        flow_guide_begin(&g);
+        flow_guide_try_mono(f, &g, st);
+        g.mono_tried = true;
+        flow_guide_seed(f, &g, grad, st, sc.scalefactor);
+    }
+    for (int round = 0; round <= GUIDED_ROUNDS; round++) {
+        if (!__ballot(have)) break;
+        int    rc = 0;
+        double p = 0.0;
+        if (have) {
+            n_rounds++;
+            rc = flow_guide_next(&f, &g, st, sc.scalefactor, &p);
+            if (rc == 0) {
+                int          hh = 0;
+                const double res = flow_end(f, sc.scalefactor, &hh, false);
+                hits += hh;
+                if (KIND == 0) certainty_store(u, flow_out, item, both, res, &hits, hh);
+                else u.hw[row_i] = res;
+                have = false;
+                n_why1 += f.why == 1;
+                e.item_steps = ~0ull;
+            }
+        }
+        if (round == GUIDED_ROUNDS) break;
+        if (rc == 2) flow_guide_feed(f, &g, p, flow_point(f, grad, p, sc.scalefactor), sc.scalefactor);
+        else if (rc == 3) flow_guide_feed_clear(f, &g, p, flow_pace(grad, p, f.epsilon));
+    }
+    if (t < n_items && had) {
+        if (have) {                                  // not ended: back on the list as it stands
+            e.item_steps = (item << 6) | (unsigned long long)f.it;
+            e.path = f.path;
+        }
+        todo[t] = e;
+    }
+    if (had) {
+        n_points = g.points;
+        n_evals = g.evals;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, n_points, n_rounds, n_evals, n_why1);
+}
+
+static void launch_literal_tail(const UpdateParams& u, unsigned long long* next, const FlowTodo* list, const unsigned long long* n_in, size_t n,
+                                unsigned long long want_flags, unsigned grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(certainty_finish_kernel, dim3(grid), dim3(64), 0, stream, u, next, list, (unsigned long long)n, u.flow_out, n_in, want_flags);
+}
+static void launch_literal_tail(const UpdateParams& u, unsigned long long* next, const HaploTodo* list, const unsigned long long* n_in, size_t n,
+                                unsigned long long want_flags, unsigned grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(haploweight_finish_kernel, dim3(grid), dim3(64), 0, stream, u, next, list, (unsigned long long)n, n_in, want_flags);
+}
+// The flows the scouts set aside among the n slots of u.todo, the guided way: pack them, GUIDED_ROUNDS points in lock step,
+// pack what is left, the same again, and the persistent kernel for the few that are still going (flows that close in on a
+// root next to which the rule's value stays under the band take dozens of points, like the literal bisection).
+// u.flow_next[28], [29]: the packed lists' lengths (device side: nothing here waits for the host).
+template <int KIND, class Entry>
+static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
+{
+    const size_t        resident = (size_t)256 * 16;
+    const size_t        w = (n + 63) / 64;
+    const unsigned      grid = (unsigned)(w < resident ? w : resident);
+    Entry*              l0 = (Entry*)u.todo;        // the scouts' list: a slot per flow they looked at
+    Entry*              l1 = (Entry*)u.todo2;       // the flows set aside for the guided bisection, packed
+    Entry*              l2 = (Entry*)u.todo3;       // what the first lock-step kernel leaves, packed
+    unsigned long long* n1 = u.flow_next + 28;
+    unsigned long long* n2 = u.flow_next + 29;
+    double*             out = KIND == 0 ? u.flow_out : nullptr;
+    launch_todo_pack<Entry>(l0, nullptr, n, l1, u.todo_counts, n1, stream);
+    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
+                       (unsigned long long)n, out);
+    launch_todo_pack<Entry>(l1, n1, n, l2, u.todo_counts, n2, stream);
+    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l2, (const unsigned long long*)n2,
+                       (unsigned long long)n, out);
+    // what is left of those: flows that close in on a root next to which the rule's value stays under the band (a quadrature
+    // or a sign per step, dozens of steps: the literal bisection's own pace) -- the step-per-round kernels with their time
+    // bound take them from where they stand (CNF2_X_GUIDED_TAIL: the guided persistent kernel instead, A/B) ...
+    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
+#ifdef CNF2_X_GUIDED_TAIL
+    hipLaunchKernelGGL((guided_finish_kernel<KIND, Entry>), dim3(grid), dim3(64), 0, stream, u, u.flow_next, (const Entry*)l2,
+                       (const unsigned long long*)n2, (unsigned long long)n, out);
+#else
+    launch_literal_tail(u, u.flow_next, l2, n2, n, 0ull, grid, stream);
+#endif
+    // ... and the flows the scouts set aside for those kernels in the first place
+    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
+    launch_literal_tail(u, u.flow_next, l0, nullptr, n, FLOW_LITERAL, grid, stream);
 }
 
 void launch_update_pass(const UpdateParams& u, hipStream_t stream)
@@ -854,10 +1107,9 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         }
         if (u.literal_finish)
             hipLaunchKernelGGL(certainty_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
-                               (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+                               (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out, (const unsigned long long*)nullptr, FLOW_LITERAL);
         else
-            hipLaunchKernelGGL((guided_finish_kernel<0, FlowTodo>), dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u,
-                               u.flow_next, (const FlowTodo*)u.todo, (unsigned long long)n, u.flow_out);
+            launch_guided<0, FlowTodo>(u, n, stream);
     }
     }
     hipLaunchKernelGGL(certainty_pick_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, u, u.flow_out);
@@ -871,10 +1123,9 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         const size_t w = (n + 63) / 64;
         if (u.literal_finish)
             hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
-                               (const HaploTodo*)u.todo, (unsigned long long)n);
+                               (const HaploTodo*)u.todo, (unsigned long long)n, (const unsigned long long*)nullptr, FLOW_LITERAL);
         else
-            hipLaunchKernelGGL((guided_finish_kernel<1, HaploTodo>), dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u,
-                               u.flow_next, (const HaploTodo*)u.todo, (unsigned long long)n, (double*)nullptr);
+            launch_guided<1, HaploTodo>(u, n, stream);
     }
 }
 

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnf2host.so")
+# CNF2HOST_LIB: a copy of the host library next to another build of libcnf2hip.so (kernel A/B timing: it binds the libcnf2hip.so of its own directory)
+LIB_PATH = os.environ.get("CNF2HOST_LIB") or os.path.join(_HERE, "libcnf2host.so")
 
 SYMBOLS = ["cnf2h_create", "cnf2h_create_on", "cnf2h_destroy", "cnf2h_last_error", "cnf2h_postmarkerdata", "cnf2h_iteration",
            "cnf2h_dump", "cnf2h_deserialize", "cnf2h_get_state", "cnf2h_set_block", "cnf2h_balanced_block", "cnf2h_set_partition", "cnf2h_get_partition", "cnf2h_set_update_flags", "cnf2h_reserve", "cnf2h_get_timing",

@@ -332,6 +332,11 @@ int    cnf2_unpack_rows(cnf2_ctx *ctx, const int32_t *recs, int n, const void *d
  * scout set aside: steps taken in the finish kernel; lane slots offered (steps / slots = lane utilisation); quadratures;
  * flows that ended because the tolerance was met.  Collected only when the environment holds CNF2_UPDATE_STATS. */
 int cnf2_update_stats(cnf2_ctx *ctx, uint64_t *out16);
+/* The same for the lock-step kernels of the guided bisection (cnf2_update.h; the flows the scouts set aside go through
+ * them first, out16[8..15] of cnf2_update_stats then describe the persistent kernel that takes what they leave):
+ * out8[0..3] certainties, out8[4..7] haplotype weights: literal points evaluated; lane slots offered; gradient evaluations;
+ * flows that ended because the tolerance was met. */
+int cnf2_update_stats_guided(cnf2_ctx *ctx, uint64_t *out8);
 /* The accumulators the context holds (what cnf2_sweep_accumulate left and cnf2_update_pass rewrote when they were called
  * with NULL accumulator pointers): host copies infprobs[n_rec][M][2][2], haplobase / haplocount[n_rec][M]; any pointer may
  * be NULL.  cnf2_upload_accumulators is the reverse (a multi-process driver whose transport moves host memory sums the

@@ -701,7 +701,7 @@ void shim_flow(int kind, double y, double g, double h, double e, double c0, doub
         const int rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals);
         out[5] = evals;
         out[6] = rc;
-        if (rc == 2) {
+        if (rc == 2 || rc == 5) {
             const unsigned long long path = f.path;
             const int                steps = f.it, spared = f.spared;
             cnf2::FlowState g2;
@@ -860,6 +860,71 @@ void shim_certainty_flows_guided(int n, const double* inf, const int32_t* v, con
         o[5] = evals;
         o[6] = g.evals;
         o[7] = g.points;
+    }
+}
+// The same for haplotype-weight flows (tuning aid): per flow hw, haplobase, haplocount (as the accumulators hold them), the two
+// alleles and their certainties, phase ratio, children, descendants.  out[n][10] = literal result, hits, gradient evaluations;
+// guided result, hits, scout evaluations, guided evaluations, guided points; what the scout returned; how the bisection ended (why).
+void shim_haplo_flows_guided(int n, const double* hw, const double* hb, const double* hc, const int32_t* a0, const int32_t* a1,
+                             const double* s0, const double* s1, const double* ratio, const int32_t* children, const int32_t* desc,
+                             double scalefactor, int scout_first, int hand_over, double* out)
+{
+    cnf2::StepControl sc = {scalefactor, 1.0};
+    for (int i = 0; i < n; i++) {
+        double* o = out + (size_t)i * 10;
+        for (int k = 0; k < 10; k++) o[k] = 0;
+        double b = hb[i], c = hc[i];
+        cnf2::HaploFlow h;
+        cnf2::haplo_flow_setup(hw[i], &b, &c, a0[i], a1[i], s0[i], s1[i], ratio[i], children[i], desc[i], sc, &h);
+        auto grad = [&](double x) { return cnf2::haplo_rgradient(h, x); };
+        const cnf2::SlopeTerms st = cnf2::haplo_slope(h);
+        {
+            cnf2::FlowState f;
+            cnf2::flow_begin(&f, grad, hw[i], h.epsilon, scalefactor, false);
+            while (cnf2::flow_advance(&f, grad, scalefactor)) {}
+            int hits = 0;
+            o[0] = cnf2::flow_end(f, scalefactor, &hits, false);
+            o[1] = hits;
+            o[2] = f.pinned ? 1 : f.it + 15 * f.quads;
+            o[9] = f.why + 10 * f.it;
+        }
+        cnf2::FlowState f;
+        cnf2::FlowGuide g;
+        cnf2::flow_begin(&f, grad, hw[i], h.epsilon, scalefactor, false);
+        cnf2::flow_guide_begin(&g);
+        int evals = 0, rc = 2;
+        if (f.pinned) {
+            while (cnf2::flow_advance(&f, grad, scalefactor)) {}
+            rc = -1;
+        } else {
+            if (scout_first) rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals, 1 << 30, hand_over != 0);
+            if (rc != 0) {
+                double p;
+                cnf2::flow_guide_try_mono(f, &g, st);
+                g.mono_tried = true;
+                cnf2::flow_guide_seed(f, &g, grad, st, scalefactor);
+                const bool trace = getenv("SHIM_TRACE_ONE") && i == atoi(getenv("SHIM_TRACE_ONE"));
+                if (trace) printf("flow %d orig %.9g eps %.3g lo %.9g hi %.9g falling %d G0 %.4g mono %d capped %d it %d\n", i, f.orig, f.epsilon, f.lo, f.hi, (int)f.falling, 1 / f.g0, (int)g.mono, (int)g.capped, f.it);
+                for (int rcn; g.points < 320 && (rcn = cnf2::flow_guide_next(&f, &g, st, scalefactor, &p)) != 0;) {
+                    if (rcn == 3) {
+                        cnf2::flow_guide_feed_clear(f, &g, p, cnf2::flow_pace(grad, p, f.epsilon));
+                        continue;
+                    }
+                    const cnf2::FlowPoint r = cnf2::flow_point(f, grad, p, scalefactor);
+                    cnf2::flow_guide_feed(f, &g, p, r, scalefactor);
+                    if (trace) printf("   it %2d mono %d point d %.9g (mid d %.9g) kind %d t/sf %.6f G %.4g  near %.9g far %.9g\n", f.it, (int)g.mono,
+                                      cnf2::flow_distance(f, p), cnf2::flow_distance(f, (f.lo + f.hi) / 2), r.kind, r.t / scalefactor, 1 / r.pace, g.near_d, g.far_d);
+                }
+                if (trace) printf("   ended it %d why %d\n", f.it, f.why);
+            }
+        }
+        int hits = 0;
+        o[3] = cnf2::flow_end(f, scalefactor, &hits, false);
+        o[4] = hits;
+        o[5] = evals;
+        o[6] = g.evals;
+        o[7] = g.points;
+        o[8] = rc;
     }
 }
 double shim_adapt_scalefactor(double scalefactor, int hits, int* old, int n_analysed)

@@ -1,7 +1,7 @@
 """Clean A/B of the update pass's variants on one box: the same deterministic run (CNF2_DETERMINISTIC accumulators: the
 variants are bit-identical, so the trajectories are) repeated with different update forms (flags of cnf2h_set_update_flags);
 per-iteration wall time of each.  usage: python tools/ab_scout.py [families=500] [snps=2500] [chroms=4] [iterations=30] [forms]
-forms = comma list of mirror, both, both_one_scout, plain (default: both,both_one_scout)"""
+forms = comma list of mirror, both, both_one_scout, plain, mirror_literal_finish, both_literal_finish (default: both,both_one_scout)"""
 import os
 import sys
 import time
@@ -19,7 +19,8 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 name = "form"
 values = (sys.argv[5] if len(sys.argv) > 5 else "both,both_one_scout").split(",")
 FORMS = {"mirror": 0, "both": capi.UPDATE_BOTH_FLOWS, "both_one_scout": capi.UPDATE_BOTH_FLOWS | capi.UPDATE_ONE_SCOUT,
-         "plain": capi.UPDATE_PLAIN}
+         "plain": capi.UPDATE_PLAIN, "mirror_literal_finish": capi.UPDATE_LITERAL_FINISH,
+         "both_literal_finish": capi.UPDATE_BOTH_FLOWS | capi.UPDATE_LITERAL_FINISH}
 ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 times, states = {}, {}
 for rep in range(2):

@@ -27,8 +27,9 @@ for it in range(iters):
     t = time.time()
     run.iteration(None)
     dt = time.time() - t
-    out = np.zeros(16, np.uint64)
+    out = np.zeros(24, np.uint64)
     L.cnf2_update_stats(run.context(), out.ctypes.data_as(C.c_void_p))
+    L.cnf2_update_stats_guided(run.context(), out[16:].ctypes.data_as(C.c_void_p))
     st = run.L.cnf2h_get_state  # noqa: F841
     sf = C.c_double(0)
     hits = C.c_int(0)
@@ -42,4 +43,8 @@ for it in range(iters):
               "%.1f steps and %.2f quadratures each, lanes %.2f, %.0f%% ended by the tolerance"
               % (name, flows, 100 * a[3] / max(flows, 1), 100 * a[2] / max(flows, 1), a[1] / max(flows - a[3], 1), 100 * todo / max(flows, 1),
                  b[0] / max(todo, 1), b[2] / max(todo, 1), b[0] / max(b[1], 1), 100 * b[3] / max(todo, 1)), flush=True)
+    # the guided kernels (last chromosome's pass): lock-step rounds [16..23], persistent tail [8..15]
+    for name, a, b in (("certainty  ", out[16:20].astype(float), out[8:12].astype(float)), ("haploweight", out[20:24].astype(float), out[12:16].astype(float))):
+        print("       %s guided: lock-step kernels %.3g points in %.3g lane-rounds (%.3g evaluations, %.3g flows ended by the tolerance); "
+              "persistent tail %.3g points in %.3g lane-rounds (%.3g evaluations)" % (name, a[0], a[1], a[2], a[3], b[0], b[1], b[2]), flush=True)
 run.close()
