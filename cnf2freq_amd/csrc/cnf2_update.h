@@ -1097,7 +1097,7 @@ CNF2_UHD void flow_guide_estimate(const FlowGuide& g, double scalefactor, double
 }
 // the start and one gradient evaluation at the distance an Euler step would reach seed the model (slope from the two)
 template <class G>
-CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, const SlopeTerms& st, double scalefactor)
+CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, const SlopeTerms& st, double scalefactor, bool sharpen = true)
 {
     const double f0 = 1.0 / fabs(f.g0);
     g->anchor_d = 0.0;
@@ -1122,7 +1122,7 @@ CNF2_UHD void flow_guide_seed(const FlowState& f, FlowGuide* g, G&& rgradient, c
     // Sharpen the estimate before anything is evaluated literally: the time to the model's answer by a 5-point rule (the
     // integrand is smooth this far from a root, and nothing depends on this value but where the first points are put),
     // the gradient there, and the model anchored on the two.  Six evaluations instead of the sixteen of a literal point.
-    if (g->mono && de < far_end) {
+    if (sharpen && g->mono && de < far_end) {
         double ds, fs;
         flow_guide_estimate(*g, scalefactor, &ds, &fs);
         if (ds > 0.0 && ds < far_end) {
@@ -1216,7 +1216,9 @@ CNF2_UHD void flow_guide_plan(const FlowState& f, double band_lo, double band_hi
 // The next thing to do: 0 = the flow has ended; 2 = evaluate *p literally (flow_point) and hand the result to flow_guide_feed;
 // 3 = evaluate the gradient alone at *p (flow_pace) and hand 1 / G to flow_guide_feed_clear.
 // Midpoints that facts cover are decided here, in the literal order, with flow_decide.
-CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, double scalefactor, double* p)
+// arbiter_only: decide what the facts decide and stop at the first midpoint they do not (2, *p = that midpoint) without choosing a
+// better point to evaluate (the lock-step kernel that evaluates a whole plan's points in a row asks this way at its end)
+CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, double scalefactor, double* p, bool arbiter_only = false)
 {
     for (;;) {
         if (!f->live) return 0;
@@ -1235,7 +1237,7 @@ CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, d
         const int    kind = flow_guide_known(*f, *g, mid);
         if (kind == PT_NONE) {
             *p = mid;
-            if (!g->mono || g->spec_left <= 0) return 2;              // literal steps until the gradient is known to be monotone
+            if (!g->mono || g->spec_left <= 0 || arbiter_only) return 2;   // literal steps until the gradient is known to be monotone
             g->spec_left--;
             const double far_end = flow_distance(*f, f->falling ? f->lo : f->hi);
             const double open_hi = g->far_d < far_end ? g->far_d : far_end;
@@ -1301,6 +1303,28 @@ CNF2_UHD int flow_guide_next(FlowState* f, FlowGuide* g, const SlopeTerms& st, d
         }
         flow_decide(f, kind == PT_NEAR ? 0.0 : (scalefactor + 0.1) * 1.1, scalefactor);
     }
+}
+// The points of one plan, to be evaluated in a row (the first lock-step kernel): the plan made from the present estimate; x[0..2] =
+// its last midpoint and the two ends of the bracket it halves, use[k] = whether the point exists and nothing is known about it
+CNF2_UHD void flow_guide_points(const FlowState& f, FlowGuide* g, double scalefactor, double x[3], bool use[3])
+{
+    const double far_end = flow_distance(f, f.falling ? f.lo : f.hi);
+    double       ds, fs;
+    flow_guide_estimate(*g, scalefactor, &ds, &fs);
+    if (!(ds > g->near_d && ds < g->far_d)) ds = 0.5 * (g->near_d + (g->far_d < far_end ? g->far_d : far_end));
+    const double half = 1e-3 * scalefactor * fs;
+    FlowPlan     P;
+    flow_guide_plan(f, ds - half, ds + half, &P);
+    g->plan_term = x[0] = P.term_x;
+    g->plan_near = x[1] = P.near_x;
+    g->plan_far = x[2] = P.far_x;
+    g->plan_has_term = P.has_term;
+    g->plan_has_near = P.has_near;
+    g->plan_has_far = P.has_far;
+    g->plan_valid = true;
+    use[0] = P.has_term && flow_guide_known(f, *g, P.term_x) == PT_NONE;
+    use[1] = P.has_near && flow_guide_known(f, *g, P.near_x) == PT_NONE;
+    use[2] = P.has_far && flow_guide_known(f, *g, P.far_x) == PT_NONE;
 }
 // a whole flow, the guided way (host tests; the device kernels run flow_guide_next / flow_point / flow_guide_feed per round)
 template <class G>

@@ -870,30 +870,30 @@ __global__ __launch_bounds__(256) void todo_count_kernel(const Entry* todo, cons
     }
     if (lane == 0) counts[wave] = c;
 }
-// exclusive scan of counts[0 .. n_waves) in place by ONE block; total[0] = their sum
+// exclusive scan of counts[0 .. n_waves) in place by ONE block; total[0] = their sum.  A thread sums a stretch of its own,
+// the 1 024 sums are scanned in LDS, the thread writes its stretch's running sums: three barriers whatever the length.
 __global__ __launch_bounds__(1024) void todo_scan_kernel(unsigned long long* counts, unsigned long long n_waves, unsigned long long* total)
 {
     __shared__ unsigned long long part[1024];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0ull;
+    const unsigned long long per = (n_waves + 1023ull) / 1024ull;
+    const unsigned long long lo = threadIdx.x * per, hi = lo + per < n_waves ? lo + per : n_waves;
+    unsigned long long       sum = 0ull;
+    for (unsigned long long i = lo; i < hi; i++) sum += counts[i];
+    part[threadIdx.x] = sum;
     __syncthreads();
-    for (unsigned long long base = 0; base < n_waves; base += 1024) {
-        const unsigned long long i = base + threadIdx.x;
-        const unsigned long long v = i < n_waves ? counts[i] : 0ull;
-        part[threadIdx.x] = v;
+    for (int o = 1; o < 1024; o <<= 1) {                           // Hillis-Steele inclusive scan of the 1 024 sums
+        const unsigned long long a = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0ull;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {                       // Hillis-Steele inclusive scan
-            const unsigned long long a = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0ull;
-            __syncthreads();
-            part[threadIdx.x] += a;
-            __syncthreads();
-        }
-        if (i < n_waves) counts[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
+        part[threadIdx.x] += a;
         __syncthreads();
     }
-    if (threadIdx.x == 0) total[0] = carry;
+    unsigned long long run = part[threadIdx.x] - sum;
+    for (unsigned long long i = lo; i < hi; i++) {
+        const unsigned long long v = counts[i];
+        counts[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023) total[0] = part[1023];
 }
 template <class Entry>
 __global__ __launch_bounds__(256) void todo_scatter_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
@@ -1021,6 +1021,99 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_rounds_kernel(Updat
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, n_points, n_rounds, n_evals, n_why1);
 }
 
+// The first of the lock-step kernels: no decisions between the points.  Nine flows in ten take exactly the same course --
+// estimate, plan, the plan's three points, the bisection's steps from the facts they leave -- so the course is laid out
+// as straight-line code: the set-up, the estimate (the certainties': one literal evaluation where an Euler step lands and
+// Newton on its value; the weights': a 5-point rule, their integrands being the smoother ones), ONE plan, its points one
+// after the other, the steps.  What the adaptive kernel above spends between its points -- the steps' loop and the plan's,
+// each as long as the wavefront's longest lane, every round -- is spent once.  A flow whose gradient is not known to be
+// monotone, or that is still going after its steps, goes on the list for the adaptive kernel as it stands.
+template <int KIND, class Entry>
+__global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_first_kernel(UpdateParams u, Entry* todo, const unsigned long long* n_in,
+                                                                          unsigned long long n_max, double* flow_out)
+{
+    const StepControl        sc = {u.scalefactor, u.entropyfactor};
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long n_items = *n_in < n_max ? *n_in : n_max;
+    if ((t & ~63ull) >= n_items) return;
+    Entry e;
+    e.item_steps = ~0ull;
+    if (t < n_items) e = todo[t];
+    const bool         had = todo_holds(e);
+    int                both = PARTNER_NONE;
+    unsigned long long item = 0;
+    size_t             row_i = 0;
+    CertaintyFlow      c;
+    HaploFlow          h;
+    FlowState          f;
+    FlowGuide          g;
+    SlopeTerms         st;
+    int                hits = 0;
+    unsigned           n_why1 = 0;
+    auto grad = [&](double x) CNF2_LI { return KIND == 0 ? certainty_rgradient(c, x) : haplo_rgradient(h, x); };
+    bool go = false;
+    if (had) {
+        double start;
+        item = FLOW_ITEM(e);
+        if (KIND == 0) {
+            certainty_item(u, item, sc, &c, &both);
+            st = certainty_slope(c);
+            start = c.curprob;
+            f.epsilon = c.epsilon;
+        } else {
+            size_t k;
+            int    r;
+            haplo_item(u, item, &row_i, &k, &r);
+            start = u.hw[row_i];
+            haplo_flow_terms(start, u.acc_hb[k], u.acc_hc[k], haplo_similarity_of(e), u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+            st = haplo_slope(h);
+            f.epsilon = h.epsilon;
+        }
+        flow_begin(&f, grad, start, f.epsilon, sc.scalefactor, false);
+        flow_replay(&f, e.path, (int)(e.item_steps & 63));
+        flow_guide_begin(&g);
+        flow_guide_try_mono(f, &g, st);
+        g.mono_tried = true;
+        flow_guide_seed(f, &g, grad, st, sc.scalefactor, KIND == 1);
+        go = g.mono;
+    }
+    double p = 0.0;
+    int    rc = 0;
+    // the estimate to plan with: a rule's value (literal: a fact as well) where none is there yet
+    if (go && !(g.best_dt < HUGE_VAL)) {
+        rc = flow_guide_next(&f, &g, st, sc.scalefactor, &p);
+        if (rc == 2) flow_guide_feed(f, &g, p, flow_point(f, grad, p, sc.scalefactor), sc.scalefactor);
+        else if (rc == 3) flow_guide_feed_clear(f, &g, p, flow_pace(grad, p, f.epsilon));
+        go = rc != 0;
+    }
+    if (go && f.live && !g.capped) {
+        double x[3];
+        bool   use[3];
+        flow_guide_points(f, &g, sc.scalefactor, x, use);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (use[k] && flow_guide_known(f, g, x[k]) == PT_NONE) flow_guide_feed(f, &g, x[k], flow_point(f, grad, x[k], sc.scalefactor), sc.scalefactor);
+    }
+    if (had) {
+        rc = flow_guide_next(&f, &g, st, sc.scalefactor, &p, true);
+        if (rc == 0) {
+            int          hh = 0;
+            const double res = flow_end(f, sc.scalefactor, &hh, false);
+            hits += hh;
+            if (KIND == 0) certainty_store(u, flow_out, item, both, res, &hits, hh);
+            else u.hw[row_i] = res;
+            n_why1 += f.why == 1;
+            e.item_steps = ~0ull;
+        } else {                                     // not ended: back on the list as it stands
+            e.item_steps = (item << 6) | (unsigned long long)f.it;
+            e.path = f.path;
+        }
+        todo[t] = e;
+    }
+    flow_hits(u.hits, hits);
+    flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, had ? g.points : 0u, had ? 5u : 0u, had ? g.evals : 0u, n_why1);
+}
+
 static void launch_literal_tail(const UpdateParams& u, unsigned long long* next, const FlowTodo* list, const unsigned long long* n_in, size_t n,
                                 unsigned long long want_flags, unsigned grid, hipStream_t stream)
 {
@@ -1048,8 +1141,13 @@ static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
     unsigned long long* n2 = u.flow_next + 29;
     double*             out = KIND == 0 ? u.flow_out : nullptr;
     launch_todo_pack<Entry>(l0, nullptr, n, l1, u.todo_counts, n1, stream);
+#ifdef CNF2_X_NO_FIRST
     hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
                        (unsigned long long)n, out);
+#else
+    hipLaunchKernelGGL((guided_first_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
+                       (unsigned long long)n, out);
+#endif
     launch_todo_pack<Entry>(l1, n1, n, l2, u.todo_counts, n2, stream);
     hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l2, (const unsigned long long*)n2,
                        (unsigned long long)n, out);

@@ -21,6 +21,8 @@ chroms = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 ped = synth.make_outbred3(fams, 4, snps, chroms, seed=2, missing=0.2)
 run = host.Run(ped)
+if os.environ.get("CNF2_AB_FLAGS"):
+    run.set_update_flags(int(os.environ["CNF2_AB_FLAGS"]))       # e.g. 524288 = CNF2_UPDATE_LITERAL_FINISH
 run.postmarkerdata()
 L = capi.load()
 for it in range(iters):
