@@ -496,8 +496,11 @@ struct SlopeTerms {
     double   c0;       // constant term: entropyfactor x prior (certainties)
 };
 #define CNF2_GL15_C 6.636457986458086      /* sum of w_i / (1 - z_i) over the 15 nodes */
+#ifndef CNF2_SCOUT_DEEP
+#define CNF2_SCOUT_DEEP (1.0 / 1048576.0)  /* flow_scout, hand_over: Euler step / bracket under which a flow stays with the scout */
+#endif
 #ifndef CNF2_SCOUT_KEEP
-#define CNF2_SCOUT_KEEP 0.3                /* flow_scout, hand_over: slope x step size from which a flow stays with the scout */
+#define CNF2_SCOUT_KEEP 0.6                /* flow_scout, hand_over: slope x step size from which a flow stays with the scout */
 #endif
 struct IntervalFacts {
     double s1;         // lower bound of -G' on the interval; <= 0 or NaN: none
@@ -737,7 +740,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
                         de = de < far_end ? de : far_end;
                         const double xe = f->orig + dir * de, dd = (xe - f->orig) * dir;
                         bool         regular = true;
-                        if (!(dd > far_end * (1.0 / 1048576.0))) regular = false;       // next to a root from the start: twenty steps or more to the band
+                        if (!(dd > far_end * CNF2_SCOUT_DEEP)) regular = false;               // next to a root from the start: more steps to the band than a plan looks ahead
                         else if (xe >= eps && xe <= top) {
                             const double ge = flow_pace(rgradient, xe, eps);
                             evals++;

@@ -852,31 +852,45 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_finish_kernel(Updat
 // by one block, the scatter.  What they move is 16 - 24 bytes per slot: a fraction of a millisecond per pass.
 template <class Entry>
 __device__ __forceinline__ bool todo_holds(const Entry& e) { return e.item_steps != ~0ull && !(e.item_steps & FLOW_FLAGS); }
-#define TODO_STRETCH 256ull
+#define TODO_STRETCH 256ull          /* slots a wavefront looks at (4 reads of 64) */
+#define TODO_BLOCK 4096ull           /* slots of a block of 16 wavefronts: the unit the counts are kept for (a list of 2^26 slots: 16 384 counts) */
 template <class Entry>
-__global__ __launch_bounds__(256) void todo_count_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
-                                                         unsigned long long* counts)
+__device__ __forceinline__ unsigned todo_wave_count(const Entry* todo, unsigned long long n, unsigned long long wave)
 {
-    const unsigned long long n = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int                lane = threadIdx.x & 63;
-    if (wave * TODO_STRETCH >= n_max) return;
-    unsigned c = 0;
+    const int lane = threadIdx.x & 63;
+    unsigned  c = 0;
     for (int k = 0; k < 4; k++) {
         const unsigned long long slot = wave * TODO_STRETCH + (unsigned long long)k * 64 + lane;
         bool holds = false;
         if (slot < n) holds = todo_holds(todo[slot]);
         c += __popcll(__ballot(holds));
     }
-    if (lane == 0) counts[wave] = c;
+    return c;
 }
-// exclusive scan of counts[0 .. n_waves) in place by ONE block; total[0] = their sum.  A thread sums a stretch of its own,
-// the 1 024 sums are scanned in LDS, the thread writes its stretch's running sums: three barriers whatever the length.
-__global__ __launch_bounds__(1024) void todo_scan_kernel(unsigned long long* counts, unsigned long long n_waves, unsigned long long* total)
+template <class Entry>
+__global__ __launch_bounds__(1024) void todo_count_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
+                                                          unsigned long long* counts)
+{
+    __shared__ unsigned wc[16];
+    const unsigned long long n = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
+    const unsigned           w = threadIdx.x >> 6;
+    const unsigned           c = todo_wave_count(todo, n, (unsigned long long)blockIdx.x * 16ull + w);
+    if ((threadIdx.x & 63) == 0) wc[w] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int i = 0; i < 16; i++) t += wc[i];
+        counts[blockIdx.x] = t;
+    }
+}
+// exclusive scan of counts[0 .. n_blocks) in place by ONE block; total[0] = their sum.  A thread sums a stretch of its own
+// (a handful of values: one count per 4 096 slots), the 1 024 sums are scanned in LDS, the thread writes its stretch's
+// running sums.
+__global__ __launch_bounds__(1024) void todo_scan_kernel(unsigned long long* counts, unsigned long long n_blocks, unsigned long long* total)
 {
     __shared__ unsigned long long part[1024];
-    const unsigned long long per = (n_waves + 1023ull) / 1024ull;
-    const unsigned long long lo = threadIdx.x * per, hi = lo + per < n_waves ? lo + per : n_waves;
+    const unsigned long long per = (n_blocks + 1023ull) / 1024ull;
+    const unsigned long long lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
     unsigned long long       sum = 0ull;
     for (unsigned long long i = lo; i < hi; i++) sum += counts[i];
     part[threadIdx.x] = sum;
@@ -896,14 +910,20 @@ __global__ __launch_bounds__(1024) void todo_scan_kernel(unsigned long long* cou
     if (threadIdx.x == 1023) total[0] = part[1023];
 }
 template <class Entry>
-__global__ __launch_bounds__(256) void todo_scatter_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
-                                                           const unsigned long long* offsets, Entry* dense)
+__global__ __launch_bounds__(1024) void todo_scatter_kernel(const Entry* todo, const unsigned long long* n_in, unsigned long long n_max,
+                                                            const unsigned long long* offsets, Entry* dense)
 {
+    __shared__ unsigned wc[16];
     const unsigned long long n = n_in ? (*n_in < n_max ? *n_in : n_max) : n_max;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned           w = threadIdx.x >> 6;
     const int                lane = threadIdx.x & 63;
-    if (wave * TODO_STRETCH >= n) return;
-    unsigned long long at = offsets[wave];
+    const unsigned long long wave = (unsigned long long)blockIdx.x * 16ull + w;
+    if ((unsigned long long)blockIdx.x * TODO_BLOCK >= n) return;
+    const unsigned c = todo_wave_count(todo, n, wave);
+    if (lane == 0) wc[w] = c;
+    __syncthreads();
+    unsigned long long at = offsets[blockIdx.x];
+    for (unsigned i = 0; i < w; i++) at += wc[i];
     for (int k = 0; k < 4; k++) {
         const unsigned long long slot = wave * TODO_STRETCH + (unsigned long long)k * 64 + lane;
         Entry e;
@@ -920,10 +940,10 @@ template <class Entry>
 static void launch_todo_pack(const Entry* src, const unsigned long long* n_in, size_t n_max, Entry* dst, unsigned long long* counts,
                              unsigned long long* total, hipStream_t stream)
 {
-    const size_t waves = (n_max + TODO_STRETCH - 1) / TODO_STRETCH, blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL(todo_count_kernel<Entry>, dim3((unsigned)blocks), dim3(256), 0, stream, src, n_in, (unsigned long long)n_max, counts);
-    hipLaunchKernelGGL(todo_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (unsigned long long)waves, total);
-    hipLaunchKernelGGL(todo_scatter_kernel<Entry>, dim3((unsigned)blocks), dim3(256), 0, stream, src, n_in, (unsigned long long)n_max,
+    const size_t blocks = (n_max + TODO_BLOCK - 1) / TODO_BLOCK;
+    hipLaunchKernelGGL(todo_count_kernel<Entry>, dim3((unsigned)blocks), dim3(1024), 0, stream, src, n_in, (unsigned long long)n_max, counts);
+    hipLaunchKernelGGL(todo_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (unsigned long long)blocks, total);
+    hipLaunchKernelGGL(todo_scatter_kernel<Entry>, dim3((unsigned)blocks), dim3(1024), 0, stream, src, n_in, (unsigned long long)n_max,
                        (const unsigned long long*)counts, dst);
 }
 
