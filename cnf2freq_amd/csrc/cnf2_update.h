@@ -758,9 +758,22 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
                 }
             }
         }
+        // A flow that is still here with a monotone gradient closes in on a root (or runs into its cap): look for the root at
+        // once -- one evaluation at the bracket's far end, and if the gradient has turned round there the closing in below --
+        // instead of waiting for the bisection's own midpoints to bracket it.  (hand_over, i.e. the device kernels' form: a
+        // wavefront's lanes then do their closing in together, once, and their steps are answered from what it left; found
+        // step by step every lane reaches it at another step number and the wavefront runs the loop below up to five times.)
+        if (hand_over && step == 0 && mono && !refined && !(far_d < HUGE_VAL)) {
+            const double xf = f->falling ? f->lo : f->hi, dd = (xf - f->orig) * dir;
+            if (dd > 0.0 && xf >= eps && xf <= top) {
+                const double gf = flow_pace(rgradient, xf, eps);
+                evals++;
+                note(dd, gf);
+            }
+        }
         // the root is bracketed by two solid facts: close in on it (false position, Illinois), each evaluation one more
-        if ((step == 3 || step == 6 || step == 10 || step == 15 || step == 21) && mono && !refined && far_d < HUGE_VAL &&
-            near_g != 0.0) {
+        if ((step == 3 || step == 6 || step == 10 || step == 15 || step == 21 || (hand_over && step == 0)) && mono && !refined &&
+            far_d < HUGE_VAL && near_g != 0.0) {
             refined = true;
             double dn = near_d, df = far_d, fn = near_g, ff = far_g;
             int    side = 0;

@@ -772,25 +772,50 @@ void Engine::iteration(FILE* out)
         check(cnf2_window_table(ctx, wtab.data()), "cnf2_window_table");
     }
     for (int c = 0; c < C; c++) {
-        if (!opt.quiet)
+        // multi-process runs with a spool directory: ranks > 0 write the likelihood lines and the rows of their block to
+        // files, rank 0 appends the files behind its own lines / rows in rank order -- the order of a single-process run --
+        // and removes them.  The names carry the run's tag (the parent's pid): two runs may share a --tmppath.
+        auto spool_name = [&](const char* what, int rank) {
+            return opt.spool_dir + "/cnf2_" + what + (opt.spool_tag.empty() ? "" : "_" + opt.spool_tag) + "_it" + std::to_string(iteration_no_) +
+                   "_chrom" + std::to_string(c + 1) + "_rank" + std::to_string(rank) + ".txt";
+        };
+        auto collect = [&](const char* what, FILE* to) {
+            exchange(X_BARRIER, nullptr, 0, 0, "the barrier behind the spooled text");
+            if (part_.rank != 0) return;
+            std::vector<char> buf(1 << 20);
+            for (int r = 1; r < part_.world; r++) {
+                FILE* f = fopen(spool_name(what, r).c_str(), "r");
+                if (!f) throw EngineError(CNF2_ERR_STATE, "cannot read " + spool_name(what, r));
+                size_t k;
+                while ((k = fread(buf.data(), 1, buf.size(), f)) > 0) fwrite(buf.data(), 1, k, to);
+                fclose(f);
+                remove(spool_name(what, r).c_str());
+            }
+        };
+        const bool spool_lines = multi && !opt.spool_dir.empty() && !opt.quiet;
+        if (!opt.quiet) {
+            FILE* lines_out = stdout;                // the two printf of cnF2freq.cpp:5399-5401 go to stdout
+            if (spool_lines && part_.rank > 0) {
+                lines_out = fopen(spool_name("lines", part_.rank).c_str(), "w");
+                if (!lines_out) throw EngineError(CNF2_ERR_STATE, "cannot write " + spool_name("lines", part_.rank));
+            }
             for (int j = 0; j < nb; j++) {
                 const int32_t* w = &wtab[(size_t)(b0 + j) * 17];
-                double mx = -1e15;               // the two printf of cnF2freq.cpp:5399-5401
+                double mx = -1e15;
                 for (int s = 0; s < 8; s++) mx = std::max(mx, factors[((size_t)j * C + c) * 8 + s]);
-                printf("%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[b0 + j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
-                       P.inds[T.dous[b0 + j]].gen < 2 ? 2 : 8);
+                fprintf(lines_out, "%d,%03d,%03d: %lf\t%lf %d\n", P.inds[T.dous[b0 + j]].n, w[1], w[0], mx, loglik[(size_t)j * C + c],
+                        P.inds[T.dous[b0 + j]].gen < 2 ? 2 : 8);
             }
-        // multi-process runs with a spool directory: ranks > 0 write the rows of their block to a file, rank 0 appends the
-        // files behind its own rows in rank order -- the order of a single-process run -- and removes them
+            if (spool_lines) {
+                if (part_.rank > 0) fclose(lines_out);
+                collect("lines", stdout);
+            }
+        }
         const bool spool = multi && !opt.spool_dir.empty() && opt.print_rows;
-        auto spool_name = [&](int rank) {
-            return opt.spool_dir + "/cnf2_rows_it" + std::to_string(iteration_no_) + "_chrom" + std::to_string(c + 1) + "_rank" +
-                   std::to_string(rank) + ".txt";
-        };
         FILE* rows_out = out;
         if (spool && part_.rank > 0) {
-            rows_out = fopen(spool_name(part_.rank).c_str(), "w");
-            if (!rows_out) throw EngineError(CNF2_ERR_STATE, "cannot write " + spool_name(part_.rank));
+            rows_out = fopen(spool_name("rows", part_.rank).c_str(), "w");
+            if (!rows_out) throw EngineError(CNF2_ERR_STATE, "cannot write " + spool_name("rows", part_.rank));
         }
         // cnF2freq.cpp:6183-6188: "%s:%d\n", a line "%.5lf\t%.5lf\t%.5lf\n" per marker, an empty line (the text is formed
         // by the host's threads, an individual each, and written in order: cnf2_format.h)
@@ -802,18 +827,7 @@ void Engine::iteration(FILE* out)
             });
         if (spool) {
             if (part_.rank > 0) fclose(rows_out);
-            exchange(X_BARRIER, nullptr, 0, 0, "the barrier behind the spooled rows");
-            if (part_.rank == 0) {
-                std::vector<char> buf(1 << 20);
-                for (int r = 1; r < part_.world; r++) {
-                    FILE* f = fopen(spool_name(r).c_str(), "r");
-                    if (!f) throw EngineError(CNF2_ERR_STATE, "cannot read " + spool_name(r));
-                    size_t k;
-                    while ((k = fread(buf.data(), 1, buf.size(), f)) > 0) fwrite(buf.data(), 1, k, out);
-                    fclose(f);
-                    remove(spool_name(r).c_str());
-                }
-            }
+            collect("rows", out);
         }
         fflush(out);
         lap("likelihood lines / rows");
@@ -879,6 +893,7 @@ void Engine::iteration(FILE* out)
 void Engine::dump(FILE* out, int limit)
 {
     sync_rows();
+    if (part_.world > 1 && part_.rank > 0) return;      // the gather above is the part every rank owes; the text is rank 0's
     std::vector<int> who;
     for (size_t r = 0; r < P.inds.size(); r++)
         if (P.inds[r].n <= limit) who.push_back((int)r);

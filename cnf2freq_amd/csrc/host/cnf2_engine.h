@@ -36,6 +36,7 @@ struct EngineOptions {
     // a single-process run (per chromosome the rows of every analysed individual, then the pass lines); empty: every rank
     // writes the rows of its own block to its own output
     std::string spool_dir;
+    std::string spool_tag;       // part of the spool files' names that is unique to the run (the executable: its parent's pid)
 };
 
 // A call into libcnf2hip.so failed (out of memory, launch error, bad state).  The command line turns it into the

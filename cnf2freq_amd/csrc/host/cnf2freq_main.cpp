@@ -22,6 +22,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dirent.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -122,7 +124,10 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
     eo.normalise = opt.normalise;
     eo.update = opt.update;
     eo.dump_all = opt.dump_all;
-    if (world > 1) eo.spool_dir = opt.tmppath;
+    if (world > 1) {
+        eo.spool_dir = opt.tmppath;
+        eo.spool_tag = "run" + std::to_string((long)getppid());       // every rank is a child of the process that read the files
+    }
     ShmTransport T;
     // any failure below the C ABI ends the run the way the reference ends on every failure (cnF2freq.cpp:21-25)
     try {
@@ -254,7 +259,14 @@ int main(int argc, char** argv)
     set_host_threads(std::max(1, host_threads() / opt.gpus));
     fflush(stdout);
     fflush(stderr);
-    std::vector<pid_t> kids;
+    static std::vector<pid_t> kids;             // static: the signal handler below ends them
+    const pid_t parent = getpid();
+    auto stop_ranks = [](int sig) {
+        for (pid_t k : kids) kill(k, SIGKILL);
+        _exit(128 + sig);
+    };
+    signal(SIGINT, stop_ranks);
+    signal(SIGTERM, stop_ranks);
     for (int r = 0; r < opt.gpus; r++) {
         const pid_t pid = fork();
         if (pid < 0) {
@@ -263,6 +275,12 @@ int main(int argc, char** argv)
             abort();
         }
         if (pid == 0) {
+            // a rank must not outlive the run: if the parent is killed the ranks would wait at a barrier for ever, holding
+            // their GPU memory
+            prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() != parent) _exit(5);             // the parent died between fork and prctl
+            signal(SIGINT, SIG_DFL);
+            signal(SIGTERM, SIG_DFL);
             const int rc = run_rank(opt, P, r, opt.gpus, region);
             fflush(stdout);
             fflush(stderr);
@@ -283,6 +301,17 @@ int main(int argc, char** argv)
                 if (k != pid) kill(k, SIGKILL);
         }
     }
-    if (failed) abort();                                  // the reference ends every failure this way (cnF2freq.cpp:21-25)
+    if (failed) {
+        // text the ranks had spooled for rank 0 (cnf2_<what>_run<pid>_...): nobody will collect it now
+        const std::string tag = "_run" + std::to_string((long)parent) + "_";
+        if (DIR* d = opendir(opt.tmppath.c_str())) {
+            while (dirent* e = readdir(d)) {
+                const std::string name = e->d_name;
+                if (name.rfind("cnf2_", 0) == 0 && name.find(tag) != std::string::npos) remove((opt.tmppath + "/" + name).c_str());
+            }
+            closedir(d);
+        }
+        abort();                                          // the reference ends every failure this way (cnF2freq.cpp:21-25)
+    }
     return 0;
 }

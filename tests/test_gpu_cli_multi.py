@@ -84,6 +84,39 @@ def test_two_ranks_write_the_output_of_one(tmp_path, shape):
     assert outs["one"][1].count(":1\n") == outs["two"][1].count(":1\n") == 18
 
 
+def test_two_ranks_print_every_likelihood_line(tmp_path):
+    """Without --quiet (the default) a run prints the two likelihood values of every analysed individual and chromosome
+    (cnF2freq.cpp:5399-5401) on stdout: with two ranks the lines of rank 1's block reach rank 0 like its rows do, and stdout is
+    that of the single-rank run -- same lines, same order, numbers to the printed precision."""
+    import __graft_entry__ as g
+    g.build()
+    ped = synth.make_outbred3(6, 3, 13, 2, seed=44, missing=0.15)
+    files = write_plantimpute(ped, tmp_path)
+    spool = tmp_path / "spool"
+    spool.mkdir()
+    outs = {}
+    for name, extra in (("one", []), ("two", ["--gpus", "2", "--single-device", "--tmppath", str(spool)])):
+        r = subprocess.run([EXE] + files + ["--output", str(tmp_path / (name + ".txt")), "--count", "3"] + extra, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[name] = [l.replace("\t", " ").split() for l in r.stdout.split("\n")]
+    assert os.listdir(spool) == []
+    a, b = outs["one"], outs["two"]
+    lik = lambda lines: [l for l in lines if len(l) == 4 and l[0].endswith(":") and l[0].count(",") == 2]
+    assert len(lik(a)) == 18 * 2 * 2                      # 18 analysed individuals x 2 chromosomes x the 2 iterations that sweep
+    assert [l[0] for l in lik(b)] == [l[0] for l in lik(a)]
+    assert len(a) == len(b)
+    for la, lb in zip(a, b):
+        assert len(la) == len(lb), (la, lb)
+        for x, y in zip(la, lb):
+            try:
+                fx, fy = float(x.rstrip(":")), float(y.rstrip(":"))
+            except ValueError:
+                assert x == y, (la, lb)
+                continue
+            assert abs(fx - fy) <= 2e-5 * max(1.0, abs(fx)), (la, lb)
+
+
 def test_a_failing_rank_ends_the_run(tmp_path):
     """More ranks than GPUs without --single-device: the rank that finds no device ends, the parent stops the others (which
     would wait at a barrier for ever) and the run aborts like every failure of the reference (cnF2freq.cpp:21-25)."""
