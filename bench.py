@@ -313,6 +313,17 @@ def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warm
             L.cnf2_sync(ctx)
             L.cnf2_last_kernel_ms(ctx, ms.ctypes.data_as(C.c_void_p), 4)
             sweep_ms.append(float(ms[0]))
+        # one more iteration with the update kernels' statistics on (a few atomics per wavefront; not among the timed ones):
+        # flows and gradient evaluations of an iteration, for the update pass's own roofline below
+        upd = None
+        try:
+            os.environ["CNF2_UPDATE_STATS"] = "1"
+            run.iteration()
+            s16, s8 = np.zeros(16, np.uint64), np.zeros(8, np.uint64)
+            if L.cnf2_update_stats(ctx, s16.ctypes.data_as(C.c_void_p)) == 0 and L.cnf2_update_stats_guided(ctx, s8.ctypes.data_as(C.c_void_p)) == 0:
+                upd = (s16.astype(float), s8.astype(float))
+        finally:
+            os.environ.pop("CNF2_UPDATE_STATS", None)
         st = run.state()
         run.close()
     finally:
@@ -322,6 +333,27 @@ def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warm
         os.close(saved_stdout)
     mean = lambda k: float(np.mean([l[k] for l in laps]))
     it_s = float(np.mean(wall))
+    update_roofline = None
+    if upd is not None:
+        s16, s8 = upd
+        # gradient evaluations of one iteration: the scouts' (one per evaluation), the guided kernels' (16 per literal point, the
+        # seeds' single ones counted), the step-per-round tail's (a step's midpoint + 15 per quadrature)
+        flows = s16[0] + s16[4]
+        evals = s16[1] + s16[5] + s8[2] + s8[6] + (s16[8] + 15.0 * s16[10]) + (s16[12] + 15.0 * s16[14])
+        points = s8[0] + s8[4]
+        upd_s = mean("update_s")
+        # a gradient evaluation: ~62 double-precision vector instructions (logit: two divisions by reciprocal + Newton, an
+        # 11-term series; the rational data term; one more division), of which ~45 are fused multiply-adds: ~100 flops
+        FLOPS_PER_EVAL, FP64_VECTOR_PEAK = 100.0, 78.6e12
+        update_roofline = {
+            "bound": "fp64_valu", "flows_per_iteration": flows, "certainty_flows": s16[0], "haploweight_flows": s16[4],
+            "gradient_evaluations_per_iteration": evals, "evaluations_per_flow": evals / max(flows, 1.0),
+            "literal_points_per_iteration": points, "evaluations_per_s": evals / upd_s,
+            "flops_per_evaluation": FLOPS_PER_EVAL, "achieved_tflops": evals * FLOPS_PER_EVAL / upd_s / 1e12,
+            "peak_tflops": FP64_VECTOR_PEAK / 1e12, "frac": evals * FLOPS_PER_EVAL / upd_s / FP64_VECTOR_PEAK,
+            "note": "evaluations the kernels really made (the literal bisection of the reference would make ~3x as many: "
+                    "cnf2_update.h); update_s is the wall time of the four passes' calls, launches and syncs included",
+        }
     return {"workload": "3-generation outbred pedigree, %d families = %d individuals, %d analysed, 20%% of genotypes missing, "
                         "%d chromosomes x %d SNPs (+1 dummy each): BASELINE config 5 at %d/2500 of its families"
                         % (fams, R, n, chroms, snps_per_chrom, fams),
@@ -329,6 +361,7 @@ def iteration_probe(local, device, fams=500, snps_per_chrom=2500, chroms=4, warm
             "sweep_accumulate_s": mean("sweep_accumulate_s"), "update_s": mean("update_s"), "host_s": mean("host_s"),
             "sweep_accumulate_kernel_ms": float(np.mean(acc_ms)), "plain_sweep_kernel_ms": float(min(sweep_ms)),
             "accumulate_over_sweep": float(np.mean(acc_ms)) / float(min(sweep_ms)),
+            "update_roofline": update_roofline,
             "postmarkerdata_s": t_pm, "scalefactor": st["scalefactor"], "last_hits": st["hits"],
             "probe_wall_s": time.perf_counter() - t_all}
 
@@ -827,6 +860,16 @@ def main():
                          # and reloaded at every marker); the kernel spills every second marker and rebuilds the others, so
                          # it moves about half of them (frac_physical) and `frac` can pass 1 without HBM being the limit
                          "binding": "valu_issue",
+                         # ... so, beside the contract's `frac`: the same launch against the other ceilings.  frac_flops = SURVEY
+                         # 8(d)'s algorithmic flops (2.7e4 per unit: the butterflies, the emission combine, the normalisation;
+                         # 8 modes, forward and backward) over the kernel's time over the FP64 vector peak; the physical bytes
+                         # against what HBM delivers to a streaming kernel (6.3 TB/s, MI355X_MICROARCH.md) rather than its 8 TB/s
+                         "bound_actual": "fp64_valu_issue",
+                         "hbm_ceiling_of_survey_8d_reached": bool(achieved * 1e9 / HBM_PEAK >= 0.97),
+                         "algorithmic_flops_per_unit": 2.7e4,
+                         "frac_flops": 2.7e4 * float(n) * M / (k_ms * 1e-3) / 78.6e12,
+                         "frac_physical_achievable": (traffic / (k_ms * 1e-3) / 6.3e12) if traffic else None,
+                         "valu_per_unit_source": "profiles/hbm_traffic.json: rocprofv3 --pmc of the same kernel sources (kernel_src_sha), not of this run",
                          # achieved / frac above are rank 0's launch; every rank's own launch beside it
                          "per_rank": [{"rank": r, "kernel_ms": km, "achieved": float(n) * M * B_UNIT / (km * 1e-3) / 1e9,
                                        "frac": float(n) * M * B_UNIT / (km * 1e-3) / HBM_PEAK,

@@ -1201,7 +1201,8 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
     const size_t resident = (size_t)256 * 16;                 // wavefronts the chip holds at 4 per SIMD
     // counters: [0] finish kernel's next slot, [1] flows set aside; then 24 statistics.  The scouts run in chunks of
     // todo_cap flows so that the list of flows set aside stays bounded.
-    (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
+    // the statistics add up over the passes of an iteration (chromosome 0's pass starts them afresh)
+    if (u.chrom == 0) (void)hipMemsetAsync(u.flow_next + 2, 0, 24 * sizeof(unsigned long long), stream);
     const size_t cap = u.todo_cap;
     // the certainties: every flow (u.mirror == 0), or the mirror pass over the sides (1) and then the pass of the ties (2)
     for (int pass = u.mirror ? 1 : 0; pass <= (u.mirror ? 2 : 0); pass++) {

@@ -326,7 +326,7 @@ int    cnf2_pack_accumulators(cnf2_ctx *ctx, const int32_t *recs, int n, double 
 int    cnf2_unpack_accumulators(cnf2_ctx *ctx, const int32_t *recs, int n, const double *d_packed);
 int    cnf2_pack_rows(cnf2_ctx *ctx, const int32_t *recs, int n, void *d_packed);
 int    cnf2_unpack_rows(cnf2_ctx *ctx, const int32_t *recs, int n, const void *d_packed);
-/* Diagnostics of the last cnf2_update_pass (flow kernels; see cnf2_kernels.hip).  out16[0..3] for the genotype
+/* Diagnostics of the update passes since the last pass of chromosome 0, i.e. of an iteration so far (flow kernels; see cnf2_update_kernels.hip).  out16[0..3] for the genotype
  * certainties, out16[4..7] for the haplotype weights: flows; gradient evaluations the scout spent on them; flows that ended
  * in the scout; flows pinned to their clamp (no evaluation beyond the first).  out16[8..11] / out16[12..15] for the flows the
  * scout set aside: steps taken in the finish kernel; lane slots offered (steps / slots = lane utilisation); quadratures;

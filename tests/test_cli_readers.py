@@ -8,7 +8,8 @@ import pytest
 
 from conftest import ROOT
 
-EXE = os.path.join(ROOT, "cnf2freq_amd", "cnF2freq")
+# CNF2_EXE: another build of the executable (tools/sanitize_host.sh runs these tests on one made with -fsanitize=address,undefined)
+EXE = os.environ.get("CNF2_EXE") or os.path.join(ROOT, "cnf2freq_amd", "cnF2freq")
 
 
 @pytest.fixture(scope="module")
