@@ -72,16 +72,14 @@ def launch_ranks(argv):
     n = requested_gpus(argv)
     if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
         return None
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_share() // n)))      # the ranks share this process's CPU quota
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torchrun hosts the rendezvous itself on a port IT finds free (a port probed here could be taken by another
+    # process before the child binds it: several benches started at the same moment)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + list(argv)
     trace = os.environ.get("CNF2_BENCH_PARENT_TRACE")
     if trace:
         with open(trace, "w") as f:

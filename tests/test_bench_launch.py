@@ -49,7 +49,7 @@ def test_parent_spawns_ranks_before_touching_hip(tmp_path):
         assert bad not in mods, "the parent had imported %s before the spawn" % bad
     assert t["cmd"][1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in t["cmd"]
     assert t["cmd"][t["cmd"].index("--nproc-per-node") + 1] == "2"
-    assert "--master-addr" in t["cmd"] and "127.0.0.1" in t["cmd"]
+    assert "--standalone" in t["cmd"] and "127.0.0.1" in t["cmd"]       # torchrun picks the rendezvous port itself
     # no GPU here: the ranks refuse to run (no CPU fallback), and the parent relays the failure
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr, r.stderr[-3000:]
