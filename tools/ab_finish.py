@@ -15,6 +15,6 @@ a = [int(x) for x in args] + [500, 2500, 4, 2, 3][len(args):]
 torch.cuda.set_device(0)
 for rep in range(2):
     for name, flags in (("guided", 0), ("literal_finish", capi.UPDATE_LITERAL_FINISH)):
-        r = bench.iteration_probe(0, torch.device("cuda", 0), fams=a[0], snps_per_chrom=a[1], chroms=a[2], warmup=a[3], timed=a[4], update_flags=flags)
+        r = bench.iteration_probe(0, torch.device("cuda", 0), fams=a[0], snps_per_chrom=a[1], chroms=a[2], warmup=a[3], timed=a[4], update_flags=flags, with_stats=False)
         print("%-15s iteration %.4f s  update %.4f s  sweep+acc %.4f s  scalefactor %.6f hits %s" %
               (name, r["iteration_s"], r["update_s"], r["sweep_accumulate_s"], r["scalefactor"], r["last_hits"]), flush=True)

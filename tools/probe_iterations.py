@@ -10,4 +10,4 @@ import torch  # noqa: E402
 
 a = [int(x) for x in args] + [500, 2500, 4, 2, 3][len(args):]
 torch.cuda.set_device(0)
-print(json.dumps(bench.iteration_probe(0, torch.device("cuda", 0), fams=a[0], snps_per_chrom=a[1], chroms=a[2], warmup=a[3], timed=a[4]), indent=1))
+print(json.dumps(bench.iteration_probe(0, torch.device("cuda", 0), fams=a[0], snps_per_chrom=a[1], chroms=a[2], warmup=a[3], timed=a[4], with_stats=False), indent=1))
