@@ -499,6 +499,12 @@ struct SlopeTerms {
 #ifndef CNF2_SCOUT_DEEP
 #define CNF2_SCOUT_DEEP (1.0 / 1048576.0)  /* flow_scout, hand_over: Euler step / bracket under which a flow stays with the scout */
 #endif
+#ifndef CNF2_SCOUT_NEAR_ROOT
+#define CNF2_SCOUT_NEAR_ROOT 0.02          /* flow_scout, hand_over: (root - midpoint) / root under which a set-aside flow takes the step-per-round kernels */
+#endif
+#ifndef CNF2_SCOUT_SATURATING
+#define CNF2_SCOUT_SATURATING 3.0          /* flow_scout, hand_over: slope towards the bracketed root x step size from which a set-aside flow takes the step-per-round kernels */
+#endif
 #ifndef CNF2_SCOUT_KEEP
 #define CNF2_SCOUT_KEEP 0.6                /* flow_scout, hand_over: slope x step size from which a flow stays with the scout */
 #endif
@@ -660,7 +666,8 @@ CNF2_UHD GradientRange flow_gradient_range(const SlopeTerms& s, double xa, doubl
 // the result, is the literal one; what changes is how much of it is computed.
 // flow_scout runs a begun flow until it ends (returns 0) or a step needs a quadrature (returns 2: the steps completed
 // and their decisions are in f->it and f->path; flow_replay + flow_advance take it from there; 5: likewise, and the gradient is
-// not known to be monotone on the bracket; 4: set aside at once for the guided bisection, see hand_over).
+// not known to be monotone on the bracket; 4: set aside at once for the guided bisection, see hand_over; 6: set aside for the
+// step-per-round kernels, see the end of the loop).
 // Written for wavefronts that run 64 scouts in lock step (all start at step 0): what costs instructions -- the attempt
 // to show the gradient monotone, the closing in on the root -- happens at fixed step numbers, the same for every lane,
 // and a same-sign step that the constant bound C15 / s1 does not settle ends the scout (the finish pass has the finer
@@ -854,6 +861,15 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         if (!spared) {
             f->it--;                   // this step is for the finish pass: hand the flow over as it stood before it
             *evaluations = evals;
+            // Which finish?  A flow whose root is bracketed and whose gradient falls off towards it faster than ~1 / step size
+            // reaches the band, if at all, within the last per cent before the root, where the rule's value saturates: dozens
+            // of cheap steps (a sign, a spared quadrature), the step-per-round kernels' case (6).  Else the guided bisection (2).
+            // (The rule's last node sits 0.6 % of the interval before its end: with the root -- a pole of the integrand -- within a
+            // per cent or two beyond the end, its value falls short of the integral, the estimates of the guided bisection with it.)
+            if (mono && hand_over && far_d < HUGE_VAL &&
+                ((far_d - d) < CNF2_SCOUT_NEAR_ROOT * far_d ||
+                 (near_g != 0.0 && far_d > near_d && scalefactor * fabs(near_g) > CNF2_SCOUT_SATURATING * (far_d - near_d))))
+                return 6;
             return mono ? 2 : 5;
         }
         f->spared++;

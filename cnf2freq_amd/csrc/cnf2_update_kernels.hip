@@ -476,7 +476,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(Upd
                     n_done = 1;
                 } else {
                     aside = true;
-                    e.item_steps = (item << 6) | (unsigned long long)f.it | (r == 3 ? FLOW_SCOUTING : (u.literal_finish ? FLOW_LITERAL : 0ull));
+                    e.item_steps = (item << 6) | (unsigned long long)f.it | (r == 3 ? FLOW_SCOUTING : (r == 6 || u.literal_finish ? FLOW_LITERAL : 0ull));
                     e.path = f.path;
                 }
             }
@@ -530,7 +530,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
                 out.path = 0;
                 n_done++;
             } else {
-                out.item_steps = (item << 6) | (unsigned long long)f.it | (u.literal_finish ? FLOW_LITERAL : 0ull);
+                out.item_steps = (item << 6) | (unsigned long long)f.it | (rs == 6 || u.literal_finish ? FLOW_LITERAL : 0ull);
                 out.path = f.path;
                 if (u.mirror == 2) u.flow_next[26] = 1ull;
             }
@@ -687,7 +687,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
                 n_done = 1;
             } else {
                 aside = true;
-                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (u.literal_finish ? FLOW_LITERAL : 0ull);
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (rs == 6 || u.literal_finish ? FLOW_LITERAL : 0ull);
                 e.path = f.path;
                 e.similarity = similarity;
             }
@@ -961,9 +961,11 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_rounds_kernel(Updat
                                                                            unsigned long long n_max, double* flow_out)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
-    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long n_items = *n_in < n_max ? *n_in : n_max;
-    if ((t & ~63ull) >= n_items) return;
+    // a wavefront takes 64 entries at a time (the launch has no more blocks than the chip holds several times over: the list's
+    // length is known on the device only, and a million blocks that find nothing to do cost a millisecond all the same)
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; (t & ~63ull) < n_items;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
     Entry e;
     e.item_steps = ~0ull;
     if (t < n_items) e = todo[t];
@@ -1039,6 +1041,7 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_rounds_kernel(Updat
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, n_points, n_rounds, n_evals, n_why1);
+    }
 }
 
 // The first of the lock-step kernels: no decisions between the points.  Nine flows in ten take exactly the same course --
@@ -1053,9 +1056,9 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_first_kernel(Update
                                                                           unsigned long long n_max, double* flow_out)
 {
     const StepControl        sc = {u.scalefactor, u.entropyfactor};
-    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long n_items = *n_in < n_max ? *n_in : n_max;
-    if ((t & ~63ull) >= n_items) return;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; (t & ~63ull) < n_items;
+         t += (unsigned long long)gridDim.x * blockDim.x) {          // 64 entries at a time (see guided_rounds_kernel)
     Entry e;
     e.item_steps = ~0ull;
     if (t < n_items) e = todo[t];
@@ -1132,6 +1135,7 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_first_kernel(Update
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, had ? g.points : 0u, had ? 5u : 0u, had ? g.evals : 0u, n_why1);
+    }
 }
 
 static void launch_literal_tail(const UpdateParams& u, unsigned long long* next, const FlowTodo* list, const unsigned long long* n_in, size_t n,
@@ -1154,6 +1158,7 @@ static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
     const size_t        resident = (size_t)256 * 16;
     const size_t        w = (n + 63) / 64;
     const unsigned      grid = (unsigned)(w < resident ? w : resident);
+    const unsigned      batch_grid = (unsigned)(w < resident * 8 ? w : resident * 8);      // the lock-step kernels: 64 entries per wavefront and pass
     Entry*              l0 = (Entry*)u.todo;        // the scouts' list: a slot per flow they looked at
     Entry*              l1 = (Entry*)u.todo2;       // the flows set aside for the guided bisection, packed
     Entry*              l2 = (Entry*)u.todo3;       // what the first lock-step kernel leaves, packed
@@ -1162,18 +1167,26 @@ static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
     double*             out = KIND == 0 ? u.flow_out : nullptr;
     launch_todo_pack<Entry>(l0, nullptr, n, l1, u.todo_counts, n1, stream);
 #ifdef CNF2_X_NO_FIRST
-    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
+    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
                        (unsigned long long)n, out);
 #else
-    hipLaunchKernelGGL((guided_first_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
+    hipLaunchKernelGGL((guided_first_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
                        (unsigned long long)n, out);
 #endif
+#ifdef CNF2_X_NO_ROUNDS
+    // experiment: what the first kernel leaves goes straight to the step-per-round kernels (its list, holes and all)
+    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
+    launch_literal_tail(u, u.flow_next, l1, n1, n, 0ull, grid, stream);
+    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
+    launch_literal_tail(u, u.flow_next, l0, nullptr, n, FLOW_LITERAL, grid, stream);
+    return;
+#endif
     launch_todo_pack<Entry>(l1, n1, n, l2, u.todo_counts, n2, stream);
-    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3((unsigned)w), dim3(64), 0, stream, u, l2, (const unsigned long long*)n2,
+    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l2, (const unsigned long long*)n2,
                        (unsigned long long)n, out);
     // what is left of those: flows that close in on a root next to which the rule's value stays under the band (a quadrature
     // or a sign per step, dozens of steps: the literal bisection's own pace) -- the step-per-round kernels with their time
-    // bound take them from where they stand (CNF2_X_GUIDED_TAIL: the guided persistent kernel instead, A/B) ...
+    // bound take them from where they stand (CNF2_X_GUIDED_TAIL: the guided persistent kernel instead, A/B).
     (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
 #ifdef CNF2_X_GUIDED_TAIL
     hipLaunchKernelGGL((guided_finish_kernel<KIND, Entry>), dim3(grid), dim3(64), 0, stream, u, u.flow_next, (const Entry*)l2,
@@ -1181,7 +1194,7 @@ static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
 #else
     launch_literal_tail(u, u.flow_next, l2, n2, n, 0ull, grid, stream);
 #endif
-    // ... and the flows the scouts set aside for those kernels in the first place
+    // ... and the flows the scouts set aside for those kernels in the first place (flow_scout: saturating next to their root)
     (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
     launch_literal_tail(u, u.flow_next, l0, nullptr, n, FLOW_LITERAL, grid, stream);
 }

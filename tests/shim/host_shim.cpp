@@ -701,7 +701,7 @@ void shim_flow(int kind, double y, double g, double h, double e, double c0, doub
         const int rc = cnf2::flow_scout(&f, grad, st, scalefactor, &evals);
         out[5] = evals;
         out[6] = rc;
-        if (rc == 2 || rc == 5) {
+        if (rc == 2 || rc == 5 || rc == 6) {
             const unsigned long long path = f.path;
             const int                steps = f.it, spared = f.spared;
             cnf2::FlowState g2;
