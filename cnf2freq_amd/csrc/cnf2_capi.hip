@@ -1094,12 +1094,18 @@ static size_t todo_chunk(size_t n_rec, size_t chrom_len, size_t markers_upto)
     const size_t n1 = n_rec * chrom_len * 4, n3 = n_rec * markers_upto;
     size_t       want = n1 > n3 ? n1 : n3;
     if (want < 4096) want = 4096;
-    const size_t cap = (size_t)1 << 26;        // x 72 B for the three lists: 4.8 GB
+    const size_t cap = (size_t)1 << 26;        // x 48 B for the two lists: 3.2 GB
     return want < cap ? want : cap;
 }
 
-// ... in doubles: three lists of 24-byte entries (the scouts' and the two packed ones of the guided kernels) and the packing's counts
-static size_t todo_doubles(size_t chunk) { return chunk * 9 + chunk / 256 + 8; }
+// ... in doubles: two lists of 24-byte entries (the scouts' and the packed one of the guided kernel; a third for the experiment with
+// a second lock-step kernel) and the packing's counts
+#ifdef CNF2_X_GUIDED_ROUNDS
+#define TODO_LISTS 3
+#else
+#define TODO_LISTS 2
+#endif
+static size_t todo_doubles(size_t chunk) { return chunk * 3 * TODO_LISTS + chunk / 256 + 8; }
 
 enum : uint32_t { ACC_RESERVE_ONLY = 1u << 31 };     // internal flag of cnf2_sweep_accumulate (not in the header)
 
@@ -1649,8 +1655,8 @@ static int update_pass_impl(cnf2_ctx* ctx, int chrom, const int32_t* recs, int n
         u.todo = ctx->d_todo;
         u.todo_cap = chunk;
         u.todo2 = ctx->d_todo + chunk * 3;
-        u.todo3 = ctx->d_todo + chunk * 6;
-        u.todo_counts = (unsigned long long*)(ctx->d_todo + chunk * 9);
+        u.todo3 = TODO_LISTS > 2 ? ctx->d_todo + chunk * 6 : nullptr;
+        u.todo_counts = (unsigned long long*)(ctx->d_todo + chunk * 3 * TODO_LISTS);
         u.scout_passes = (flags & CNF2_UPDATE_ONE_SCOUT) ? 1 : 2;
         u.mirror = (flags & CNF2_UPDATE_BOTH_FLOWS) ? 0 : 1;
         u.literal_finish = (flags & CNF2_UPDATE_LITERAL_FINISH) ? 1 : 0;

@@ -751,6 +751,7 @@ __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(
     flow_stats(u.stats ? u.stats + 12 : nullptr, n_steps, n_rounds, n_quads, n_why1);
 }
 
+#ifdef CNF2_X_GUIDED_PERSISTENT
 // ---- the guided finish: the flows the scouts set aside, with the literal decisions from three or four quadratures each ----
 // (cnf2_update.h, "the guided bisection").  Persistent like the finish kernels above -- a wavefront is 64 independent workers
 // over a queue of its own -- but a round is not "the next bisection step": a lane asks for the literal evaluation of ONE
@@ -844,6 +845,8 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_finish_kernel(Updat
     if (hits) atomicAdd(u.hits, hits);
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 8 : 12) : nullptr, n_points, n_rounds, n_evals, n_why1);
 }
+
+#endif  // CNF2_X_GUIDED_PERSISTENT
 
 // The scouts' list has a slot per flow they looked at, and most slots are empty (a certainty flow exists only where a
 // record has evidence at the marker: a quarter of the slots of a pass; the flows that ended in the scout are gone too).
@@ -947,6 +950,7 @@ static void launch_todo_pack(const Entry* src, const unsigned long long* n_in, s
                        (const unsigned long long*)counts, dst);
 }
 
+#ifdef CNF2_X_GUIDED_ROUNDS
 // The first rounds of the guided bisection in lock step: one thread per slot of the scout's list.  A flow that was set aside
 // lives 3 - 5 rounds in the guided form, so in the persistent kernel above a wavefront takes flows up nearly every round --
 // set-up code (loads, the prior's logarithms, the gradient at the start, the replay, the slope bound) that runs for the 16
@@ -1044,13 +1048,15 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_rounds_kernel(Updat
     }
 }
 
+#endif  // CNF2_X_GUIDED_ROUNDS
+
 // The first of the lock-step kernels: no decisions between the points.  Nine flows in ten take exactly the same course --
 // estimate, plan, the plan's three points, the bisection's steps from the facts they leave -- so the course is laid out
 // as straight-line code: the set-up, the estimate (the certainties': one literal evaluation where an Euler step lands and
 // Newton on its value; the weights': a 5-point rule, their integrands being the smoother ones), ONE plan, its points one
-// after the other, the steps.  What the adaptive kernel above spends between its points -- the steps' loop and the plan's,
+// after the other, the steps.  What an adaptive form (guided_rounds_kernel, an experiment now) spends between its points -- the steps' loop and the plan's,
 // each as long as the wavefront's longest lane, every round -- is spent once.  A flow whose gradient is not known to be
-// monotone, or that is still going after its steps, goes on the list for the adaptive kernel as it stands.
+// monotone, or that is still going after its steps, stays on the list as it stands for the step-per-round kernels.
 template <int KIND, class Entry>
 __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_first_kernel(UpdateParams u, Entry* todo, const unsigned long long* n_in,
                                                                           unsigned long long n_max, double* flow_out)
@@ -1148,53 +1154,40 @@ static void launch_literal_tail(const UpdateParams& u, unsigned long long* next,
 {
     hipLaunchKernelGGL(haploweight_finish_kernel, dim3(grid), dim3(64), 0, stream, u, next, list, (unsigned long long)n, n_in, want_flags);
 }
-// The flows the scouts set aside among the n slots of u.todo, the guided way: pack them, GUIDED_ROUNDS points in lock step,
-// pack what is left, the same again, and the persistent kernel for the few that are still going (flows that close in on a
-// root next to which the rule's value stays under the band take dozens of points, like the literal bisection).
-// u.flow_next[28], [29]: the packed lists' lengths (device side: nothing here waits for the host).
+// The flows the scouts set aside among the n slots of u.todo, the guided way: pack them, the straight-line kernel, and the
+// step-per-round kernels for what it leaves.  u.flow_next[28]: the packed list's length (device side: nothing here waits for
+// the host).
 template <int KIND, class Entry>
 static void launch_guided(const UpdateParams& u, size_t n, hipStream_t stream)
 {
     const size_t        resident = (size_t)256 * 16;
     const size_t        w = (n + 63) / 64;
     const unsigned      grid = (unsigned)(w < resident ? w : resident);
-    const unsigned      batch_grid = (unsigned)(w < resident * 8 ? w : resident * 8);      // the lock-step kernels: 64 entries per wavefront and pass
+    const unsigned      batch_grid = (unsigned)(w < resident * 8 ? w : resident * 8);      // the lock-step kernel: 64 entries per wavefront and pass
     Entry*              l0 = (Entry*)u.todo;        // the scouts' list: a slot per flow they looked at
     Entry*              l1 = (Entry*)u.todo2;       // the flows set aside for the guided bisection, packed
-    Entry*              l2 = (Entry*)u.todo3;       // what the first lock-step kernel leaves, packed
     unsigned long long* n1 = u.flow_next + 28;
-    unsigned long long* n2 = u.flow_next + 29;
     double*             out = KIND == 0 ? u.flow_out : nullptr;
     launch_todo_pack<Entry>(l0, nullptr, n, l1, u.todo_counts, n1, stream);
-#ifdef CNF2_X_NO_FIRST
-    hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
-                       (unsigned long long)n, out);
-#else
     hipLaunchKernelGGL((guided_first_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l1, (const unsigned long long*)n1,
                        (unsigned long long)n, out);
-#endif
-#ifdef CNF2_X_NO_ROUNDS
-    // experiment: what the first kernel leaves goes straight to the step-per-round kernels (its list, holes and all)
-    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
-    launch_literal_tail(u, u.flow_next, l1, n1, n, 0ull, grid, stream);
-    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
-    launch_literal_tail(u, u.flow_next, l0, nullptr, n, FLOW_LITERAL, grid, stream);
-    return;
-#endif
+    const Entry*              left = l1;            // what the first kernel leaves: its list, holes and all
+    const unsigned long long* n_left = n1;
+#ifdef CNF2_X_GUIDED_ROUNDS
+    // experiment (profiles/r05_t_*): pack what is left and give it four adaptive rounds in lock step before the tail
+    Entry*              l2 = (Entry*)u.todo3;
+    unsigned long long* n2 = u.flow_next + 29;
     launch_todo_pack<Entry>(l1, n1, n, l2, u.todo_counts, n2, stream);
     hipLaunchKernelGGL((guided_rounds_kernel<KIND, Entry>), dim3(batch_grid), dim3(64), 0, stream, u, l2, (const unsigned long long*)n2,
                        (unsigned long long)n, out);
-    // what is left of those: flows that close in on a root next to which the rule's value stays under the band (a quadrature
-    // or a sign per step, dozens of steps: the literal bisection's own pace) -- the step-per-round kernels with their time
-    // bound take them from where they stand (CNF2_X_GUIDED_TAIL: the guided persistent kernel instead, A/B).
-    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
-#ifdef CNF2_X_GUIDED_TAIL
-    hipLaunchKernelGGL((guided_finish_kernel<KIND, Entry>), dim3(grid), dim3(64), 0, stream, u, u.flow_next, (const Entry*)l2,
-                       (const unsigned long long*)n2, (unsigned long long)n, out);
-#else
-    launch_literal_tail(u, u.flow_next, l2, n2, n, 0ull, grid, stream);
+    left = l2;
+    n_left = n2;
 #endif
-    // ... and the flows the scouts set aside for those kernels in the first place (flow_scout: saturating next to their root)
+    // What is left -- one flow in ten early in a run: a plan that did not come true, a gradient not known to be monotone -- and
+    // the flows the scouts set aside for them in the first place (flow_scout: next to their root, where the rule's value
+    // saturates) go to the step-per-round kernels with their time bound, from where they stand.
+    (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
+    launch_literal_tail(u, u.flow_next, left, n_left, n, 0ull, grid, stream);
     (void)hipMemsetAsync(u.flow_next, 0, sizeof(unsigned long long), stream);
     launch_literal_tail(u, u.flow_next, l0, nullptr, n, FLOW_LITERAL, grid, stream);
 }
