@@ -24,6 +24,7 @@ UPDATE_ONE_SCOUT = 1 << 17        # the certainties' scout in one pass (A/B)
 UPDATE_LITERAL_FINISH = 1 << 19   # the set-aside flows one literal bisection step per round instead of the guided bisection (A/B)
 DETERMINISTIC = 16384
 TURN_VALU = 32768
+FLUSH_TINY = 1 << 20              # cnf2_sweep: general kernel with adjustprobs' 1e-300 rule (the reference's behaviour to the letter)
 STATIC_JOBS = 1 << 18             # wave w sweeps jobs w, w + waves, ... instead of taking jobs from the launch's counter (A/B)
 MINFACTOR = float(np.float32(-1e15))
 IGNORED = -1e30
@@ -250,7 +251,7 @@ class Context:
 
     # -- the sweep -------------------------------------------------------------
     def sweep(self, ind_begin=0, ind_end=None, dosage=True, raw=False, ties=True, full_spill=False,
-              merge_modes=False, xpose=False, log_paths=False, ties_general=False, static_jobs=False):
+              merge_modes=False, xpose=False, log_paths=False, ties_general=False, static_jobs=False, flush_tiny=False):
         ind_end = self.n_ind if ind_end is None else ind_end
         n = ind_end - ind_begin
         factors = np.zeros((n, self.n_chrom, 8))
@@ -258,7 +259,8 @@ class Context:
         dos = np.zeros((n, self.n_markers, 3)) if dosage else None
         flags = ((0 if dosage else NO_DOSAGE) | (RAW_DOSAGE if raw else 0) | (0 if ties else NO_TIES)
                  | (FULL_SPILL if full_spill else 0) | (MERGE_MODES if merge_modes else 0) | (XPOSE if xpose else 0)
-                 | (LOG_PATHS if log_paths else 0) | (TIES_GENERAL if ties_general else 0) | (STATIC_JOBS if static_jobs else 0))
+                 | (LOG_PATHS if log_paths else 0) | (TIES_GENERAL if ties_general else 0) | (STATIC_JOBS if static_jobs else 0)
+                 | (FLUSH_TINY if flush_tiny else 0))
         self._chk(self.L.cnf2_sweep(self.h, ind_begin, ind_end, _p(factors), _p(loglik),
                                     _p(dos) if dosage else None, flags), "cnf2_sweep")
         out = dict(factors=factors, loglik=loglik, dosage=dos)

@@ -616,7 +616,7 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
     // CNF2_MERGE_MODES: windows whose two parents are homozygous with equal sure everywhere go four to a
     // wavefront (fb_packed_kernel); groups are formed per chromosome, what does not fill a group of four
     // stays with the ordinary kernel
-    const bool merge = (flags & CNF2_MERGE_MODES) && !(flags & CNF2_FULL_SPILL);
+    const bool merge = (flags & CNF2_MERGE_MODES) && !(flags & (CNF2_FULL_SPILL | CNF2_FLUSH_TINY));
     auto mergeable = [&](const Window& w) {
         if (w.n_groups > 0 && !(flags & CNF2_NO_TIES)) return false;
         if (w.shiftignore != 0 || w.shiftend != 8 || (w.flags[0] & SLOT_FOUNDER)) return false;
@@ -663,7 +663,8 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         for (int c : chrom_order(ctx))
             for (int j = 0; j < n; j++) {
                 if (merge && packed[j]) continue;
-                const bool tied = ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES);
+                // (CNF2_FLUSH_TINY: every window takes the general kernel's route, the second list)
+                const bool tied = (ctx->windows[ind_begin + j].n_groups > 0 && !(flags & CNF2_NO_TIES)) || (flags & CNF2_FLUSH_TINY);
                 if (tied != (pass == 1)) continue;
                 Job jb;
                 jb.ind   = j;
@@ -780,7 +781,8 @@ int cnf2_sweep(cnf2_ctx* ctx, int ind_begin, int ind_end, double* factors_out, d
         pt.spill  = ctx->d_spill + (size_t)((n_fast > 0 || n_packed > 0) ? grid_fast : 0) * CNF2_WAVES_PER_BLOCK * stride;
         // the tile-producer kernel with a pass per tie combination; the general kernel (one lane per table entry, per-marker
         // producer) with the full spill and where asked for
-        if ((flags & CNF2_FULL_SPILL) || (flags & CNF2_TIES_GENERAL)) launch_fb(pt, grid_gen, false, ctx->stream2);
+        if (flags & CNF2_FLUSH_TINY) pt.flags |= KP_FLUSH_TINY;
+        if ((flags & CNF2_FULL_SPILL) || (flags & (CNF2_TIES_GENERAL | CNF2_FLUSH_TINY))) launch_fb(pt, grid_gen, false, ctx->stream2);
         else launch_fb_fast_tied(pt, grid_gen, ctx->stream2);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream2));

@@ -18,7 +18,8 @@ namespace cnf2 {
 enum { KP_NO_DOSAGE = 1, KP_RAW_DOSAGE = 2, KP_NO_TIES = 4,
        KP_ACC_TABLE = 8,    // accumulate: the table-form kernel does every window
        KP_ACC_ATTOP = 16,
-       KP_ACC_LANES = 32 }; // accumulate: path form with one lane per path (acc_paths_kernel) instead of the tile form // accumulate: the batch holds windows whose root is the top of its lines (table form)
+       KP_ACC_LANES = 32,
+       KP_FLUSH_TINY = 64 };  // general sweep kernel: a state under 1e-300 of its vector is set to 0 before the emission (cnF2freq.cpp:1607-1611) // accumulate: path form with one lane per path (acc_paths_kernel) instead of the tile form // accumulate: the batch holds windows whose root is the top of its lines (table form)
 
 // One unit of sequential work: an analysed individual on one chromosome
 // (the body of the loops at cnF2freq.cpp:5283 and 5294).

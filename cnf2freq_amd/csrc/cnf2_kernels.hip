@@ -462,6 +462,12 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
                     p.dbg_fwbw[(((size_t)s * len + (m - first)) * 3 + 0) * 64 + j * 8 + c.lo] = a[j];
                 if (c.lo == 0) p.dbg_factors[((size_t)s * len + (m - first)) * 3 + 0] = dbg_factor;
             }
+            // "We will multiply this already small number with an even smaller number... let's assume it's zero" (adjustprobs,
+            // cnF2freq.cpp:1607-1611): the vector is normalised here as it is there, so the threshold is the reference's
+            if (p.flags & KP_FLUSH_TINY) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] = a[j] < 1e-300 ? 0.0 : a[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) a[j] *= e[j];
             bool   was_dead = dead;
@@ -614,6 +620,10 @@ __global__ __launch_bounds__(CNF2_BLOCK) void fb_kernel(KernelParams p)
 
             // beta_{m-1} = T (e_m . beta_m), rescaled (cnF2freq.cpp:2238 with d = -1, then 2273-2367)
             if (m > first) {
+                if (p.flags & KP_FLUSH_TINY) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) b[j] = b[j] < 1e-300 ? 0.0 : b[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) b[j] *= e[j];
                 double sum = scale_chain(b, &bmant, &bexpo, &bdead);

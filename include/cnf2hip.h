@@ -88,6 +88,14 @@ enum {
                                     step (midpoint, bound, quadrature) per round, as in rounds 3 / 4, instead of the guided
                                     bisection (cnf2_update.h: the same decisions from 3 - 4 quadratures per flow).  Same
                                     results to the bit; A/B switch and cross-check */
+    CNF2_FLUSH_TINY   = 1u << 20, /* cnf2_sweep: every window through the general kernel (one lane per table entry, vectors
+                                    normalised at every marker as the reference normalises them) WITH adjustprobs' rule that a
+                                    state under 1e-300 of its vector is set to exactly 0 before the emission is applied
+                                    (cnF2freq.cpp:1607-1611).  The fast kernels carry such states (no
+                                    effect on valid data above 1e-6 -- except where every OTHER state then becomes exactly
+                                    impossible, a locked phase contradicting certain genotypes: the reference declares the
+                                    shift mode impossible, the fast kernels return the likelihood of the 1e-303 state).
+                                    This flag is the reference's behaviour to the letter, at the general kernel's speed */
     CNF2_DETERMINISTIC = 1u << 14, /* cnf2_sweep_accumulate: every analysed individual writes what its window members receive at a
                                     locus into a row of its own (336 B per individual x marker, allocated for the whole
                                     range) and one more kernel adds the rows of every record in ascending order of the

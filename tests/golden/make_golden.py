@@ -327,8 +327,45 @@ def generate_update_units(seed=20261004):
     print("update units ->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def make_flush_impossible():
+    """Adversarial but valid data on which adjustprobs' 1e-300 rule (cnF2freq.cpp:1607-1611) decides a result: 152 markers at ONE
+    map position at which a nearly phase-locked heterozygous parent makes half of a child's states lose ~1e-2 per marker (they
+    end below 1e-300 of their vector and the reference sets them to exactly 0), then one more marker at the same position at
+    which every genotype is certain and the parent's phase is locked the OTHER way round: the states that survived are now
+    exactly impossible, the states that would fit are the ones the rule removed -- the reference declares the shift modes that
+    lock onto that strand impossible (MINFACTOR)."""
+    ped = synth.make_outbred3(1, 2, 190, 1, seed=9, missing=0.0, chrom_cm=30.0)
+    ped.allele, ped.sure, ped.hw, ped.pos = ped.allele.copy(), ped.sure.copy(), ped.hw.copy(), ped.pos.copy()
+    kid = int(ped.dous[0])
+    p0, p1 = int(ped.par[kid, 0]), int(ped.par[kid, 1])
+    lo, hi = 10, 162
+    ped.pos[lo:hi + 1] = ped.pos[lo]
+    for r, al in ((kid, (1, 1)), (p0, (1, 2)), (p1, (1, 1))):
+        ped.allele[ped.row_of[r], lo:hi] = al
+        ped.sure[ped.row_of[r], lo:hi] = 1e-3
+        ped.allele[ped.row_of[r], hi] = al
+        ped.sure[ped.row_of[r], hi] = 0.0
+    ped.hw[ped.row_of[p0], lo:hi] = 0.999
+    ped.hw[ped.row_of[p0], hi] = 0.0
+    return ped
+
+
+def generate_flush_impossible():
+    """G15: the reference's own likelihoods (oracle/_ref, HOT LOOP 1) on make_flush_impossible()."""
+    ped = make_flush_impossible()
+    R = RefPed(ped, ieee=True)
+    factors, _ = R.sweep_batch(ped.dous, threads=1)
+    out = {"in_" + k: v for k, v in ped_inputs(ped).items()}
+    out["factors"] = factors
+    path = os.path.join(os.path.dirname(__file__), "flush_impossible.npz")
+    np.savez_compressed(path, **out)
+    print("flush case ->", path, "%.1f KB" % (os.path.getsize(path) / 1024), "impossible modes:", int((factors < -1e14).sum()))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["fixtures", "traj", "units"]
+    what = sys.argv[1:] or ["fixtures", "traj", "units", "flush"]
+    if "flush" in what:
+        generate_flush_impossible()
     if "fixtures" in what:
         for name in CASES:
             generate(name)

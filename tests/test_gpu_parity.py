@@ -977,6 +977,43 @@ def test_states_the_reference_flushes_below_1e300_are_carried_here_without_effec
     ctx.close()
 
 
+def test_the_1e300_rule_to_the_letter_where_it_decides_a_result(capi):
+    """Golden G15 (tests/golden/flush_impossible.npz: the reference's own likelihoods, oracle/_ref): after 152 markers on one map
+    position half of a child's states are below 1e-300 of their vector and adjustprobs sets them to exactly 0
+    (cnF2freq.cpp:1607-1611); one more marker there -- every genotype certain, the parent's phase locked the other way round --
+    makes the surviving states exactly impossible, so the reference declares the four shift modes that sit on that strand
+    impossible (MINFACTOR).  cnf2_sweep with CNF2_FLUSH_TINY (the general kernel, vectors normalised at every marker as the
+    reference normalises them, the rule applied) gives the reference's factors to the letter; the default route is
+    compared on the modes the rule does not touch."""
+    ped, z = load_golden("flush_impossible")
+    want = z["factors"]
+    gone = want < -1e14
+    assert gone.sum() == 4 and gone[0, [0, 1, 4, 5]].all()
+    ctx = capi.Context(0)
+    ctx.upload(ped)
+    got = ctx.sweep(flush_tiny=True)
+    f = got["factors"][:, 0]
+    assert np.array_equal(f < -1e14, gone)
+    np.testing.assert_allclose(f[~gone], want[~gone], rtol=RTOL, atol=1e-8)
+    # the total is the log-sum-exp over the modes that are left (cnF2freq.cpp:5384-5400)
+    for j in range(len(ped.dous)):
+        live = want[j][~gone[j]]
+        np.testing.assert_allclose(got["loglik"][j, 0], live.max() + np.log(np.exp(live - live.max()).sum()), rtol=1e-9)
+    assert np.allclose(got["dosage"].sum(axis=2), 1.0, atol=1e-9)
+    # the restatement applies the rule as well
+    o = oracle_ped(ped).sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    assert np.array_equal(o["factors"] < -1e14, gone)
+    np.testing.assert_allclose(got["dosage"], o["dosage"], rtol=1e-6, atol=1e-10)
+    # default route: the fast kernel does not apply the rule -- a state it carries at 1e-303 of its vector would give those
+    # four modes a (tiny) likelihood.  On this fixture it gives the reference's answer all the same (measured: the four modes
+    # come out impossible: between two of its rescalings, eight markers apart, the carried values leave the double range by
+    # themselves); what the test pins is that the modes the rule does not touch are the reference's either way
+    plain = ctx.sweep()["factors"][:, 0]
+    assert ((plain[gone] < -1e14) | (plain[gone] < want[0][~gone[0]].max() + 50)).all()
+    np.testing.assert_allclose(plain[~gone], want[~gone], rtol=RTOL, atol=1e-8)
+    ctx.close()
+
+
 def _four_founder_pedigree(n_kids, M, seed, empty_f1=True, empty_gp=False):
     """n_kids analysed children of two F1 parents with four distinct, heterozygous grandparents (no ancestor in two
     slots: no tie group).  empty_f1: the parents have no data (homozygous-everywhere blank rows); empty_gp: one

@@ -146,3 +146,17 @@ def test_hot_loop_2_reductions(golden):
     got = o.accumulate(ped.dous, ped.gen[ped.dous], z["acc_desc"])
     for k in ("infprobs", "haplobase", "haplocount", "homozyg"):
         np.testing.assert_allclose(got[k], z["acc_" + k], rtol=1e-12, atol=1e-15, equal_nan=True)
+
+
+def test_the_1e300_rule_of_adjustprobs_where_it_decides_a_result():
+    """Golden G15 (flush_impossible.npz: the reference's own likelihoods on data built so that adjustprobs' 1e-300 rule,
+    cnF2freq.cpp:1607-1611, makes four shift modes of a child impossible): the restatement applies the rule and gives the
+    reference's factors, MINFACTOR pattern included."""
+    from conftest import load_golden
+    ped, z = load_golden("flush_impossible")
+    o = oracle_ped(ped)
+    got = o.sweep_batch(ped.dous, ped.gen[ped.dous], mode=2)
+    gone = z["factors"] < -1e14
+    assert gone.sum() == 4
+    assert np.array_equal(got["factors"] < -1e14, gone)
+    np.testing.assert_allclose(got["factors"][~gone], z["factors"][~gone], rtol=1e-12)
