@@ -806,6 +806,30 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
                     side = -1;
                 }
             }
+            // False position closes in on the root from ONE side as a rule: the other fact stays where it was, and every
+            // midpoint between the two still costs the bisection an evaluation.  Bring both facts to within a few noise
+            // widths of the root: steps of 4, 16, 64, ... times noise / slope away from the estimate, on either side, until
+            // the gradient there is solid (each evaluation a fact like any other; hand_over, i.e. the device kernels' form).
+            if (hand_over && far_d < HUGE_VAL && far_d > near_d) {
+                const double slope = fabs(far_g - near_g) / (far_d - near_d);
+                const double dr = fabs(far_g - near_g) > 0.0 ? near_d + (far_d - near_d) * fabs(near_g) / fabs(far_g - near_g) : 0.5 * (near_d + far_d);
+                double       step0 = slope > 0.0 ? 4.0 * B.noise / slope : 0.0;
+                if (!(step0 > 0.0) || !isfinite(step0)) step0 = 1e-3 * (far_d - near_d);
+                for (int sgn = 1; sgn >= -1; sgn -= 2) {
+                    double st = step0;
+                    for (int k = 0; k < 6; k++, st *= 4.0) {
+                        const double dp = dr + sgn * st;
+                        if (!(dp > near_d && dp < far_d)) break;              // the fact on this side is that close already
+                        const double xp = f->orig + dir * dp, dd = (xp - f->orig) * dir;
+                        if (!(xp >= eps && xp <= top) || !(dd > near_d && dd < far_d)) break;
+                        const double gp = flow_pace(rgradient, xp, eps);
+                        evals++;
+                        const double before = sgn > 0 ? far_d : near_d;
+                        note(dd, gp);
+                        if ((sgn > 0 ? far_d : near_d) != before) break;        // solid: this side is done
+                    }
+                }
+            }
         }
         f->it++;
         const double mid = (f->lo + f->hi) / 2;
