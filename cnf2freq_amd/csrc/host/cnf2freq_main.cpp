@@ -34,6 +34,7 @@
 
 #include "cnf2_engine.h"
 #include "cnf2_readers.h"
+#include "cnf2_rccl_transport.h"
 #include "cnf2_shm_transport.h"
 #include "cnf2hip.h"
 
@@ -55,6 +56,9 @@ struct Options {
     bool        parse_only = false;   // print the parsed tables and stop (no GPU needed; used by tests)
     int         gpus = 1;             // --gpus N: N ranks, one GPU each
     bool        single_device = false;   // --single-device: every rank on GPU 0 (rehearsal of --gpus N on a one-GPU box)
+    std::string transport;               // --transport rccl|shm: what the ranks exchange through (default: rccl when every rank has
+                                         // a GPU of its own, shm -- staging through a shared region on the host -- with --single-device)
+    bool        rccl_selftest = false;   // --rccl-selftest: the RCCL transport's collectives with a world of one on GPU 0, then stop
 };
 
 static bool parse(int argc, char** argv, Options& o)
@@ -95,6 +99,8 @@ static bool parse(int argc, char** argv, Options& o)
         else if (a == "--parse-only") o.parse_only = true;
         else if (a == "--gpus") o.gpus = atoi(val().c_str());
         else if (a == "--single-device") o.single_device = true;
+        else if (a == "--transport") o.transport = val();
+        else if (a == "--rccl-selftest") o.rccl_selftest = true;
         else {
             fprintf(stderr, "unsupported option %s (this build covers the PlantImpute path only)\n", a.c_str());
             return false;
@@ -128,7 +134,9 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
         eo.spool_dir = opt.tmppath;
         eo.spool_tag = "run" + std::to_string((long)getppid());       // every rank is a child of the process that read the files
     }
-    ShmTransport T;
+    ShmTransport  T;
+    RcclTransport TR;
+    const bool    use_rccl = world > 1 && (opt.transport.empty() ? !opt.single_device : opt.transport == "rccl");
     // any failure below the C ABI ends the run the way the reference ends on every failure (cnF2freq.cpp:21-25)
     try {
     Engine E(P, ctx, eo);
@@ -137,7 +145,11 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
         T.R = region;
         T.ctx = ctx;
         T.rank = rank;
-        E.set_partition(rank, world, ShmTransport::call, &T);
+        if (use_rccl) {
+            if (TR.init(region, ctx, rank, world) != 0) return 4;
+            E.set_partition(rank, world, RcclTransport::call, &TR);
+        } else
+            E.set_partition(rank, world, ShmTransport::call, &T);
         E.set_root_threads(host_threads() * world);          // rank 0 infers the genotypes for all while the others wait
     }
     if (opt.preprocess) E.postmarkerdata(opt.limit);                 // cnF2freq.cpp:8083-8085
@@ -147,6 +159,7 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
     }
     if (world > 1) {
         const Partition& Q = E.partition();
+        if (rank == 0) fprintf(stderr, "transport: %s\n", use_rccl ? "RCCL in place on the exchange buffer" : "shared memory on the host");
         if (rank == 0) {
             size_t xb[4];
             E.exchange_bytes(xb);
@@ -189,10 +202,47 @@ static int run_rank(const Options& opt, Pedigree& P, int rank, int world, ShmReg
     return 0;
 }
 
+// --rccl-selftest: the RCCL transport with a world of one on GPU 0 -- the communicator's set-up through the shared region, then
+// reduce-scatter, all-gather, the hit-counter sum, a barrier and the host broadcast on the context's exchange buffer, through
+// the same entry the engine calls.  (Two ranks need two GPUs: RCCL refuses two ranks on one device.)
+static int rccl_selftest()
+{
+    ShmRegion* R = shm_region_create(1, (size_t)1 << 20);
+    cnf2_ctx*  ctx = nullptr;
+    if (!R || cnf2_ctx_create(0, &ctx) != CNF2_OK) {
+        fprintf(stderr, "rccl selftest: no region / no device: %s\n", cnf2_last_error(nullptr));
+        return 3;
+    }
+    RcclTransport T;
+    if (T.init(R, ctx, 0, 1) != 0) return 4;
+    const size_t n = 100000;
+    void*        buf = nullptr;
+    if (cnf2_exchange_buffer(ctx, n * sizeof(double), &buf) != CNF2_OK) return 5;
+    std::vector<double> v(n), w(n, 0.0);
+    for (size_t i = 0; i < n; i++) v[i] = 0.5 + (double)i * 1e-3;
+    int bad = 0;
+    bad |= cnf2_exchange_write(ctx, 0, v.data(), n * sizeof(double)) != CNF2_OK;
+    bad |= RcclTransport::call(&T, X_SUM_SEGMENTS, buf, n, n) != 0;              // one segment: the sum of one rank's values
+    bad |= RcclTransport::call(&T, X_GATHER_SEGMENTS, buf, n * sizeof(double), n * sizeof(double)) != 0;
+    bad |= cnf2_exchange_read(ctx, 0, w.data(), n * sizeof(double)) != CNF2_OK;
+    for (size_t i = 0; i < n; i++) bad |= w[i] != v[i];
+    int32_t h[2] = {7, 11};
+    bad |= RcclTransport::call(&T, X_SUM_HITS, h, 2, 2) != 0 || h[0] != 7 || h[1] != 11;
+    bad |= RcclTransport::call(&T, X_BARRIER, nullptr, 0, 0) != 0;
+    unsigned char hb[300];
+    for (int i = 0; i < 300; i++) hb[i] = (unsigned char)(i * 7);
+    bad |= RcclTransport::call(&T, X_BCAST_HOST, hb, 300, 0) != 0 || hb[299] != (unsigned char)(299 * 7);
+    T.finish();
+    cnf2_ctx_destroy(ctx);
+    printf("rccl selftest: %s (world 1, %zu doubles through ncclReduceScatter and ncclAllGather in place)\n", bad ? "FAILED" : "ok", n);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv)
 {
     Options opt;
     if (!parse(argc, argv, opt)) return 2;
+    if (opt.rccl_selftest) return rccl_selftest();
     Pedigree P;
     if (!opt.mapfile.empty()) {
         FILE* f = fopen(opt.mapfile.c_str(), "rt");
@@ -240,6 +290,10 @@ int main(int argc, char** argv)
         return 0;
     }
 
+    if (opt.transport != "" && opt.transport != "rccl" && opt.transport != "shm") {
+        fprintf(stderr, "--transport must be rccl or shm\n");
+        return 2;
+    }
     if (opt.gpus < 1 || opt.gpus > 64) {
         fprintf(stderr, "--gpus must be between 1 and 64\n");
         return 2;

@@ -129,3 +129,14 @@ def test_a_failing_rank_ends_the_run(tmp_path):
                         str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "a rank ended abnormally" in r.stderr and "needs N GPUs" in r.stderr
+
+
+def test_rccl_transport_of_the_executable_with_a_world_of_one():
+    """`cnF2freq --gpus N` exchanges through RCCL, in place on the context's exchange buffer, when every rank has a GPU of its own
+    (csrc/host/cnf2_rccl_transport.h; the reference's reduce per individual, cnF2freq.cpp:6245-6254).  A one-GPU box can run
+    its collectives with a world of one: the communicator's set-up through the shared region, ncclReduceScatter and ncclAllGather
+    on the device buffer through the entry the engine calls, the host-side operations behind them."""
+    import __graft_entry__ as g
+    g.build()
+    r = subprocess.run([EXE, "--rccl-selftest"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl selftest: ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

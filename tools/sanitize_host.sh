@@ -23,8 +23,10 @@ for san in address,undefined thread; do
     echo "exit code $?"
 done
 echo "-- cnF2freq --parse-only with -fsanitize=address,undefined through tests/test_cli_readers.py"
-g++ -O1 -g -std=c++17 -fopenmp -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all -I$R/include -o $T/cnF2freq_asan \
-    $C/host/cnf2freq_main.cpp $C/host/cnf2_readers.cpp $C/host/cnf2_engine.cpp -L$R/cnf2freq_amd -lcnf2hip -lpthread -Wl,-rpath,$R/cnf2freq_amd \
+ROCM=${ROCM:-/opt/rocm}
+g++ -O1 -g -std=c++17 -fopenmp -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all -D__HIP_PLATFORM_AMD__ -I$R/include -I$ROCM/include \
+    -o $T/cnF2freq_asan $C/host/cnf2freq_main.cpp $C/host/cnf2_readers.cpp $C/host/cnf2_engine.cpp -L$R/cnf2freq_amd -lcnf2hip -L$ROCM/lib -lrccl -lamdhip64 \
+    -lpthread -Wl,-rpath,$R/cnf2freq_amd -Wl,-rpath,$ROCM/lib \
     && (cd $R && ASAN_OPTIONS=detect_leaks=0 CNF2_EXE=$T/cnF2freq_asan python -m pytest tests/test_cli_readers.py -x -q 2>&1 | tail -3)
 } 2>&1 | tee $LOG
 if grep -q "ERROR: \|runtime error\|WARNING: ThreadSanitizer\|FAILED\|BUILD FAILED" $LOG; then echo "sanitize_host.sh: REPORTS FOUND"; exit 1; fi
