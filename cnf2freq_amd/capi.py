@@ -35,7 +35,7 @@ SYMBOLS = [
     "cnf2_upload_map", "cnf2_upload_rows", "cnf2_update_rows", "cnf2_update_rows_device",
     "cnf2_upload_pedigree",
     "cnf2_window_info", "cnf2_sweep", "cnf2_sync", "cnf2_fwbw_store", "cnf2_locked_query",
-    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances",
+    "cnf2_turn_scan", "cnf2_turn_scan_rows", "cnf2_state_posterior", "cnf2_haplos", "cnf2_infprobs", "cnf2_infprobs_rows", "cnf2_descendants", "cnf2_accumulate", "cnf2_sweep_accumulate", "cnf2_sweep_turn_scan", "cnf2_fixparents_scan", "cnf2_variances", "cnf2_variances_exact",
     "cnf2_snapshot_priors", "cnf2_update_pass", "cnf2_download_rows", "cnf2_download_accumulators", "cnf2_upload_accumulators", "cnf2_accumulator_ptrs", "cnf2_update_stats", "cnf2_update_stats_guided", "cnf2_addvariance", "cnf2_emission", "cnf2_emission_paths",
     "cnf2_selftest_lane_xor", "cnf2_last_kernel_ms", "cnf2_last_paths", "cnf2_workspace_bytes", "cnf2_reserve_accumulate", "cnf2_clock_probe", "cnf2_sweep_clock", "cnf2_stream",
     "cnf2_set_grid_reserve", "cnf2_set_batch_jobs", "cnf2_window_table", "cnf2_update_pass_records", "cnf2_exchange_buffer", "cnf2_exchange_download", "cnf2_exchange_upload", "cnf2_exchange_read", "cnf2_exchange_write",
@@ -113,6 +113,7 @@ def load():
         L.cnf2_sweep_turn_scan.argtypes = [vp, i32, i32, vp, vp, C.c_uint32]
         L.cnf2_fixparents_scan.argtypes = [vp, vp, i32, vp]
         L.cnf2_variances.argtypes = [vp, vp, i32, i32, vp]
+        L.cnf2_variances_exact.argtypes = [vp, vp, vp, i32, i32, vp]
         L.cnf2_snapshot_priors.argtypes = [vp, vp]
         L.cnf2_update_pass.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, C.c_uint32]
         L.cnf2_download_rows.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -421,6 +422,14 @@ class Context:
         v = np.zeros((len(recs), self.n_markers))
         self._chk(self.L.cnf2_variances(self.h, _p(recs), len(recs), (1 if ordered else 0) | (2 if brute else 0), _p(v)),
                   "cnf2_variances")
+        return v
+
+    def variances_exact(self, recs, markers, ordered=True):
+        """addvariance of (recs[q], markers[q]) with the reference's own rounding (cnf2_variances_exact)"""
+        recs, markers = np.ascontiguousarray(recs, np.int32), np.ascontiguousarray(markers, np.int32)
+        assert recs.shape == markers.shape
+        v = np.zeros(len(recs))
+        self._chk(self.L.cnf2_variances_exact(self.h, _p(recs), _p(markers), len(recs), 1 if ordered else 0, _p(v)), "cnf2_variances_exact")
         return v
 
     def snapshot_priors(self, has_prior):

@@ -1997,6 +1997,35 @@ int cnf2_variances(cnf2_ctx* ctx, const int32_t* recs, int n, int ordered, doubl
     return CNF2_OK;
 }
 
+// var_out[q] = addvariance of record recs[q] at marker markers[q] with the reference's own rounding (variance_exact)
+int cnf2_variances_exact(cnf2_ctx* ctx, const int32_t* recs, const int32_t* markers, int n, int ordered, double* var_out)
+{
+    if (!ctx || !recs || !markers || !var_out || n < 0) return fail(ctx, CNF2_ERR_ARG, "bad scan arguments");
+    if (!ctx->d_rho || !ctx->d_allele8 || ctx->ped.n_rec == 0) return fail(ctx, CNF2_ERR_STATE, "map, rows and pedigree must be uploaded first");
+    if (n == 0) return CNF2_OK;
+    for (int q = 0; q < n; q++)
+        if (markers[q] < 0 || markers[q] >= ctx->n_markers) return fail(ctx, CNF2_ERR_ARG, "marker out of range at %d", q);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slab = 1 << 20;
+    int       rc;
+    // per entry: the result, then (behind all results) its marker
+    if ((rc = ensure(ctx, &ctx->d_scratch, &ctx->scratch_cap, (size_t)(n < slab ? n : slab) * 2))) return rc;
+    for (int i0 = 0; i0 < n; i0 += slab) {
+        const int k = n - i0 < slab ? n - i0 : slab;
+        if ((rc = scan_windows(ctx, recs + i0, k, (ordered & 1) ? 1 : 2))) return rc;
+        int32_t* d_markers = (int32_t*)(ctx->d_scratch + k);
+        HIP_TRY(ctx, hipMemcpyAsync(d_markers, markers + i0, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        KernelParams p;
+        base_params(ctx, &p);
+        p.windows = ctx->d_scanwin;
+        launch_variance_exact(p, d_markers, k, ctx->d_scratch, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(var_out + i0, ctx->d_scratch, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CNF2_OK;
+}
+
 int cnf2_addvariance(cnf2_ctx* ctx, int ind, int chrom, double* var_out)
 {
     int rc = ready(ctx);

@@ -157,6 +157,7 @@ void launch_copy_rows_u8(const uint8_t* src, size_t src_stride, const int32_t* s
                          const int32_t* dst_idx, int n, size_t elems, hipStream_t stream);
 void launch_okvals(const KernelParams& p, int n_windows, uint8_t* out, hipStream_t stream);
 void launch_addvariance_batch(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
+void launch_variance_exact(const KernelParams& p, const int32_t* markers, int n, double* out, hipStream_t stream);
 void launch_variance_closed(const KernelParams& p, int n_windows, double* out, hipStream_t stream);
 // rows = false: the instantiation that forms no per-locus rows (p.dosage is not written; windows with tie groups can take
 // it too: the posterior weights do not see the tie rule)

@@ -2396,6 +2396,41 @@ void launch_variance_closed(const KernelParams& p, int n_windows, double* out, h
     hipLaunchKernelGGL(variance_closed_kernel, dim3((p.n_markers + 255) / 256, n_windows), dim3(256), 0, stream, p, out);
 }
 
+// addvariance for (window q of p.windows, markers[q]) with the reference's own rounding (variance_exact, cnf2_variance.h): four
+// lanes per entry, one per class of the reference's loops -- 32 768 additions each, in the reference's order --, the first of
+// them squares and adds the four.  out[q], NaN where the reference leaves the entry alone.  Called for the handful of markers
+// per (record, chromosome) that can win lockhaplos' comparison, never for all.
+__global__ __launch_bounds__(256) void variance_exact_kernel(KernelParams p, const int32_t* markers, int n, double* out)
+{
+    const int  t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int  k = t & 3;
+    const bool live = (t >> 2) < n;
+    const int  q = live ? t >> 2 : n - 1;
+    const Window w = p.windows[q];
+    const int    m = markers[q];
+    Slot slot[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) slot[j] = load_slot(p, w.row[j] < 0 ? 0 : w.row[j], m);
+    double ok, full;
+    variance_exact_class(w, slot, k >> 1, k & 1, &ok, &full);
+    double oks[4], fulls[4];
+    const int base = (threadIdx.x & 63) & ~3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        oks[j] = __shfl(ok, base + j);
+        fulls[j] = __shfl(full, base + j);
+    }
+    if (live && k == 0) {
+        bool         valid;
+        const double v = variance_exact_finish(oks, fulls, &valid);
+        out[q] = valid ? v : nan("");
+    }
+}
+void launch_variance_exact(const KernelParams& p, const int32_t* markers, int n, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(variance_exact_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream, p, markers, n, out);
+}
+
 // =====================================================================================
 // Batched HOT LOOP 2: every accumulator of cnF2freq.cpp:5416-5577 for one (job, marker)
 // per wavefront, from the posterior weights a STOREW sweep left behind, through the table form of cnf2_acctab.h:

@@ -19,6 +19,13 @@
 
 namespace cnf2 {
 
+// operations as written, none contracted into an FMA (the exact evaluation below depends on it)
+#if defined(__clang__)
+#define CNF2_FP_LITERAL _Pragma("clang fp contract(off)")
+#else
+#define CNF2_FP_LITERAL                                     // g++ on x86-64 without -mfma has nothing to contract with
+#endif
+
 struct VMatch {
     double base, msv;
     int    mv;
@@ -28,6 +35,7 @@ struct VMatch {
 // unknown incoming allele is not bound to the stored one (and so never turns the error odds into 1)
 CNF2_HD VMatch variance_match(int inmv, double sv, int mf, double sf)
 {
+    CNF2_FP_LITERAL
     VMatch m;
     bool   miss;
     if (inmv == 0) {
@@ -127,6 +135,125 @@ CNF2_HD double variance_closed(const Window& w, const Slot slot[7], bool* valid)
         }
     *valid = sum != 0.0;
     return 2.0 * sq;                                        // the two shift modes give the same classes
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same number with the reference's OWN rounding: lockhaplos (cnF2freq.cpp:3045-3081) takes the first marker of
+// strictly largest variance, and markers whose configurations are mirror images of each other (the alleles of two
+// parents exchanged, ...) have variances that are equal in exact arithmetic and differ in the reference by the rounding
+// of its sums -- which of them it locks is decided by those last bits.  So the markers that can win are evaluated once
+// more the way addvariance adds: 8 classes (shift mode, i & 1, flag2 & 1), each a serial sum over i, flag2 and the two
+// alleles of trackpossible's value, every value the product of the same factors in the same order
+// (cnF2freq.cpp:1191-1340 in NO_EQUIVALENCE mode; no operation contracted).  What makes that affordable: a value depends
+// on (i, flag2) only through which of 8 values each parent's line takes -- (firstpar of the parent, its allele index, the
+// traced grandparent's allele index) -- so the 16 384 values of a class are products of three table entries and the sums
+// are 32 768 additions in the reference's order.  The shift mode changes nothing in this mode: classes 4-7 repeat 0-3.
+// Bit-equal to the reference's variances[] on goldens G10 / G12 (tests/test_host_emission.py on the CPU,
+// tests/test_gpu_engine.py through cnf2_variances_exact).
+// ---------------------------------------------------------------------------------------------------------------------
+
+// trackpossible<false, NO_EQUIVALENCE> below the root: the recursion into parent P (genwidth 2) for incoming allele inmv
+// with error odds sv, the parent using allele index f2n_p and tracing grandparent firstpar_p, who uses allele index f2n_g
+CNF2_HD double variance_exact_line(const Window& w, const Slot slot[7], int P, int inmv, double sv, int firstpar_p, int f2n_p,
+                                   int f2n_g)
+{
+    CNF2_FP_LITERAL
+    const int sp = 1 + 3 * P;
+    if (!(w.flags[sp] & SLOT_PRESENT)) return 1.0 + sv;                    // cnF2freq.cpp:1043-1046
+    const bool   attop = (w.flags[sp] & SLOT_FOUNDER) != 0;                // cnF2freq.cpp:1120
+    const Slot&  d = slot[sp];
+    const VMatch m = variance_match(inmv, sv, f2n_p ? d.a1 : d.a0, f2n_p ? d.s1 : d.s0);
+    double       baseval = m.base, msv = m.msv;
+    if (attop) {                                                           // cnF2freq.cpp:1213-1221
+        baseval += msv;
+        msv = 0.0;
+    } else if (msv != 0.0) msv /= baseval;
+    baseval *= 0.5;                                                        // cnF2freq.cpp:1229-1233
+    if (baseval == 0.0 || attop) return baseval;                           // cnF2freq.cpp:1271
+    const int sg = sp + 1 + firstpar_p;                                    // only the traced line, cnF2freq.cpp:1291
+    double    up;
+    if (!(w.flags[sg] & SLOT_PRESENT)) up = 1.0 + msv;
+    else {
+        const Slot&  g = slot[sg];
+        const VMatch t = variance_match(m.mv, msv, f2n_g ? g.a1 : g.a0, f2n_g ? g.s1 : g.s0);
+        up = t.base;
+        up += t.msv;                                                       // genwidth 1: top of the line
+        up *= 0.5;
+    }
+    baseval *= up;                                                         // cnF2freq.cpp:1336-1340
+    return baseval;
+}
+
+// One class of addvariance's loops (cnF2freq.cpp:1514-1541): i & 1 = firstpar, flag2 & 1 = f2n; *ok the signed sum over the
+// two alleles (before fabs), *full the plain one
+CNF2_HD void variance_exact_class(const Window& w, const Slot slot[7], int firstpar, int f2n, double* ok_out, double* full_out)
+{
+    CNF2_FP_LITERAL
+    const Slot& root = slot[0];
+    const bool  attop = (w.flags[0] & SLOT_FOUNDER) != 0;
+    const int    mf = f2n ? root.a1 : root.a0, mo = f2n ? root.a0 : root.a1;
+    const double sf = f2n ? root.s1 : root.s0, so = f2n ? root.s0 : root.s1;
+    double base[2], lo[8], lt[2][8];
+    for (int al = 0; al < 2; al++) {
+        const VMatch m = variance_match(al ? root.a1 : root.a0, al ? root.s1 : root.s0, mf, sf);
+        double baseval = m.base, msv = m.msv;
+        if (attop) {
+            baseval += msv;
+            msv = 0.0;
+        } else if (msv != 0.0) msv /= baseval;
+        baseval *= 0.5;
+        if (baseval != 0.0 && !attop && so != 0.0) baseval *= (1.0 - so);  // cnF2freq.cpp:1298-1302
+        base[al] = baseval;
+        for (int k = 0; k < 8; k++)
+            lt[al][k] = attop ? 1.0 : variance_exact_line(w, slot, firstpar, m.mv, msv, k & 1, (k >> 1) & 1, k >> 2);
+    }
+    const double ssv = so != 0.0 ? so / (1.0 - so) : 0.0;
+    for (int k = 0; k < 8; k++) lo[k] = attop ? 1.0 : variance_exact_line(w, slot, firstpar ^ 1, mo, ssv, k & 1, (k >> 1) & 1, k >> 2);
+    double ok = 0.0, full = 0.0;
+    for (int i = firstpar; i < 128; i += 2) {
+        const int fp0 = (i >> 1) & 1, fp1 = (i >> 4) & 1;                  // firstpar of parent 0 / 1 (upflagit, cnF2freq.cpp:321-329)
+        for (int flag2 = f2n; flag2 < 128; flag2 += 2) {
+            if (flag2 & w.flag2ignore) continue;
+            const int b0 = (flag2 >> 1) & 7, b1 = (flag2 >> 4) & 7;
+            const int k0 = fp0 | ((b0 & 1) << 1) | (((b0 >> 1 >> fp0) & 1) << 2);
+            const int k1 = fp1 | ((b1 & 1) << 1) | (((b1 >> 1 >> fp1) & 1) << 2);
+            const int ko = firstpar ? k0 : k1, kt = firstpar ? k1 : k0;
+            for (int al = 0; al < 2; al++) {
+                double term = base[al];
+                if (term != 0.0 && !attop) {
+                    term *= lo[ko];                                        // cnF2freq.cpp:1322
+                    if (term != 0.0) term *= lt[al][kt];                   // cnF2freq.cpp:1336-1340
+                }
+                if (al) ok += term;
+                else ok -= term;
+                full += term;
+            }
+        }
+    }
+    *ok_out = ok;
+    *full_out = full;
+}
+
+// addvariance's result from the four class sums (the classes of shift mode 1 repeat those of shift mode 0)
+CNF2_HD double variance_exact_finish(const double ok[4], const double full[4], bool* valid)
+{
+    CNF2_FP_LITERAL
+    double sum = 0.0, sqsum = 0.0;
+    for (int s = 0; s < 2; s++)
+        for (int k = 0; k < 4; k++) {
+            const double a = fabs(ok[k]);
+            sum += full[k];
+            sqsum += a * a;
+        }
+    *valid = sum != 0.0;
+    return sqsum;
+}
+
+CNF2_HD double variance_exact(const Window& w, const Slot slot[7], bool* valid)
+{
+    double ok[4], full[4];
+    for (int k = 0; k < 4; k++) variance_exact_class(w, slot, k >> 1, k & 1, &ok[k], &full[k]);
+    return variance_exact_finish(ok, full, valid);
 }
 
 } // namespace cnf2

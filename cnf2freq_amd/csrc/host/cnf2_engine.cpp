@@ -591,31 +591,111 @@ void Engine::postmarkerdata_local(int indcount)
             }
     }
     lap("variances (GPU)");
-    // lockhaplos (cnF2freq.cpp:3045-3081): per chromosome, lock the phase at the marker of largest variance
+    // lockhaplos (cnF2freq.cpp:3045-3081): per chromosome, lock the phase at the first marker of STRICTLY largest variance.
+    // Markers whose genotype configurations are the same have the same variance to the bit in the reference, and markers whose
+    // configurations are mirror images of each other have variances that are equal in exact arithmetic and differ there by the
+    // rounding of the reference's sums: which one it locks is decided by those bits.  The closed form agrees with the
+    // reference's number to ~1e-9, so it says which markers CAN win (those within 1e-8 of the largest); when they hold more
+    // than one configuration, the first marker of each is evaluated once more with the reference's own additions in the
+    // reference's order (cnf2_variances_exact: its bits) and the reference's comparison is made on those.
+    struct Choice {
+        int bestpos;           // decided by the closed form alone (one configuration can win), -1: nothing to lock
+        int rep_first, rep_n;  // else: its entries among the exact evaluations
+    };
+    std::vector<Choice>               choice(recs.size() * (size_t)C);
+    std::vector<std::vector<int32_t>> reps_of(recs.size());
+#pragma omp parallel for schedule(dynamic, 16) num_threads(host_threads())
+    for (size_t q = 0; q < recs.size(); q++) {
+        const int r = recs[q];
+        // the window's members: a configuration is what they hold at the marker
+        int rel[7] = {r, P.inds[r].pars[0], -1, -1, P.inds[r].pars[1], -1, -1};
+        for (int p = 0; p < 2; p++)
+            if (rel[1 + 3 * p] >= 0) {
+                rel[2 + 3 * p] = P.inds[rel[1 + 3 * p]].pars[0];
+                rel[3 + 3 * p] = P.inds[rel[1 + 3 * p]].pars[1];
+            }
+        auto same_configuration = [&](int a, int b) {
+            for (int k = 0; k < 7; k++) {
+                if (rel[k] < 0) continue;
+                const Individual& X = P.inds[rel[k]];
+                if (X.allele[a * 2] != X.allele[b * 2] || X.allele[a * 2 + 1] != X.allele[b * 2 + 1] ||
+                    memcmp(&X.sure[a * 2], &X.sure[b * 2], 2 * sizeof(double)) != 0)
+                    return false;
+            }
+            return true;
+        };
+        const Individual& I = P.inds[r];
+        for (int c = 0; c < C; c++) {
+            int& ls = lockstart_[(size_t)r * C + c];
+            if (ls >= P.chromstarts[c + 1]) ls = 0;
+            Choice&      ch = choice[q * C + c];
+            const int    j0 = std::max(P.chromstarts[c], ls), j1 = P.chromstarts[c + 1];
+            const double* v = &variances_[(size_t)r * M];
+            double        best = 0;
+            for (int j = j0; j < j1; j++) best = std::max(best, v[j]);
+            const double can_win = best * (1.0 - 1e-8) - 1e-18;
+            ch.bestpos = -1;
+            ch.rep_first = (int)reps_of[q].size();
+            ch.rep_n = 0;
+            for (int j = j0; j < j1; j++) {
+                if (!(v[j] >= can_win)) continue;
+                // both alleles alike: the two terms of every path cancel exactly, there as here (0 never wins)
+                if (I.allele[j * 2] == I.allele[j * 2 + 1] && I.sure[j * 2] == I.sure[j * 2 + 1]) continue;
+                bool seen = false;
+                for (int k = 0; k < ch.rep_n && !seen; k++) seen = same_configuration(reps_of[q][ch.rep_first + k], j);
+                if (!seen) {
+                    reps_of[q].push_back(j);
+                    ch.rep_n++;
+                }
+            }
+            if (ch.rep_n == 1 && best > 1e-18) {            // one configuration can win: its first marker
+                ch.bestpos = reps_of[q][ch.rep_first];
+                reps_of[q].pop_back();
+                ch.rep_n = 0;
+            }
+        }
+    }
+    std::vector<int32_t> ex_rec, ex_marker;
+    std::vector<size_t>  ex_of(recs.size() + 1, 0);
+    for (size_t q = 0; q < recs.size(); q++) {
+        ex_of[q] = ex_rec.size();
+        ex_rec.insert(ex_rec.end(), reps_of[q].size(), recs[q]);
+        ex_marker.insert(ex_marker.end(), reps_of[q].begin(), reps_of[q].end());
+    }
+    std::vector<double> ex_var(ex_rec.size());
+    if (!ex_rec.empty())
+        check(cnf2_variances_exact(ctx, ex_rec.data(), ex_marker.data(), (int)ex_rec.size(), 1, ex_var.data()), "cnf2_variances_exact");
+    exact_variances_ = (long)ex_rec.size();
     // (records are independent; the messages of a run that is not quiet keep their order by running it on one thread)
-#pragma omp parallel for schedule(static) num_threads(host_threads()) if (opt.quiet)
+    long by_bits = 0;
+#pragma omp parallel for schedule(static) num_threads(host_threads()) reduction(+ : by_bits) if (opt.quiet)
     for (size_t q = 0; q < recs.size(); q++) {
         const int   r = recs[q];
         Individual& I = P.inds[r];
         for (int c = 0; c < C; c++) {
-            int& ls = lockstart_[(size_t)r * C + c];
-            if (ls >= P.chromstarts[c + 1]) ls = 0;
-            int    bestpos = -1;
-            double bestvar = 0;
-            // the reference takes the first marker of strictly largest variance.  Markers whose genotype configuration is
-            // the same have the same variance to the bit there; here the closed form agrees with it to ~1e-9 only, so a
-            // marker must beat the best one so far by more than that to replace it (ties go to the first, as there)
-            for (int j = std::max(P.chromstarts[c], ls); j != P.chromstarts[c + 1]; j++)
-                if (variances_[(size_t)r * M + j] > bestvar * (1.0 + 1e-8)) {
-                    bestpos = j;
-                    bestvar = variances_[(size_t)r * M + j];
+            const Choice& ch = choice[q * C + c];
+            int           bestpos = ch.bestpos;
+            double        bestvar = 0;
+            for (int k = 0; k < ch.rep_n; k++) {
+                const size_t e = ex_of[q] + ch.rep_first + k;
+                // NaN: the reference leaves the entry as it was
+                const double x = ex_var[e] == ex_var[e] ? ex_var[e] : variances_[(size_t)r * M + ex_marker[e]];
+                if (x > bestvar) {                          // cnF2freq.cpp:3058
+                    bestpos = ex_marker[e];
+                    bestvar = x;
                 }
+            }
+            if (ch.rep_n > 1) by_bits++;
             if (bestpos == -1) continue;
             if (!opt.quiet) printf("Fixing point: %d %d %d\n", I.n, c + 1, bestpos);
             I.hw[bestpos] = I.hw[bestpos] <= 0.5 ? 0 : 1;
-            ls = bestpos + 1;
+            lockstart_[(size_t)r * C + c] = bestpos + 1;
         }
     }
+    locked_by_bits_ = by_bits;
+    if (timing)
+        fprintf(stderr, "  [postmarkerdata] lockhaplos: %ld of %zu (record, chromosome) pairs held more than one configuration that could win; %ld entries summed in the reference's order\n",
+                locked_by_bits_, recs.size() * (size_t)C, exact_variances_);
     push_rows();
     lap("lockhaplos, rows to the device");
 }

@@ -139,6 +139,8 @@ private:
     std::vector<int>    descendants_, children_;
     std::vector<double> variances_;
     std::vector<int>    lockstart_;          // [inds][C]
+    long                locked_by_bits_ = 0;  // lockhaplos: (record, chromosome) pairs decided by the reference's own rounding
+    long                exact_variances_ = 0; //             entries evaluated for that
     double scalefactor_ = 0.013, entropyfactor_ = 1.0;   // cnF2freq.cpp:3573-3574
     int    oldhits_ = 0, oldhits2_ = 0, last_hits_ = 0;
     bool   rows_stale_ = false;   // the device rows were updated since they were last copied to the host

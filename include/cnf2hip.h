@@ -281,9 +281,16 @@ int cnf2_addvariance(cnf2_ctx *ctx, int ind, int chrom, double *var_out);
  *                        paths factorise per line; one thread per record x marker).  ordered bit 0: founder flags as fixtrees
  *                        has assigned them when the records are visited in ascending order (an ancestor's flag counts if its
  *                        record index is not above the record's own), else every flag; bit 1: brute force like
- *                        cnf2_addvariance (cross-check). */
+ *                        cnf2_addvariance (cross-check).
+ *  cnf2_variances_exact  var_out[n]: the entry of record recs[q] at marker markers[q] with the reference's OWN rounding -- the
+ *                        reference's additions in the reference's order (cnF2freq.cpp:1514-1541), bit-equal to its variances[]
+ *                        on goldens G10 / G12.  lockhaplos (cnF2freq.cpp:3056) takes the first marker of STRICTLY largest
+ *                        variance, and mirror-image configurations tie in exact arithmetic: which of them the reference locks
+ *                        is decided by the last bits of its sums, so the host evaluates the markers that can win through this
+ *                        entry (a handful per record and chromosome) and compares those. */
 int cnf2_fixparents_scan(cnf2_ctx *ctx, const int32_t *recs, int n, uint8_t *ok_out);
 int cnf2_variances(cnf2_ctx *ctx, const int32_t *recs, int n, int ordered, double *var_out);
+int cnf2_variances_exact(cnf2_ctx *ctx, const int32_t *recs, const int32_t *markers, int n, int ordered, double *var_out);
 
 /* Per-iteration parameter updates on the device (processinfprobs cnF2freq.cpp:4179-4323,
  * updatehaploweights 4533-4734, cappedgd 4040-4177 with an own 15-point Gauss-Legendre rule; toulbar2 and the phase

@@ -580,6 +580,25 @@ int shim_variance(int n_rec, const int32_t* par, const uint8_t* empty, const int
     return valid ? 1 : 0;
 }
 
+// the same entry summed in the reference's order (variance_exact): the reference's bits
+int shim_variance_exact(int n_rec, const int32_t* par, const uint8_t* empty, const int32_t* gen, const int32_t* row_of,
+                        const uint8_t* allele, const double* sure, const double* hw, int n_markers, int rec, int marker,
+                        double* out)
+{
+    HostPedigree P = make_ped(n_rec, par, empty, gen, row_of);
+    Window w;
+    derive_window(P, rec, &w, nullptr);
+    Slot slot[7];
+    for (int k = 0; k < 7; k++) {
+        const int row = w.row[k] < 0 ? 0 : w.row[k];
+        size_t i = (size_t)row * n_markers + marker;
+        slot[k] = unpack_slot((uint8_t)(allele[i * 2] | (allele[i * 2 + 1] << 4)), sure[i * 2], sure[i * 2 + 1], hw[i]);
+    }
+    bool valid;
+    *out = variance_exact(w, slot, &valid);
+    return valid ? 1 : 0;
+}
+
 // ---- per-iteration updates (cnf2_update.h) ----
 double shim_cap_step(double intended, double orig, double epsilon, int* hits, int breakathalf)
 {

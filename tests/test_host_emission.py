@@ -394,7 +394,7 @@ def test_closed_form_variance_matches_addvariance(shim, maker):
     ped.allele = ped.allele.copy()
     ped.allele[hit, 1] = 9
     o = oracle_ped(ped)
-    seen_none = seen_val = 0
+    seen_none = seen_val = differs = 0
     for rec in range(ped.n_rec):
         f2i = o.fixtrees(rec).flag2ignore
         for m in range(ped.n_markers):
@@ -409,4 +409,33 @@ def test_closed_form_variance_matches_addvariance(shim, maker):
                 # the value is a squared difference of two nearly equal sums: cancellation amplifies rounding
                 assert abs(got[0] - want) <= 1e-8 * abs(want) + 1e-18, (rec, m, got[0], want)
                 seen_val += 1
+            # variance_exact: the reference's additions in the reference's order -- the same bits (the oracle's are the
+            # reference's on goldens G10 / G12, tests/test_oracle_golden.py)
+            exact = np.zeros(1)
+            ok = shim.shim_variance_exact(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, rec, m, _p(exact))
+            assert ok == (0 if want is None else 1)
+            if want is not None:
+                assert exact[0] == want, (rec, m, exact[0], want)
+                differs += int(exact[0] != got[0])
     assert seen_val > 50
+    assert differs > 0, "the closed form has the reference's bits everywhere: the case proves nothing"
+
+
+def test_variance_exact_has_the_references_bits_on_the_goldens(shim):
+    """variance_exact (cnf2_variance.h: addvariance's additions in the reference's order) against the reference's OWN
+    variances[] on goldens G10 (oracle/_ref), every record and marker: equal to the bit."""
+    from conftest import load_golden, GOLDEN_CASES
+    total = 0
+    for case in GOLDEN_CASES:
+        ped, z = load_golden(case)
+        for rec in range(ped.n_rec):
+            for m in range(ped.n_markers):
+                want = z["variances"][rec, m]
+                got = np.zeros(1)
+                ok = shim.shim_variance_exact(*_ped_args(ped), _p(ped.allele), _p(ped.sure), _p(ped.hw), ped.n_markers, rec, m, _p(got))
+                if np.isnan(want):
+                    assert ok == 0
+                else:
+                    assert ok == 1 and got[0] == want, (case, rec, m, got[0], want)
+                    total += 1
+    assert total > 1500
