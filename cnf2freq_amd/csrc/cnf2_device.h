@@ -145,7 +145,7 @@ struct UpdateParams {
     unsigned long long* todo_counts;  // [todo_cap / 256 + 2] scratch of the packing
     size_t         todo_cap;      // flows per chunk of a scout = entries of todo
     int            mirror;        // certainties: run one flow per side where both values have evidence, the other is its mirror image
-    int            scout_passes;  // certainties: 2 = a short first scout pass and a second for the flows still going; 1 = one pass (A/B)
+    int            scout_passes;  // 2 = a short first scout pass and a second for the flows still going; 1 = one pass (A/B)
     int            literal_finish; // the flows set aside take one literal bisection step per round (rounds 3 / 4) instead of the guided bisection (A/B, cross-check)
     double*        flow_out;      // [n_rec][markers of chrom][2][2] new probabilities from the certainty flows
 };

@@ -418,6 +418,9 @@ __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* f
     }
 }
 
+#ifndef HAPLO_SCOUT_STEPS
+#define HAPLO_SCOUT_STEPS 8     /* steps of the weights' first scout pass (iteration probe's update passes / late iterations of a 1 500-family run against one pass: 1: +4 % / +4.5 %, 4: -1.5 % / -1.3 %, 8: -6 % / -2.6 %, 12: -5 % / 0, 16: -4.5 % / 0, 24: -4.5 % / +0.5 %; profiles/r05_zz_ab_haploweight_scout_two_passes.log) */
+#endif
 #ifndef FLOW_SCOUT_STEPS
 #define FLOW_SCOUT_STEPS 8      /* steps of the first scout pass (2: +5 %, 3: +2.5 %, 5: +2 %, 12: -0.3 %, 16: +0.6 % on 40 iterations, tools/ab_scout.py) */
 #endif
@@ -679,15 +682,17 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
             n_pinned = 1;
         } else {
             const SlopeTerms st = haplo_slope(h);
-            // (one pass: most weight flows scout for dozens of steps, so a second pass takes nearly all of them up again -- measured
-            // 1.2 % slower over 40 iterations, tools/ab_scout.py)
-            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, 1 << 30, !u.literal_finish);
+            // Two passes like the certainties' since the flows that reach their step size leave at step 0 (hand_over): what stays
+            // scouts for dozens of steps, a few lanes of every wavefront, and the second pass packs those 64 to a wavefront.
+            // (Round 4, before the hand-over, nearly every flow was still going after the first pass: one pass was 1.2 % faster.)
+            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, u.scout_passes == 2 ? HAPLO_SCOUT_STEPS : 1 << 30, !u.literal_finish);
             if (rs == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
             } else {
                 aside = true;
-                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it | (rs == 6 || u.literal_finish ? FLOW_LITERAL : 0ull);
+                e.item_steps = ((item0 + t) << 6) | (unsigned long long)f.it |
+                               (rs == 3 ? FLOW_SCOUTING : (rs == 6 || u.literal_finish ? FLOW_LITERAL : 0ull));
                 e.path = f.path;
                 e.similarity = similarity;
             }
@@ -699,6 +704,54 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
     }
     flow_hits(u.hits, hits);
     flow_stats(u.stats ? u.stats + 4 : nullptr, n_flows, (unsigned)evals, n_done, n_pinned);
+}
+
+// Second scout pass of the weights: the flows the first pass left scouting after HAPLO_SCOUT_STEPS steps, 64 of them per wavefront
+// (persistent, the finish pass's supply); a flow ends here or its slot is rewritten for the finish pass.
+__global__ CNF2_SCOUT_OCC __launch_bounds__(64) void haploweight_scout2_kernel(UpdateParams u, unsigned long long* next, HaploTodo* todo,
+                                                                unsigned long long item0, unsigned long long n_items)
+{
+    const StepControl         sc = {u.scalefactor, u.entropyfactor};
+    __shared__ HaploTodo  queue[FLOW_QUEUE];
+    FlowSupply<HaploTodo> q = {0ull, 0ull, 0, true};
+    int      hits = 0, evals_all = 0;
+    unsigned n_done = 0;
+    for (;;) {
+        flow_supply(&q, queue, next, (const HaploTodo*)todo, n_items, 64, FLOW_SCOUTING);
+        if (q.count == 0) break;
+        HaploTodo e;
+        if (flow_pop(&q, queue, true, &e)) {
+            const unsigned long long item = FLOW_ITEM(e);
+            size_t row_i, k;
+            int    r;
+            haplo_item(u, item, &row_i, &k, &r);
+            const double hw = u.hw[row_i];
+            HaploFlow    h;
+            haplo_flow_terms(hw, u.acc_hb[k], u.acc_hc[k], e.similarity, u.ratio[k], u.children[r], u.descendants[r], sc, &h);
+            FlowState f;
+            auto grad = [&](double x) CNF2_LI { return haplo_rgradient(h, x); };
+            flow_begin(&f, grad, hw, h.epsilon, sc.scalefactor, false);
+            flow_replay(&f, e.path, (int)(e.item_steps & 63));
+            const SlopeTerms st = haplo_slope(h);
+            int       evals = 0;
+            HaploTodo out;
+            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, 1 << 30, !u.literal_finish);
+            if (rs == 0) {
+                u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
+                out.item_steps = ~0ull;
+                out.path = 0;
+                n_done++;
+            } else {
+                out.item_steps = (item << 6) | (unsigned long long)f.it | (rs == 6 || u.literal_finish ? FLOW_LITERAL : 0ull);
+                out.path = f.path;
+            }
+            out.similarity = e.similarity;
+            todo[item - item0] = out;
+            evals_all += evals;
+        }
+    }
+    if (hits) atomicAdd(u.hits, hits);
+    flow_stats(u.stats ? u.stats + 4 : nullptr, 0u, (unsigned)evals_all, n_done, 0u);
 }
 
 __global__ CNF2_FINISH_OCC __launch_bounds__(64) void haploweight_finish_kernel(UpdateParams u, unsigned long long* next, const HaploTodo* todo,
@@ -1246,6 +1299,9 @@ void launch_update_pass(const UpdateParams& u, hipStream_t stream)
         hipLaunchKernelGGL(haploweight_scout_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, u, (unsigned long long)i0,
                            (unsigned long long)n, (HaploTodo*)u.todo);
         const size_t w = (n + 63) / 64;
+        if (u.scout_passes == 2)
+            hipLaunchKernelGGL(haploweight_scout2_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next + 1,
+                               (HaploTodo*)u.todo, (unsigned long long)i0, (unsigned long long)n);
         if (u.literal_finish)
             hipLaunchKernelGGL(haploweight_finish_kernel, dim3((unsigned)(w < resident ? w : resident)), dim3(64), 0, stream, u, u.flow_next,
                                (const HaploTodo*)u.todo, (unsigned long long)n, (const unsigned long long*)nullptr, FLOW_LITERAL);

@@ -82,8 +82,8 @@ enum {
     CNF2_UPDATE_BOTH_FLOWS = 1u << 16, /* cnf2_update_pass, fast form: run the certainty flow of BOTH allele values of a side, as
                                     processinfprobs does (cnF2freq.cpp:4222-4290), instead of one flow and its mirror image
                                     (DESIGN.md section 3.11).  The bit-exact form: equal to CNF2_UPDATE_PLAIN to the bit */
-    CNF2_UPDATE_ONE_SCOUT = 1u << 17, /* cnf2_update_pass, fast form: the certainties' scout in one pass instead of two (same
-                                    results to the bit; A/B switch, tools/ab_scout.py) */
+    CNF2_UPDATE_ONE_SCOUT = 1u << 17, /* cnf2_update_pass, fast form: the scouts (certainties and, since round 5, weights) in one pass
+                                    instead of two (same results to the bit; A/B switch, tools/ab_scout.py) */
     CNF2_UPDATE_LITERAL_FINISH = 1u << 19, /* cnf2_update_pass, fast form: the flows the scouts set aside take one literal bisection
                                     step (midpoint, bound, quadrature) per round, as in rounds 3 / 4, instead of the guided
                                     bisection (cnf2_update.h: the same decisions from 3 - 4 quadratures per flow).  Same
