@@ -500,7 +500,7 @@ struct SlopeTerms {
 #define CNF2_SCOUT_DEEP (1.0 / 1048576.0)  /* flow_scout, hand_over: Euler step / bracket under which a flow stays with the scout */
 #endif
 #ifndef CNF2_SCOUT_NEAR_ROOT
-#define CNF2_SCOUT_NEAR_ROOT 0.02          /* flow_scout, hand_over: (root - midpoint) / root under which a set-aside flow takes the step-per-round kernels */
+#define CNF2_SCOUT_NEAR_ROOT 0.002         /* flow_scout, hand_over: (root - midpoint) / root under which a set-aside flow takes the step-per-round kernels (0.02 -> 0.002: probe update passes -2.4 %, late iterations -0.5 %, config 5 x 100 103.0 -> 101.5 s; 0.1: +5 % early; profiles/r05_zz_ab_hand_over_thresholds.log) */
 #endif
 #ifndef CNF2_SCOUT_SATURATING
 #define CNF2_SCOUT_SATURATING 3.0          /* flow_scout, hand_over: slope towards the bracketed root x step size from which a set-aside flow takes the step-per-round kernels */

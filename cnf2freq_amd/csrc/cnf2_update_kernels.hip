@@ -471,6 +471,9 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(Upd
             } else {
                 const SlopeTerms st = certainty_slope(c);
                 const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30, !u.literal_finish);
+#ifdef CNF2_X_RC_HIST
+                if (u.stats && (r == 2 || r >= 4)) atomicAdd(u.stats + 20 + (r == 2 ? 0 : r - 3), 1ull);
+#endif
                 if (r == 0) {
                     int          h = 0;
                     const double out = flow_end(f, sc.scalefactor, &h, false);
@@ -524,6 +527,9 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(64) void certainty_scout2_kernel(Upd
             int evals = 0;
             FlowTodo out;
             const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, 1 << 30, !u.literal_finish);
+#ifdef CNF2_X_RC_HIST
+            if (u.stats && (rs == 2 || rs >= 4)) atomicAdd(u.stats + 20 + (rs == 2 ? 0 : rs - 3), 1ull);
+#endif
             if (rs == 0) {
                 int          h = 0;
                 const double res = flow_end(f, sc.scalefactor, &h, false);
@@ -1193,6 +1199,9 @@ __global__ CNF2_GUIDED_OCC __launch_bounds__(64) void guided_first_kernel(Update
         todo[t] = e;
     }
     flow_hits(u.hits, hits);
+#ifdef CNF2_X_RC_HIST
+    if (KIND == 0)
+#endif
     flow_stats(u.stats ? u.stats + (KIND == 0 ? 16 : 20) : nullptr, had ? g.points : 0u, had ? 5u : 0u, had ? g.evals : 0u, n_why1);
     }
 }
