@@ -422,7 +422,7 @@ __device__ __forceinline__ void certainty_store(const UpdateParams& u, double* f
 #define HAPLO_SCOUT_STEPS 8     /* steps of the weights' first scout pass (iteration probe's update passes / late iterations of a 1 500-family run against one pass: 1: +4 % / +4.5 %, 4: -1.5 % / -1.3 %, 8: -6 % / -2.6 %, 12: -5 % / 0, 16: -4.5 % / 0, 24: -4.5 % / +0.5 %; profiles/r05_zz_ab_haploweight_scout_two_passes.log) */
 #endif
 #ifndef FLOW_SCOUT_STEPS
-#define FLOW_SCOUT_STEPS 8      /* steps of the first scout pass (2: +5 %, 3: +2.5 %, 5: +2 %, 12: -0.3 %, 16: +0.6 % on 40 iterations, tools/ab_scout.py) */
+#define FLOW_SCOUT_STEPS 12     /* steps of the first scout pass (round 4, against 8: 2: +5 %, 3: +2.5 %, 5: +2 %, 12: -0.3 %, 16: +0.6 % on 40 iterations, tools/ab_scout.py; round 5, with the hand-over: 6: +1 % / +0.3 %, 12: -1.9 % / -0.4 % on the probe's update passes / late iterations, profiles/r05_zz_ab_haploweight_scout_two_passes.log) */
 #endif
 template <bool TWO_PASSES>
 __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(UpdateParams u, unsigned long long item0, unsigned long long n_items,
