@@ -694,7 +694,7 @@ void Engine::postmarkerdata_local(int indcount)
     }
     locked_by_bits_ = by_bits;
     if (timing)
-        fprintf(stderr, "  [postmarkerdata] lockhaplos: %ld of %zu (record, chromosome) pairs held more than one configuration that could win; %ld entries summed in the reference's order\n",
+        fprintf(stderr, "  [lockhaplos] %ld of %zu (record, chromosome) pairs held more than one configuration that could win; %ld entries summed in the reference's order\n",
                 locked_by_bits_, recs.size() * (size_t)C, exact_variances_);
     push_rows();
     lap("lockhaplos, rows to the device");
