@@ -20,7 +20,7 @@ ACC_LANES = 2048
 TIES_GENERAL = 4096
 UPDATE_PLAIN = 8192
 UPDATE_BOTH_FLOWS = 1 << 16       # both allele values' certainty flows (the bit-exact form of the fast update kernels)
-UPDATE_ONE_SCOUT = 1 << 17        # the certainties' scout in one pass (A/B)
+UPDATE_ONE_SCOUT = 1 << 17        # the scouts (certainties', weights') in one pass instead of two (A/B)
 UPDATE_LITERAL_FINISH = 1 << 19   # the set-aside flows one literal bisection step per round instead of the guided bisection (A/B)
 DETERMINISTIC = 16384
 TURN_VALU = 32768
