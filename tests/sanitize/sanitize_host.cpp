@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "cnf2_update.h"
+#include "cnf2_variance.h"
 #include "host/cnf2_format.h"
 #include "host/cnf2_partition.h"
 #include "host/cnf2_readers.h"
@@ -202,6 +203,39 @@ static int part_update()
     return diff ? fail("update") : 0;
 }
 
+// ---- addvariance: the closed form against the sums in the reference's order (variance_exact) on random windows
+static int part_variance()
+{
+    std::mt19937_64 rng(29);
+    auto   uni = [&] { return (double)(rng() >> 11) * (1.0 / 9007199254740992.0); };
+    size_t n = 0, off = 0;
+    for (int i = 0; i < 3000; i++) {
+        cnf2::Window w;
+        memset(&w, 0, sizeof(w));
+        cnf2::Slot slot[7];
+        for (int k = 0; k < 7; k++) {
+            static const int vals[4] = {0, 1, 2, 9};
+            slot[k].a0 = vals[rng() % 4];
+            slot[k].a1 = vals[rng() % 4];
+            slot[k].s0 = (rng() % 4 == 0) ? 0.0 : 0.2 * uni();
+            slot[k].s1 = (rng() % 4 == 0) ? 0.0 : 0.2 * uni();
+            slot[k].hw = uni();
+            w.row[k] = k;
+            w.flags[k] = (uint8_t)((rng() % 8 ? cnf2::SLOT_PRESENT : 0) | (rng() % 5 == 0 ? cnf2::SLOT_FOUNDER : 0));
+            w.tie[k] = -1;
+        }
+        w.flags[0] |= cnf2::SLOT_PRESENT;
+        w.flag2ignore = (uint8_t)(rng() % 3 == 0 ? rng() & 127 : 0);
+        bool         va, vb;
+        const double a = cnf2::variance_closed(w, slot, &va), b = cnf2::variance_exact(w, slot, &vb);
+        if (va != vb) return fail("variance: validity");
+        if (va && fabs(a - b) > 1e-8 * fabs(b) + 1e-18) off++;
+        n++;
+    }
+    printf("variance: %zu windows, %zu beyond 1e-8 between the closed form and the reference's order\n", n, off);
+    return off ? fail("variance") : 0;
+}
+
 // ---- the transport: one rank's part of the self-test of tests/shim, here with the ranks as threads
 static int transport_rank(ShmRegion* R, int rank, int world, int seg_doubles, int seg_bytes)
 {
@@ -262,6 +296,7 @@ int main(int argc, char** argv)
     rc |= part_format();
     rc |= part_partition();
     rc |= part_update();
+    rc |= part_variance();
     rc |= part_transport();
     rc |= part_readers(dir);
     if (!rc) printf("sanitize_host: ok\n");
