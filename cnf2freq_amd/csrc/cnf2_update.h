@@ -675,13 +675,18 @@ CNF2_UHD GradientRange flow_gradient_range(const SlopeTerms& s, double xa, doubl
 // max_steps: give up after that many steps of this call (returns 3: the flow is neither ended nor at a quadrature; its
 // completed steps are in f->it and f->path like for 2) -- the first of two scout passes runs a few steps of every flow,
 // the second the rest of the few that are still going, with wavefronts full of them.
+// find_root = false: no closing in on the root in this call (the far end's evaluation, the false-position loop, the
+// tightening): the first of two scout passes leaves it to the second.  A flow that is still going after the first pass's
+// steps starts again in the second and would find its root twice -- thirty evaluations, and the false-position loop as long
+// as the wavefront's slowest lane -- while the flows that do end within the first pass's steps end there by signs all the
+// same (probe's update passes -3.6 %, late iterations -2.6 %, profiles/r05_zzz_ab_first_pass_without_root.log).
 // hand_over: the flows set aside go to the guided bisection (below), which needs 3 - 4 quadratures wherever the gradient is
 // monotone, however far the scout has come: a flow whose gradient is monotone but whose steps the constant bound does not
 // settle is set aside at once (what the scout would spend on it -- the closing in on the root, a dozen evaluations --
 // buys the guided bisection nothing).
 template <class G>
 CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, double scalefactor, int* evaluations, int max_steps = 1 << 30,
-                        bool hand_over = false)
+                        bool hand_over = false, bool find_root = true)
 {
     const double eps = f->epsilon, top = 1.0 - f->epsilon;
     const double limit = scalefactor * (1.0 - 1e-3) * (1.0 - 1e-9);
@@ -770,7 +775,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         // instead of waiting for the bisection's own midpoints to bracket it.  (hand_over, i.e. the device kernels' form: a
         // wavefront's lanes then do their closing in together, once, and their steps are answered from what it left; found
         // step by step every lane reaches it at another step number and the wavefront runs the loop below up to five times.)
-        if (hand_over && step == 0 && mono && !refined && !(far_d < HUGE_VAL)) {
+        if (find_root && hand_over && step == 0 && mono && !refined && !(far_d < HUGE_VAL)) {
             const double xf = f->falling ? f->lo : f->hi, dd = (xf - f->orig) * dir;
             if (dd > 0.0 && xf >= eps && xf <= top) {
                 const double gf = flow_pace(rgradient, xf, eps);
@@ -779,7 +784,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
             }
         }
         // the root is bracketed by two solid facts: close in on it (false position, Illinois), each evaluation one more
-        if ((step == 3 || step == 6 || step == 10 || step == 15 || step == 21 || (hand_over && step == 0)) && mono && !refined &&
+        if (find_root && (step == 3 || step == 6 || step == 10 || step == 15 || step == 21 || (hand_over && step == 0)) && mono && !refined &&
             far_d < HUGE_VAL && near_g != 0.0) {
             refined = true;
             double dn = near_d, df = far_d, fn = near_g, ff = far_g;

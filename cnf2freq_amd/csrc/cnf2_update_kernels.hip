@@ -470,7 +470,7 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void certainty_scout_kernel(Upd
                 n_pinned = 1;
             } else {
                 const SlopeTerms st = certainty_slope(c);
-                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30, !u.literal_finish);
+                const int        r = flow_scout(&f, grad, st, sc.scalefactor, &evals, TWO_PASSES ? FLOW_SCOUT_STEPS : 1 << 30, !u.literal_finish, !TWO_PASSES);
 #ifdef CNF2_X_RC_HIST
                 if (u.stats && (r == 2 || r >= 4)) atomicAdd(u.stats + 20 + (r == 2 ? 0 : r - 3), 1ull);
 #endif
@@ -691,7 +691,8 @@ __global__ CNF2_SCOUT_OCC __launch_bounds__(256) void haploweight_scout_kernel(U
             // Two passes like the certainties' since the flows that reach their step size leave at step 0 (hand_over): what stays
             // scouts for dozens of steps, a few lanes of every wavefront, and the second pass packs those 64 to a wavefront.
             // (Round 4, before the hand-over, nearly every flow was still going after the first pass: one pass was 1.2 % faster.)
-            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, u.scout_passes == 2 ? HAPLO_SCOUT_STEPS : 1 << 30, !u.literal_finish);
+            const int rs = flow_scout(&f, grad, st, sc.scalefactor, &evals, u.scout_passes == 2 ? HAPLO_SCOUT_STEPS : 1 << 30, !u.literal_finish,
+                                      u.scout_passes != 2);
             if (rs == 0) {
                 u.hw[row_i] = flow_end(f, sc.scalefactor, &hits, false);
                 n_done = 1;
