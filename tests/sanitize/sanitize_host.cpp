@@ -170,7 +170,7 @@ static int part_update()
 {
     std::mt19937_64 rng(13);
     auto   uni = [&] { return (double)(rng() >> 11) * (1.0 / 9007199254740992.0); };
-    size_t diff = 0, n = 0;
+    size_t diff = 0, diff2 = 0, passes2 = 0, n = 0;
     for (int i = 0; i < 4000; i++) {
         const int    kind = (int)(rng() & 1);
         const double y = (i % 3 == 0) ? 0.02 + 0.96 * uni() : ((i % 3 == 1) ? pow(10.0, -5.0 + 3.5 * uni()) : 1.0 - pow(10.0, -5.0 + 3.5 * uni()));
@@ -197,10 +197,31 @@ static int part_update()
         const double a = cnf2::flow_step(grad, yy, eps, sf, &h1, false);
         const double b = cnf2::flow_step_guided(grad, st, yy, eps, sf, &h2, false);
         diff += (a != b) || (h1 != h2);
+        // the device kernels' two scout passes: 8 steps without closing in on the root, the flows still going begun again and
+        // scouted to their end (or to the step that needs a quadrature: literal steps from there)
+        cnf2::FlowState f;
+        cnf2::flow_begin(&f, grad, yy, eps, sf, false);
+        int h3 = 0;
+        if (!f.pinned) {
+            int ev = 0;
+            int rs = cnf2::flow_scout(&f, grad, st, sf, &ev, 8, true, false);
+            if (rs == 3) {
+                const unsigned long long path = f.path;
+                const int                it = f.it;
+                cnf2::flow_begin(&f, grad, yy, eps, sf, false);
+                cnf2::flow_replay(&f, path, it);
+                rs = cnf2::flow_scout(&f, grad, st, sf, &ev, 1 << 30, true, true);
+                passes2++;
+            }
+        }
+        while (cnf2::flow_advance(&f, grad, sf)) {}
+        const double c2 = cnf2::flow_end(f, sf, &h3, false);
+        diff2 += (a != c2) || (h1 != h3);
         n++;
     }
-    printf("update: %zu flows, %zu differ between the literal and the guided bisection\n", n, diff);
-    return diff ? fail("update") : 0;
+    printf("update: %zu flows, %zu differ between the literal and the guided bisection, %zu between the literal and the two scout passes (%zu went into the second)\n",
+           n, diff, diff2, passes2);
+    return (diff || diff2) ? fail("update") : 0;
 }
 
 // ---- addvariance: the closed form against the sums in the reference's order (variance_exact) on random windows
