@@ -505,6 +505,9 @@ struct SlopeTerms {
 #ifndef CNF2_SCOUT_SATURATING
 #define CNF2_SCOUT_SATURATING 3.0          /* flow_scout, hand_over: slope towards the bracketed root x step size from which a set-aside flow takes the step-per-round kernels */
 #endif
+#ifndef CNF2_SCOUT_MONO_AT
+#define CNF2_SCOUT_MONO_AT(step) (step == 0 || step == 1 || step == 2 || step == 4 || step == 7 || step == 11 || step == 16)   /* flow_scout: the steps at which the monotonicity proof is tried (again) */
+#endif
 #ifndef CNF2_SCOUT_KEEP
 #define CNF2_SCOUT_KEEP 0.6                /* flow_scout, hand_over: slope x step size from which a flow stays with the scout */
 #endif
@@ -729,7 +732,7 @@ CNF2_UHD int flow_scout(FlowState* f, G&& rgradient, const SlopeTerms& st, doubl
         }
         if (step >= max_steps) return 3;
         // is the gradient monotone on the bracket (and on the way from the start)?  Tried while the bracket shrinks.
-        if (step == 0 || step == 1 || step == 2 || step == 4 || step == 7 || step == 11 || step == 16) {
+        if (CNF2_SCOUT_MONO_AT(step)) {
             if (!mono && f->lo >= eps && f->hi <= top) {
                 const double xa = f->lo < f->orig ? f->lo : f->orig, xb = f->hi > f->orig ? f->hi : f->orig;
                 B = flow_interval(st, xa, xb, true);
